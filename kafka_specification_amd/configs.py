@@ -1,0 +1,53 @@
+"""Named model configurations: the BASELINE.json ladder and the set of constants whose
+kernels `build()` specialises ahead of time (anything else is specialised on first use)."""
+from .checker import CheckerConfig
+
+KAFKA = ("KafkaTruncateToHighWatermark", "Kip101", "Kip279", "Kip320", "Kip320FirstTry")
+
+# BASELINE.json configs.  KafkaReplication.tla has no Next, so "KafkaReplication,
+# 3 brokers, maxLogLen=6" is bound to root module Kip320; MaxRecords / MaxLeaderEpoch are not
+# pinned by BASELINE.json and are stated with every number.
+HEADLINE = dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=2,
+                invariants=("TypeOk", "WeakIsr", "StrongIsr"))
+BASELINE_CONFIGS = {
+    "config0_idsequence": dict(model="IdSequence", max_id=1000, invariants=("TypeOk",)),
+    "config1_finite_replicated_log": dict(model="FiniteReplicatedLog", n_replicas=2, log_size=4, n_log_records=4,
+                                          invariants=("TypeOk",)),
+    "config2_headline_kip320_3brokers_log6": HEADLINE,
+    "config3_kip279_5brokers": dict(model="Kip279", n_replicas=5, log_size=2, max_records=2, max_leader_epoch=2,
+                                    invariants=("TypeOk",)),
+    "config4_kip320_7brokers_log8": dict(model="Kip320", n_replicas=7, log_size=8, max_records=8,
+                                         max_leader_epoch=3, invariants=("TypeOk",)),
+}
+
+
+def precompile_list():
+    out = []
+    for m in KAFKA:
+        for (N, L, R, E) in [(2, 2, 2, 1), (3, 2, 2, 1), (3, 1, 1, 2), (2, 3, 3, 2), (3, 2, 2, 2)]:
+            out.append(dict(model=m, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E))
+    out += [dict(model="Kip320", n_replicas=3, log_size=3, max_records=3, max_leader_epoch=2),
+            dict(model="KafkaTruncateToHighWatermark", n_replicas=3, log_size=3, max_records=3, max_leader_epoch=1),
+            dict(model="Kip279", n_replicas=3, log_size=2, max_records=3, max_leader_epoch=2),
+            dict(model="Kip101", n_replicas=3, log_size=3, max_records=2, max_leader_epoch=2),
+            dict(model="Kip320FirstTry", n_replicas=3, log_size=3, max_records=3, max_leader_epoch=1),
+            dict(model="Kip320", n_replicas=3, log_size=4, max_records=4, max_leader_epoch=2),
+            dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=1),
+            dict(model="Kip320", n_replicas=3, log_size=5, max_records=5, max_leader_epoch=2)]
+    for M in (0, 1, 10, 1000):
+        out.append(dict(model="IdSequence", max_id=M))
+    for K in (1, 2, 3, 4):
+        out.append(dict(model="FiniteReplicatedLog", n_replicas=2, log_size=4, n_log_records=K))
+    for c in BASELINE_CONFIGS.values():
+        out.append({k: v for k, v in c.items() if k != "invariants"})
+    seen, uniq = set(), []
+    for c in out:
+        key = tuple(sorted(c.items()))
+        if key not in seen:
+            seen.add(key)
+            uniq.append(c)
+    return uniq
+
+
+def all_precompile_configs():
+    return [CheckerConfig(**c) for c in precompile_list()]

@@ -1,0 +1,847 @@
+// kmc_device.h — gfx950 device code of the model checker: the Next-state relations and
+// invariants of the Kafka replication specs lowered onto the bit-packed state vector of
+// kmc_layout.h, and the BFS level kernels.  Written for wave64 CDNA4 only.
+//
+// Specialisation: everything is a template over one (model, N, L, R, E[, K]); the host
+// engine instantiates exactly one configuration per code object with KMC_INSTANTIATE (via
+// hiprtc), so every bit offset, loop bound and action-instance index below is a compile-time
+// constant and a packed state lives in W 64-bit registers per lane.
+//
+// Kernel shape (k_expand): one wavefront lane per frontier state.
+//   * coalesced loads of the SoA frontier planes (plane k, state i at fin[k*stride+i]);
+//   * the action instances of `Next` (every binding of the specs' \E over replicas /
+//     requests) are walked in a wave-uniform loop; a scalar binary dispatch jumps to the
+//     statically specialised guard+effect of instance i, so lanes never diverge on *which*
+//     action they evaluate, only on whether it is enabled;
+//   * enabled successors are compacted with __ballot + mbcnt prefix ranks into a per-wave
+//     LDS ring (SoA, conflict-free), which write-combines them until 64 are queued;
+//   * a flush drains exactly 64 successors, one per lane, so the random HBM probes of the
+//     fingerprint table always run with a full wave of independent requests in flight:
+//     64-bit mix hash -> open-addressed linear probe -> atomicCAS(0 -> fp) claim;
+//   * winners check the invariants and append the state to the next frontier through one
+//     wave-aggregated atomicAdd, written as coalesced SoA planes.
+// The seen-set replaces tlc2.tool.fp.FPSet, the frontier arrays replace
+// tlc2.tool.queue.StateQueue and this loop replaces tlc2.tool.Worker.run [TLC-recall; TLC is
+// not part of /root/reference].
+#pragma once
+#include "kmc_layout.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define KMC_DEV __device__ __forceinline__
+
+#define KMC_MODE_LOCAL 0u    // probe/insert the local table, append winners to the next frontier
+#define KMC_MODE_SHARDED 1u  // bucket successors by owner(fp) into per-destination send buffers
+#define KMC_MODE_ENUM 2u     // write every successor (state, fp, kind) to a list: trace replay
+
+#define KMC_ERR_FRONTIER_FULL 1u
+#define KMC_ERR_TABLE_FULL 2u
+#define KMC_ERR_SEND_FULL 4u
+#define KMC_ERR_ENUM_FULL 8u
+
+#define KMC_FLAG_TRACE 1u
+
+#define KMC_MAX_KINDS 16
+#define KMC_MAX_SHARDS 8
+#define KMC_QCAP 128  // per-wave LDS ring capacity (successors); flush granularity is 64
+
+// One per BFS level; the host zeroes it before the level runs and reads it back after.
+struct KmcLevelCtl {
+    u64 next_count;                  // states appended to the next frontier
+    u64 generated[KMC_MAX_KINDS];    // successors generated per action kind (Next disjunct)
+    u64 viol_count[4];               // new states violating invariant k
+    u64 viol_fp_inv[4];              // max over violators of ~fp  (=> min fp), 0 = none
+    u64 deadlock_count;              // expanded states without any successor
+    u64 deadlock_fp_inv;
+    u64 send_count[KMC_MAX_SHARDS];  // SHARDED: records bucketed per destination
+    u64 enum_count;                  // ENUM: records written
+    u64 inserted;                    // table claims (== next_count unless the frontier overflowed)
+    u32 err;
+    u32 pad;
+};
+
+struct KmcArgs {
+    const u64* fin;    // current frontier, SoA planes
+    u64 fin_stride;    // plane stride in states
+    u64 n_in;          // number of states in the current frontier (k_expand) / records (k_insert)
+    u64* fout;         // next frontier, SoA planes
+    u64 fout_stride;
+    u64 fout_cap;
+    u64* table;        // open-addressed fingerprint table, 0 = empty
+    u64 table_mask;    // capacity-1 (capacity is a power of two)
+    u64* pred;         // optional: predecessor fingerprint per table slot (trace reconstruction)
+    KmcLevelCtl* ctl;
+    u64 seed;
+    u64* send;         // SHARDED: [shard][send_cap] AoS records of W+1 words (state, parent fp)
+    u64 send_cap;      //          also the ENUM output list: records of W+2 words (state, fp, kind)
+    const u64* recv;   // k_insert input: AoS records of W+1 words
+    u32 inv_mask;
+    u32 mode;
+    u32 flags;
+    u32 nshards;
+};
+
+// ----------------------------------------------------------------------------------------
+// small compile-time helpers
+// ----------------------------------------------------------------------------------------
+template <int V> struct KmcIC { static constexpr int value = V; };
+
+template <int LO, int HI, class F> KMC_DEV void kmc_static_for(F&& f) {
+    if constexpr (LO < HI) {
+        f(KmcIC<LO>{});
+        kmc_static_for<LO + 1, HI>(f);
+    }
+}
+// wave-uniform binary dispatch of a runtime index onto a compile-time constant
+template <int LO, int HI, class F> KMC_DEV void kmc_dispatch(int i, F&& f) {
+    if constexpr (HI - LO == 1) {
+        f(KmcIC<LO>{});
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (i < MID) kmc_dispatch<LO, MID>(i, f);
+        else kmc_dispatch<MID, HI>(i, f);
+    }
+}
+
+KMC_DEV u32 kmc_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+KMC_DEV u32 kmc_rank_in(u64 mask) {  // number of set bits of mask below this lane
+    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+KMC_DEV u64 kmc_bcast64(u64 v, int src) {
+    u32 lo = __builtin_amdgcn_readlane((u32)v, src), hi = __builtin_amdgcn_readlane((u32)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+KMC_DEV u32 kmc_min(u32 a, u32 b) { return a < b ? a : b; }
+// Opaque redefinition: stops LICM from hoisting every action instance's guard/effect out of
+// the instance loop (they only depend on the loop-invariant state), which would keep all of
+// them live at once and cost the kernel its occupancy.
+KMC_DEV void kmc_launder(u32& x) { asm volatile("" : "+v"(x)); }
+KMC_DEV void kmc_launder(u64& x) { asm volatile("" : "+v"(x)); }
+
+// 64-bit fingerprint of a packed state.  Never 0 (0 marks an empty table slot).
+template <int W> KMC_HD inline u64 kmc_fingerprint(const u64* w, u64 seed) {
+    u64 h = seed ^ (0x9E3779B97F4A7C15ull * (u64)(W + 1));
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        h ^= w[k];
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+    }
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 29;
+    h *= 0xbf58476d1ce4e5b9ull;
+    h ^= h >> 32;
+    return h ? h : 1ull;
+}
+KMC_HD inline u32 kmc_owner(u64 fp, u32 nshards) { return (u32)((fp >> 40) % nshards); }
+
+// ========================================================================================
+// IdSequence.tla standalone
+// ========================================================================================
+template <long long MAXID> struct KmcIdSequence {
+    static constexpr int W = 1, NKINDS = 1, NINST = 1;
+    struct Pre { u64 nextId; };
+    static KMC_DEV void init(u64* w) { w[0] = 0; }  // IdSequence.tla:37
+    static KMC_DEV Pre extract(const u64* s) { return Pre{s[0]}; }
+    static KMC_DEV void launder(Pre& p) { kmc_launder(p.nextId); }
+    template <int I> static KMC_DEV bool inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
+        // Next == \E id \in IdSet : NextId(id)   (IdSequence.tla:39, NextId :30-33)
+        kind = 0; extra = 0;
+        t[0] = p.nextId + 1;
+        return (long long)p.nextId <= MAXID;
+    }
+    static KMC_DEV u32 violated(const u64* t, u32 inv_mask) {  // TypeOk, IdSequence.tla:43
+        return (inv_mask & 1u) && !((long long)t[0] <= MAXID + 1) ? 1u : 0u;
+    }
+};
+
+// ========================================================================================
+// FiniteReplicatedLog.tla standalone
+// ========================================================================================
+template <int N, int L, int K> struct KmcFiniteReplicatedLog {
+    static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_FINITE_REPLICATED_LOG, N, L, 0, 0, K);
+    static_assert(Y.valid, "FiniteReplicatedLog parameters cannot be packed");
+    static constexpr int W = Y.W, NKINDS = 3;
+    static constexpr int C_APPEND = N * K, C_TRUNC = N * L, C_REPL = N * (N - 1);
+    static constexpr int NINST = C_APPEND + C_TRUNC + C_REPL;
+    static constexpr u64 MR = (1ull << Y.BR) - 1;
+    struct Pre { u32 end[N]; u64 logv[N]; };
+
+    static KMC_DEV void init(u64* w) {  // FiniteReplicatedLog.tla:97
+        for (int k = 0; k < W; ++k) w[k] = 0;
+    }
+    static KMC_DEV Pre extract(const u64* s) {
+        Pre p;
+        kmc_static_for<0, N>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            p.end[r] = (u32)kmc_getbits(s, Y.end_off[r], Y.BO);
+            p.logv[r] = kmc_getbits(s, Y.log_off[r], Y.BR * L);
+        });
+        return p;
+    }
+    static KMC_DEV void launder(Pre& p) {
+        for (int r = 0; r < N; ++r) { kmc_launder(p.end[r]); kmc_launder(p.logv[r]); }
+    }
+    template <int I> static KMC_DEV bool inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
+        extra = 0;
+        for (int k = 0; k < W; ++k) t[k] = s[k];
+        if constexpr (I < C_APPEND) {
+            // \E record, offset : Append(replica, record, offset)   (:116, :99-103)
+            constexpr int r = I / K, rec = I % K + 1;
+            kind = 0;
+            const u32 end = p.end[r];
+            kmc_setbits(t, Y.log_off[r], Y.BR * L, p.logv[r] | ((u64)rec << (end * Y.BR)));
+            kmc_setbits(t, Y.end_off[r], Y.BO, end + 1);
+            return end < (u32)L;
+        } else if constexpr (I < C_APPEND + C_TRUNC) {
+            // \E offset \in Offsets : TruncateTo(replica, offset)   (:117, :105-109)
+            constexpr int J = I - C_APPEND, r = J / L, o = J % L;
+            kind = 1;
+            constexpr u64 keep = (o * Y.BR >= 64) ? ~0ull : ((1ull << (o * Y.BR)) - 1ull);
+            kmc_setbits(t, Y.log_off[r], Y.BR * L, p.logv[r] & keep);
+            kmc_setbits(t, Y.end_off[r], Y.BO, o);
+            return (u32)o <= p.end[r];
+        } else {
+            // \E other # replica : ReplicateTo(replica, other)   (:118, :111-113)
+            constexpr int J = I - C_APPEND - C_TRUNC, from = J / (N - 1), q = J % (N - 1), to = q + (q >= from);
+            kind = 2;
+            const u32 eto = p.end[to];
+            const u64 rec = (p.logv[from] >> (eto * Y.BR)) & MR;
+            kmc_setbits(t, Y.log_off[to], Y.BR * L, p.logv[to] | (rec << (eto * Y.BR)));
+            kmc_setbits(t, Y.end_off[to], Y.BO, eto + 1);
+            return eto < p.end[from] && eto < (u32)L;
+        }
+    }
+    static KMC_DEV u32 violated(const u64* t, u32 inv_mask) {  // TypeOk, :90-95
+        if (!(inv_mask & 1u)) return 0;
+        bool ok = true;
+        const Pre p = extract(t);
+        kmc_static_for<0, N>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            ok = ok && p.end[r] <= (u32)L;
+            kmc_static_for<0, L>([&](auto O) {
+                constexpr int o = decltype(O)::value;
+                const u32 c = (u32)((p.logv[r] >> (o * Y.BR)) & MR);
+                ok = ok && c <= (u32)K && ((u32)o < p.end[r] ? c != 0 : c == 0);
+            });
+        });
+        return ok ? 0u : 1u;
+    }
+};
+
+// ========================================================================================
+// KafkaReplication.tla and the five modules that give it a Next
+// ========================================================================================
+template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
+    static constexpr KmcLayout Y = kmc_make_layout(MODEL, N, L, R, E, 0);
+    static_assert(Y.valid, "Kafka model parameters cannot be packed (need L*bits(record) <= 64, N <= 8, E <= 7)");
+    static constexpr int W = Y.W;
+    static constexpr bool FIRST = MODEL == KMC_MODEL_KIP320_FIRST_TRY;
+    static constexpr bool K320 = MODEL == KMC_MODEL_KIP320;
+    static constexpr int NKINDS = FIRST ? 10 : 9;
+    static constexpr int NP = N * (N - 1);  // ordered pairs of distinct replicas
+    // action instances, in the order of the Next disjuncts (the index of the disjunct is
+    // the "kind"): KafkaTruncateToHighWatermark.tla:33-42, Kip101.tla:49-58, Kip279.tla:53-62,
+    // Kip320.tla:150-159, Kip320FirstTry.tla:159-169
+    static constexpr int B0 = 0;                    // ControllerElectLeader          (newLeader)
+    static constexpr int B1 = B0 + N;               // ControllerShrinkIsr            (replica)
+    static constexpr int B2 = B1 + N;               // BecomeLeader                   (request epoch, leader)
+    static constexpr int B3 = B2 + (E + 1) * N;     // Leader*ExpandIsr*              (leader, replica) incl. replica = leader
+    static constexpr int B4 = B3 + N * N;           // Leader*ShrinkIsr*              (leader, replica # leader)
+    static constexpr int B5 = B4 + NP;              // LeaderWrite                    (replica)
+    static constexpr int B6 = B5 + N;               // *LeaderIncHighWatermark        (leader)
+    static constexpr int B7 = B6 + N;               // BecomeFollower*                (leader, replica # leader, request epoch)
+    static constexpr int B8 = B7 + NP * (E + 1);    // FollowerReplicate / *Fetch     (leader, follower # leader)
+    static constexpr int B9 = B8 + NP;              // FollowerTruncate (Kip320FirstTry only)
+    static constexpr int NINST = B9 + (FIRST ? NP : 0);
+
+    static constexpr u64 MR = (1ull << Y.BR) - 1;    // one record
+    static constexpr u32 MEr = (1u << Y.BEr) - 1;    // record.epoch
+    static constexpr u32 FULL = (1u << N) - 1;
+
+    struct Pre {
+        u32 end[N], hw[N], ep1[N], ldr1[N], isr[N];
+        u64 logv[N];
+        u32 nextRec, nextEp, qep1, qldr1, qisr;
+        u32 rldr1[E + 1], risr[E + 1];
+    };
+
+    static KMC_DEV void init(u64* w) {  // Init, KafkaReplication.tla:109-120
+        for (int k = 0; k < W; ++k) w[k] = 0;
+        kmc_setbits(w, Y.qisr_off, Y.BI, FULL);  // quorumState.isr = Replicas (:119)
+    }
+
+    static KMC_DEV Pre extract(const u64* s) {
+        Pre p;
+        kmc_static_for<0, N>([&](auto RR) {
+            constexpr int r = decltype(RR)::value;
+            p.logv[r] = kmc_getbits(s, Y.log_off[r], Y.BR * L);
+            p.end[r] = (u32)kmc_getbits(s, Y.end_off[r], Y.BO);
+            p.hw[r] = (u32)kmc_getbits(s, Y.hw_off[r], Y.BO);
+            p.ep1[r] = (u32)kmc_getbits(s, Y.ep_off[r], Y.BE);
+            p.ldr1[r] = (u32)kmc_getbits(s, Y.ldr_off[r], Y.BL);
+            p.isr[r] = (u32)kmc_getbits(s, Y.isr_off[r], Y.BI);
+        });
+        p.nextRec = (u32)kmc_getbits(s, Y.nextrec_off, Y.BNR);
+        p.nextEp = (u32)kmc_getbits(s, Y.nextep_off, Y.BE);
+        p.qep1 = (u32)kmc_getbits(s, Y.qep_off, Y.BE);
+        p.qldr1 = (u32)kmc_getbits(s, Y.qldr_off, Y.BL);
+        p.qisr = (u32)kmc_getbits(s, Y.qisr_off, Y.BI);
+        kmc_static_for<0, E + 1>([&](auto EE) {
+            constexpr int e = decltype(EE)::value;
+            p.rldr1[e] = (u32)kmc_getbits(s, Y.reqldr_off[e], Y.BL);
+            p.risr[e] = (u32)kmc_getbits(s, Y.reqisr_off[e], Y.BI);
+        });
+        return p;
+    }
+
+    static KMC_DEV void launder(Pre& p) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            kmc_launder(p.end[r]); kmc_launder(p.hw[r]); kmc_launder(p.ep1[r]); kmc_launder(p.ldr1[r]);
+            kmc_launder(p.isr[r]); kmc_launder(p.logv[r]);
+        }
+        kmc_launder(p.nextRec); kmc_launder(p.nextEp); kmc_launder(p.qep1); kmc_launder(p.qldr1); kmc_launder(p.qisr);
+#pragma unroll
+        for (int e = 0; e <= E; ++e) { kmc_launder(p.rldr1[e]); kmc_launder(p.risr[e]); }
+    }
+
+    // ---- log helpers (FiniteReplicatedLog.tla as instantiated at KafkaReplication.tla:84) ----
+    static KMC_DEV u32 rec_at(u64 logv, u32 o) { return (u32)((logv >> (o * Y.BR)) & MR); }
+    static KMC_DEV u32 rec_epoch(u32 rec) { return rec & MEr; }
+    static KMC_DEV u64 keep_below(u32 off) {  // mask of the slots < off
+        const u32 sh = off * Y.BR;
+        return sh >= 64 ? ~0ull : ((1ull << sh) - 1ull);
+    }
+    // TruncateTo(replica, off) for off <= end (FiniteReplicatedLog.tla:105-109)
+    template <int r> static KMC_DEV void truncate(u64* t, const Pre& p, u32 off) {
+        kmc_setbits(t, Y.log_off[r], Y.BR * L, p.logv[r] & keep_below(off));
+        kmc_setbits(t, Y.end_off[r], Y.BO, off);
+    }
+
+    // ---- predicates (KafkaReplication.tla:126-131) ----
+    template <int r> static KMC_DEV bool presumes(const Pre& p) { return p.ldr1[r] == (u32)(r + 1); }
+    template <int l> static KMC_DEV bool is_true_leader(const Pre& p) {
+        return p.qldr1 == (u32)(l + 1) && presumes<l>(p) && p.ep1[l] == p.qep1;
+    }
+
+    // ControllerUpdateIsr(newLeader, newIsr) (:138-145); the guard nextLeaderEpoch <= E is the caller's
+    static KMC_DEV void controller_update(u64* t, const Pre& p, u32 newLdr1, u32 newIsr) {
+        kmc_setbits(t, Y.qep_off, Y.BE, p.nextEp + 1);
+        kmc_setbits(t, Y.qldr_off, Y.BL, newLdr1);
+        kmc_setbits(t, Y.qisr_off, Y.BI, newIsr);
+        kmc_static_for<0, E + 1>([&](auto EE) {
+            constexpr int e = decltype(EE)::value;
+            if (p.nextEp == (u32)e) {
+                kmc_setbits(t, Y.reqldr_off[e], Y.BL, newLdr1);
+                kmc_setbits(t, Y.reqisr_off[e], Y.BI, newIsr);
+            }
+        });
+        kmc_setbits(t, Y.nextep_off, Y.BE, p.nextEp + 1);
+    }
+    // QuorumUpdateLeaderAndIsr(leader, newIsr) effect (:213-217)
+    template <int l> static KMC_DEV void quorum_update(u64* t, u32 newIsr) {
+        kmc_setbits(t, Y.qisr_off, Y.BI, newIsr);
+        kmc_setbits(t, Y.isr_off[l], Y.BI, newIsr);
+    }
+    // IsFollowerCaughtUp(leader, follower, endOffset) (:219-225): the \E record is satisfied by
+    // the leader's own record at endOffset-1 whenever that offset is below its end.
+    template <int l, int f> static KMC_DEV bool caught_up(const Pre& p, u32 endOffset) {
+        return p.ldr1[f] == (u32)(l + 1) && endOffset <= p.end[l] && endOffset <= p.end[f];
+    }
+    // Kip320.tla:39-42
+    template <int l, int f> static KMC_DEV bool following_epoch(const Pre& p) {
+        return presumes<l>(p) && p.ldr1[f] == (u32)(l + 1) && p.ep1[f] == p.ep1[l];
+    }
+    // HasHighWatermarkReachedCurrentEpoch (Kip320.tla:87-92, Kip320FirstTry.tla:122-127)
+    template <int l> static KMC_DEV bool hw_reached_epoch(const Pre& p) {
+        return p.hw[l] == p.end[l] ||
+               (p.hw[l] < p.end[l] && rec_epoch(rec_at(p.logv[l], p.hw[l])) + 1 == p.ep1[l]);
+    }
+    // IsFollowerCaughtUpToLeaderEpoch (Kip320FirstTry.tla:49-57)
+    template <int l, int f> static KMC_DEV bool caught_up_epoch(const Pre& p, u32 endOffset) {
+        if (!(presumes<l>(p) && p.ldr1[f] == (u32)(l + 1))) return false;
+        if (endOffset == 0) return true;
+        const u32 o = endOffset - 1;
+        return o < p.end[l] && o < p.end[f] &&
+               rec_epoch(rec_at(p.logv[f], o)) == rec_epoch(rec_at(p.logv[l], o));
+    }
+    // FollowerNeedsTruncation (Kip320FirstTry.tla:64-69)
+    template <int f, int l> static KMC_DEV bool needs_truncation(const Pre& p) {
+        if (p.end[f] > p.end[l]) return true;
+        if (p.end[f] == 0) return false;
+        const u32 o = p.end[f] - 1;
+        return o < p.end[l] && rec_epoch(rec_at(p.logv[l], o)) != rec_epoch(rec_at(p.logv[f], o));
+    }
+    // FirstNonMatchingOffsetFromTail(leader, follower) (Kip279.tla:27-45)
+    template <int l, int f> static KMC_DEV u32 first_non_matching(const Pre& p) {
+        const u64 x = p.logv[l] ^ p.logv[f];
+        const u32 lim = kmc_min(p.end[l], p.end[f]);  // leader empty => no match => 0
+        u32 best = 0;
+        kmc_static_for<0, L>([&](auto O) {
+            constexpr int o = decltype(O)::value;
+            if ((u32)o < lim && ((x >> (o * Y.BR)) & MR) == 0) best = o + 1;
+        });
+        return best;
+    }
+    // LookupOffsetForEpoch(leader, follower, epoch) (Kip101.tla:27-39)
+    template <int l, int f> static KMC_DEV u32 lookup_offset_for_epoch(const Pre& p, u32 epoch) {
+        const u32 el = p.end[l];
+        u32 first_larger = p.hw[f];  // offsetWithLargerEpochs = {} -> follower hw
+        bool found = false;
+        kmc_static_for<0, L>([&](auto O) {
+            constexpr int o = decltype(O)::value;
+            if (!found && (u32)o < el && rec_epoch(rec_at(p.logv[l], o)) > epoch) { first_larger = o; found = true; }
+        });
+        if (el == 0) return p.hw[f];
+        if (rec_epoch(rec_at(p.logv[l], el - 1)) == epoch) return el;
+        return first_larger;
+    }
+
+    // ---- one action instance: guard + effect ---------------------------------------------
+    // Returns "enabled"; when enabled, t holds the successor.  `extra` reports additional
+    // satisfying bindings that yield the same successor (TLC counts them as generated).
+    template <int I> static KMC_DEV bool inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
+        extra = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) t[k] = s[k];
+        if constexpr (I < B1) {
+            // ControllerElectLeader (KafkaReplication.tla:176-179)
+            constexpr int r = I - B0;
+            kind = 0;
+            controller_update(t, p, r + 1, p.qisr);
+            return (p.qisr >> r & 1u) && p.qldr1 != (u32)(r + 1) && p.nextEp <= (u32)E;
+        } else if constexpr (I < B2) {
+            // ControllerShrinkIsr (:158-168), three mutually exclusive cases per replica
+            constexpr int r = I - B1;
+            kind = 1;
+            const bool is_ldr = p.qldr1 == (u32)(r + 1);
+            const bool only = p.qisr == (1u << r);
+            const u32 newLdr1 = is_ldr ? 0u : p.qldr1;
+            const u32 newIsr = (is_ldr && only) ? p.qisr : (p.qisr & ~(1u << r));
+            controller_update(t, p, newLdr1, newIsr);
+            return (is_ldr || (p.qisr >> r & 1u)) && p.nextEp <= (u32)E;
+        } else if constexpr (I < B3) {
+            // BecomeLeader (:186-195): request e names leader l
+            constexpr int J = I - B2, e = J / N, l = J % N;
+            kind = 2;
+            kmc_setbits(t, Y.ep_off[l], Y.BE, e + 1);
+            kmc_setbits(t, Y.ldr_off[l], Y.BL, l + 1);
+            kmc_setbits(t, Y.isr_off[l], Y.BI, p.risr[e]);
+            return (u32)e < p.nextEp && p.rldr1[e] == (u32)(l + 1) && (u32)(e + 1) > p.ep1[l];
+        } else if constexpr (I < B4) {
+            constexpr int J = I - B3, l = J / N, r = J % N;
+            kind = 3;
+            const u32 isr = p.isr[l];
+            quorum_update<l>(t, isr | (1u << r));
+            bool g = !(isr >> r & 1u) && is_true_leader<l>(p);
+            if constexpr (K320) {  // FencedLeaderExpandIsr (Kip320.tla:110-117)
+                g = g && following_epoch<l, r>(p) && p.hw[l] <= p.end[r] /* HasFollowerReachedHighWatermark :94-98 */
+                    && hw_reached_epoch<l>(p);
+            } else if constexpr (FIRST) {  // LeaderExpandIsrBetterFencing (Kip320FirstTry.tla:134-141)
+                g = g && caught_up_epoch<l, r>(p, p.hw[l]) && hw_reached_epoch<l>(p);
+            } else {  // LeaderExpandIsr (KafkaReplication.tla:248-254)
+                g = g && caught_up<l, r>(p, p.hw[l]);
+            }
+            return g;
+        } else if constexpr (I < B5) {
+            constexpr int J = I - B4, l = J / (N - 1), q = J % (N - 1), r = q + (q >= l);
+            kind = 4;
+            const u32 isr = p.isr[l];
+            quorum_update<l>(t, isr & ~(1u << r));
+            bool g = (isr >> r & 1u) && is_true_leader<l>(p);
+            if constexpr (K320) {  // FencedLeaderShrinkIsr (Kip320.tla:78-85)
+                g = g && (!following_epoch<l, r>(p) || p.end[r] < p.end[l]);
+            } else if constexpr (FIRST) {  // LeaderShrinkIsrBetterFencing (Kip320FirstTry.tla:114-120)
+                g = g && !caught_up_epoch<l, r>(p, p.end[l]);
+            } else {  // LeaderShrinkIsr (KafkaReplication.tla:233-239)
+                g = g && !caught_up<l, r>(p, p.end[l]);
+            }
+            return g;
+        } else if constexpr (I < B6) {
+            // LeaderWrite (KafkaReplication.tla:202-207)
+            constexpr int r = I - B5;
+            kind = 5;
+            const u32 end = p.end[r];
+            const u64 rec = ((u64)(p.nextRec + 1) << Y.BEr) | (u64)(p.ep1[r] - 1);
+            kmc_setbits(t, Y.log_off[r], Y.BR * L, p.logv[r] | (rec << (end * Y.BR)));
+            kmc_setbits(t, Y.end_off[r], Y.BO, end + 1);
+            kmc_setbits(t, Y.nextrec_off, Y.BNR, p.nextRec + 1);
+            return presumes<r>(p) && p.nextRec <= (u32)(R - 1) && end < (u32)L;
+        } else if constexpr (I < B7) {
+            constexpr int l = I - B6;
+            kind = 6;
+            const u32 hw = p.hw[l];
+            kmc_setbits(t, Y.hw_off[l], Y.BO, hw + 1);
+            bool g;
+            if constexpr (K320) {  // FencedLeaderIncHighWatermark (Kip320.tla:63-70)
+                g = hw < p.end[l];
+                kmc_static_for<0, N>([&](auto F) {
+                    constexpr int f = decltype(F)::value;
+                    if (p.isr[l] >> f & 1u) g = g && following_epoch<l, f>(p) && hw < p.end[f];
+                });
+            } else if constexpr (FIRST) {  // ImprovedLeaderIncHighWatermark (Kip320FirstTry.tla:90-97)
+                g = presumes<l>(p) && hw < p.end[l];
+                kmc_static_for<0, N>([&](auto F) {
+                    constexpr int f = decltype(F)::value;
+                    if (p.isr[l] >> f & 1u) g = g && caught_up_epoch<l, f>(p, hw + 1);
+                });
+            } else {  // LeaderIncHighWatermark (KafkaReplication.tla:264-271)
+                g = presumes<l>(p) && hw <= (u32)(L - 1);
+                kmc_static_for<0, N>([&](auto F) {
+                    constexpr int f = decltype(F)::value;
+                    if (p.isr[l] >> f & 1u) g = g && p.ldr1[f] == (u32)(l + 1) && hw < p.end[f];
+                });
+            }
+            return g;
+        } else if constexpr (I < B8) {
+            // become follower of leader l at request epoch e (leader \in Replicas in every caller,
+            // so the `leader = None` branch of KafkaReplication.tla:285-286 / Kip320.tla:138-140 is dead)
+            constexpr int J = I - B7, pr = J / (E + 1), e = J % (E + 1);
+            constexpr int l = pr / (N - 1), q = pr % (N - 1), r = q + (q >= l);
+            kind = 7;
+            bool g = (u32)e < p.nextEp && p.rldr1[e] == (u32)(l + 1) && (u32)(e + 1) > p.ep1[r];
+            kmc_setbits(t, Y.ep_off[r], Y.BE, e + 1);
+            kmc_setbits(t, Y.ldr_off[r], Y.BL, l + 1);
+            kmc_setbits(t, Y.isr_off[r], Y.BI, p.risr[e]);
+            if constexpr (FIRST) {
+                // BecomeFollower (Kip320FirstTry.tla:148-157): no truncation, hw unchanged
+            } else {
+                u32 off;
+                if constexpr (MODEL == KMC_MODEL_TRUNCATE_TO_HW) {
+                    off = p.hw[r];  // KafkaTruncateToHighWatermark.tla:29-31
+                } else if constexpr (MODEL == KMC_MODEL_KIP101) {
+                    // BecomeFollowerTruncateKip101 (Kip101.tla:41-47)
+                    const u32 er = p.end[r];
+                    const u32 last_epoch = rec_epoch(rec_at(p.logv[r], er == 0 ? 0 : er - 1));
+                    off = er == 0 ? 0u : lookup_offset_for_epoch<l, r>(p, last_epoch);
+                } else {
+                    // BecomeFollowerTruncateKip279 (Kip279.tla:47-51) / FencedBecomeFollowerAndTruncate (Kip320.tla:134-148)
+                    off = first_non_matching<l, r>(p);
+                    if constexpr (MODEL == KMC_MODEL_KIP279) extra = p.end[r] == 0 ? 1u : 0u;  // both disjuncts fire
+                    if constexpr (K320) g = g && presumes<l>(p) && p.ep1[l] == (u32)(e + 1);
+                }
+                g = g && off <= p.end[r];  // TruncateTo is disabled, not clamped (FiniteReplicatedLog.tla:106)
+                truncate<r>(t, p, off);
+                kmc_setbits(t, Y.hw_off[r], Y.BO, kmc_min(off, p.hw[r]));  // BecomeFollowerAndTruncateTo (:281-294)
+            }
+            return g;
+        } else if constexpr (I < B9) {
+            // ReplicateTo(leader, follower) + follower hw (KafkaReplication.tla:302-310,
+            // Kip320.tla:49-56, Kip320FirstTry.tla:103-111)
+            constexpr int J = I - B8, l = J / (N - 1), q = J % (N - 1), f = q + (q >= l);
+            kind = 8;
+            const u32 ef = p.end[f];
+            const u64 rec = rec_at(p.logv[l], ef);
+            kmc_setbits(t, Y.log_off[f], Y.BR * L, p.logv[f] | (rec << (ef * Y.BR)));
+            kmc_setbits(t, Y.end_off[f], Y.BO, ef + 1);
+            kmc_setbits(t, Y.hw_off[f], Y.BO, kmc_min(p.hw[l], ef + 1));
+            bool g = ef < p.end[l] && ef < (u32)L;
+            if constexpr (K320) g = g && following_epoch<l, f>(p);
+            else if constexpr (FIRST) g = g && caught_up_epoch<l, f>(p, ef);
+            else g = g && presumes<l>(p) && p.ldr1[f] == (u32)(l + 1);
+            return g;
+        } else {
+            // FollowerTruncate (Kip320FirstTry.tla:75-82)
+            constexpr int J = I - B9, l = J / (N - 1), q = J % (N - 1), f = q + (q >= l);
+            kind = 9;
+            const u32 off = first_non_matching<l, f>(p);
+            truncate<f>(t, p, off);
+            kmc_setbits(t, Y.hw_off[f], Y.BO, kmc_min(off, p.hw[f]));
+            return presumes<l>(p) && p.ldr1[f] == (u32)(l + 1) && needs_truncation<f, l>(p) && off <= p.end[f];
+        }
+    }
+
+    // ---- invariants; bit k of the result = invariant k violated ---------------------------
+    // 0 TypeOk (:101-107)  1 WeakIsr (:320-326)  2 StrongIsr (:334-340)  3 LeaderInIsr (:345)
+    static KMC_DEV u32 violated(const u64* t, u32 inv_mask) {
+        if (inv_mask == 0) return 0;
+        const Pre p = extract(t);
+        u32 bad = 0;
+        if (inv_mask & 1u) {
+            bool ok = p.nextEp <= (u32)(E + 1) && p.nextRec <= (u32)R && p.qep1 <= (u32)(E + 1) && p.qldr1 <= (u32)N;
+            kmc_static_for<0, N>([&](auto RR) {
+                constexpr int r = decltype(RR)::value;
+                ok = ok && p.end[r] <= (u32)L && p.hw[r] <= (u32)L && p.ep1[r] <= (u32)(E + 1) && p.ldr1[r] <= (u32)N;
+                kmc_static_for<0, L>([&](auto O) {
+                    constexpr int o = decltype(O)::value;
+                    const u32 c = rec_at(p.logv[r], o);
+                    const u32 id1 = c >> Y.BEr;
+                    const bool in_records = id1 >= 1 && id1 <= (u32)R && rec_epoch(c) <= (u32)E;
+                    ok = ok && ((u32)o < p.end[r] ? in_records : c == 0);
+                });
+            });
+            kmc_static_for<0, E + 1>([&](auto EE) {
+                constexpr int e = decltype(EE)::value;
+                if ((u32)e < p.nextEp) ok = ok && p.rldr1[e] <= (u32)N;
+            });
+            if (!ok) bad |= 1u;
+        }
+        if (inv_mask & 6u) {
+            bool weak = true, strong = true;
+            kmc_static_for<0, N>([&](auto R1) {
+                constexpr int r1 = decltype(R1)::value;
+                const u32 hw = p.hw[r1];
+                if (presumes<r1>(p) && hw > 0) {
+                    kmc_static_for<0, N>([&](auto R2) {
+                        constexpr int r2 = decltype(R2)::value;
+                        // \A offset < hw : \E record : HasEntry(r1,..) /\ HasEntry(r2,..)
+                        const bool same = hw <= p.end[r1] && hw <= p.end[r2] &&
+                                          ((p.logv[r1] ^ p.logv[r2]) & keep_below(hw)) == 0;
+                        if (p.isr[r1] >> r2 & 1u) weak = weak && same;
+                        if (p.qisr >> r2 & 1u) strong = strong && same;
+                    });
+                }
+            });
+            if ((inv_mask & 2u) && !weak) bad |= 2u;
+            if ((inv_mask & 4u) && !strong) bad |= 4u;
+        }
+        if (inv_mask & 8u) {
+            const bool ok = p.qldr1 != 0 && (p.qisr >> (p.qldr1 - 1) & 1u);
+            if (!ok) bad |= 8u;
+        }
+        return bad;
+    }
+};
+
+// ========================================================================================
+// successor sink: table probe/insert + frontier append, or owner bucketing, or enumeration
+// ========================================================================================
+template <class M> struct KmcSink {
+    static constexpr int W = M::W;
+
+    // Executed by the whole wave; lanes with valid=false only take part in the ballots.
+    static KMC_DEV void process(const KmcArgs& a, bool valid, const u64* t, u64 meta) {
+        const u64 fp = kmc_fingerprint<W>(t, a.seed);
+        if (a.mode == KMC_MODE_LOCAL) {
+            bool isnew = false;
+            if (valid) {
+                u64 i = fp & a.table_mask;
+                bool done = false;
+                // open addressing, linear probing.  Slots only ever change 0 -> fp, so a plain
+                // (possibly stale) load can only mis-report "empty", which the CAS then corrects.
+                for (u64 probes = 0; !done && probes <= a.table_mask; ++probes) {
+                    u64 v = a.table[i];
+                    if (v == 0) {
+                        v = atomicCAS(&a.table[i], 0ull, fp);
+                        if (v == 0) {
+                            isnew = true;
+                            done = true;
+                            if (a.pred) a.pred[i] = meta;
+                        }
+                    }
+                    if (v == fp) done = true;
+                    i = (i + 1) & a.table_mask;
+                }
+                if (!done) atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
+            }
+            if (isnew && a.inv_mask) {
+                const u32 bad = M::violated(t, a.inv_mask);
+                if (bad) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (bad >> k & 1u) {
+                            atomicAdd(&a.ctl->viol_count[k], 1ull);
+                            atomicMax(&a.ctl->viol_fp_inv[k], ~fp);
+                        }
+                }
+            }
+            const u64 m = __ballot(isnew);
+            if (m) {
+                const int leader = __builtin_ctzll(m);
+                const u32 n = __popcll(m);
+                u64 base = 0;
+                if ((int)kmc_lane() == leader) base = atomicAdd(&a.ctl->next_count, (u64)n);
+                base = kmc_bcast64(base, leader);
+                const u64 idx = base + kmc_rank_in(m);
+                if (isnew) {
+                    if (idx < a.fout_cap) {
+#pragma unroll
+                        for (int k = 0; k < W; ++k) a.fout[(u64)k * a.fout_stride + idx] = t[k];
+                    } else {
+                        atomicOr(&a.ctl->err, KMC_ERR_FRONTIER_FULL);
+                    }
+                }
+            }
+        } else if (a.mode == KMC_MODE_SHARDED) {
+            if (valid) {
+                const u32 dst = kmc_owner(fp, a.nshards);
+                const u64 pos = atomicAdd(&a.ctl->send_count[dst], 1ull);
+                if (pos < a.send_cap) {
+                    u64* rec = a.send + ((u64)dst * a.send_cap + pos) * (u64)(W + 1);
+#pragma unroll
+                    for (int k = 0; k < W; ++k) rec[k] = t[k];
+                    rec[W] = meta;
+                } else {
+                    atomicOr(&a.ctl->err, KMC_ERR_SEND_FULL);
+                }
+            }
+        } else {  // KMC_MODE_ENUM
+            if (valid) {
+                const u64 pos = atomicAdd(&a.ctl->enum_count, 1ull);
+                if (pos < a.send_cap) {
+                    u64* rec = a.send + pos * (u64)(W + 2);
+#pragma unroll
+                    for (int k = 0; k < W; ++k) rec[k] = t[k];
+                    rec[W] = fp;
+                    rec[W + 1] = meta;
+                } else {
+                    atomicOr(&a.ctl->err, KMC_ERR_ENUM_FULL);
+                }
+            }
+        }
+    }
+};
+
+// ========================================================================================
+// kernels
+// ========================================================================================
+#define KMC_BLOCK 256
+#define KMC_WAVES (KMC_BLOCK / 64)
+
+template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
+    constexpr int W = M::W;
+    // per-wave successor ring: W state planes + 1 meta plane (parent fp, or kind in ENUM mode)
+    __shared__ u64 ring[KMC_WAVES][W + 1][KMC_QCAP];
+    const u32 lane = kmc_lane();
+    const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, keep it scalar
+    u64(*q)[KMC_QCAP] = ring[wib];
+    u32 head = 0, count = 0;  // wave-uniform: ring read position / occupancy
+    u64 gen[M::NKINDS];
+#pragma unroll
+    for (int k = 0; k < M::NKINDS; ++k) gen[k] = 0;
+    u64 deadlocks = 0;
+
+    auto flush = [&](u32 nv) {
+        u64 t[W];
+        const u32 pos = (head + lane) & (KMC_QCAP - 1);
+#pragma unroll
+        for (int k = 0; k < W; ++k) t[k] = q[k][pos];
+        const u64 meta = q[W][pos];
+        KmcSink<M>::process(a, lane < nv, t, meta);
+        head = (head + nv) & (KMC_QCAP - 1);
+        count -= nv;
+    };
+
+    const u64 nwaves = (u64)gridDim.x * KMC_WAVES;
+    const u64 ntiles = (a.n_in + 63) >> 6;
+    for (u64 tile = (u64)blockIdx.x * KMC_WAVES + wib; tile < ntiles; tile += nwaves) {
+        const u64 idx = (tile << 6) + lane;
+        const bool valid = idx < a.n_in;
+        u64 s[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) s[k] = valid ? a.fin[(u64)k * a.fin_stride + idx] : 0ull;
+        const u64 parent = (a.flags & KMC_FLAG_TRACE) ? kmc_fingerprint<W>(s, a.seed) : 0ull;
+        typename M::Pre pre = M::extract(s);
+        u32 nsucc = 0;
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < M::NINST; ++i) {
+            M::launder(pre);
+#pragma unroll
+            for (int k = 0; k < W; ++k) kmc_launder(s[k]);
+            bool en = false;
+            int kind = 0;
+            u32 extra = 0;
+            u64 t[W];
+            kmc_dispatch<0, M::NINST>(i, [&](auto I) {
+                en = M::template inst<decltype(I)::value>(pre, s, t, kind, extra);
+            });
+            en = en && valid;
+            const u64 m = __ballot(en);
+            if (m == 0) continue;
+            const u32 n = __popcll(m);
+            u64 weight = n;
+            if (__ballot(en && extra)) {  // rare: bindings that repeat a successor
+                u32 x = en ? extra : 0u;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+                weight += __builtin_amdgcn_readfirstlane(x);
+            }
+#pragma unroll
+            for (int k = 0; k < M::NKINDS; ++k)
+                if (k == kind) gen[k] += weight;
+            if (en) {
+                const u32 pos = (head + count + kmc_rank_in(m)) & (KMC_QCAP - 1);
+#pragma unroll
+                for (int k = 0; k < W; ++k) q[k][pos] = t[k];
+                q[W][pos] = a.mode == KMC_MODE_ENUM ? (u64)kind : parent;
+                ++nsucc;
+            }
+            count += n;
+            if (count >= 64) flush(64);
+        }
+        const u64 dm = __ballot(valid && nsucc == 0);
+        if (dm) {
+            deadlocks += __popcll(dm);
+            if (valid && nsucc == 0) atomicMax(&a.ctl->deadlock_fp_inv, ~kmc_fingerprint<W>(s, a.seed));
+        }
+    }
+    if (count) flush(count);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < M::NKINDS; ++k)
+            if (gen[k]) atomicAdd(&a.ctl->generated[k], gen[k]);
+        if (deadlocks) atomicAdd(&a.ctl->deadlock_count, deadlocks);
+    }
+}
+
+// Inserts a list of AoS records (W state words + predecessor fp) into the local table:
+// the initial state, and the receive side of the multi-GPU exchange.
+template <class M> KMC_DEV void kmc_insert_body(const KmcArgs& a) {
+    constexpr int W = M::W;
+    const u64 n = a.n_in;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 rounds = (n + stride - 1) / stride;
+    for (u64 r = 0; r < rounds; ++r) {
+        const u64 idx = r * stride + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = idx < n;
+        u64 t[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) t[k] = valid ? a.recv[idx * (u64)(W + 1) + k] : 0ull;
+        const u64 meta = valid ? a.recv[idx * (u64)(W + 1) + W] : 0ull;
+        KmcArgs b = a;
+        b.mode = KMC_MODE_LOCAL;
+        KmcSink<M>::process(b, valid, t, meta);
+    }
+}
+
+// Writes Init as one AoS record (W words + predecessor 0) at a.send.
+template <class M> KMC_DEV void kmc_init_body(const KmcArgs& a) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        u64 w[M::W];
+        M::init(w);
+        for (int k = 0; k < M::W; ++k) a.send[k] = w[k];
+        a.send[M::W] = 0;
+    }
+}
+
+// Finds the state(s) of a frontier whose fingerprint equals a.seed-keyed target (passed in
+// a.table_mask) and copies the words to a.send: used to fetch a violation witness.
+template <class M> KMC_DEV void kmc_find_body(const KmcArgs& a) {
+    constexpr int W = M::W;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; idx < a.n_in; idx += stride) {
+        u64 s[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) s[k] = a.fin[(u64)k * a.fin_stride + idx];
+        if (kmc_fingerprint<W>(s, a.seed) == a.table_mask) {
+            for (int k = 0; k < W; ++k) a.send[k] = s[k];
+            a.send[W] = idx;
+        }
+    }
+}
+
+#define KMC_INSTANTIATE(NAME, ...)                                                                       \
+    extern "C" __global__ __launch_bounds__(KMC_BLOCK) void kmc_expand_##NAME(KmcArgs a) {               \
+        kmc_expand_body<__VA_ARGS__>(a);                                                                 \
+    }                                                                                                    \
+    extern "C" __global__ __launch_bounds__(KMC_BLOCK) void kmc_insert_##NAME(KmcArgs a) {               \
+        kmc_insert_body<__VA_ARGS__>(a);                                                                 \
+    }                                                                                                    \
+    extern "C" __global__ __launch_bounds__(KMC_BLOCK) void kmc_init_##NAME(KmcArgs a) {                 \
+        kmc_init_body<__VA_ARGS__>(a);                                                                   \
+    }                                                                                                    \
+    extern "C" __global__ __launch_bounds__(KMC_BLOCK) void kmc_find_##NAME(KmcArgs a) {                 \
+        kmc_find_body<__VA_ARGS__>(a);                                                                   \
+    }

@@ -1,0 +1,961 @@
+// kmc_engine.cpp — host side of the MI355X model checker behind the C ABI of include/kmc.h.
+//
+// Owns: specialising the device code for one (model, constants) through hiprtc (with an
+// on-disk code-object cache), the HBM fingerprint table / frontier buffers, and the
+// level-synchronous BFS loop that stands in for TLC's ModelChecker + Worker threads
+// [TLC-recall; TLC is not part of /root/reference].  No CPU fallback exists: without a HIP
+// device or compiler every entry point fails with KMC_E_DEVICE / KMC_E_COMPILE.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kmc.h"
+#include "kmc_device.h"   // host-visible parts: KmcArgs, KmcLevelCtl, layout, fingerprint
+#include "kmc_sources.inc"  // generated: KMC_SRC_LAYOUT, KMC_SRC_DEVICE (the same two headers as text)
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[2048];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(KMC_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+const char* const MODEL_NAMES[] = {"IdSequence", "FiniteReplicatedLog", "KafkaTruncateToHighWatermark",
+                                   "Kip101",     "Kip279",              "Kip320",
+                                   "Kip320FirstTry"};
+const char* const INV_NAMES[] = {"TypeOk", "WeakIsr", "StrongIsr", "LeaderInIsr"};
+
+const char* const KINDS_BASE[] = {"ControllerElectLeader", "ControllerShrinkIsr", "BecomeLeader",
+                                  "LeaderExpandIsr",       "LeaderShrinkIsr",     "LeaderWrite",
+                                  "LeaderIncHighWatermark", nullptr,              "FollowerReplicate"};
+const char* const KINDS_KIP320[] = {"ControllerElectLeader",        "ControllerShrinkIsr",
+                                    "BecomeLeader",                 "FencedLeaderExpandIsr",
+                                    "FencedLeaderShrinkIsr",        "LeaderWrite",
+                                    "FencedLeaderIncHighWatermark", "FencedBecomeFollowerAndTruncate",
+                                    "FencedFollowerFetch"};
+const char* const KINDS_FIRST[] = {"ControllerElectLeader",
+                                   "ControllerShrinkIsr",
+                                   "BecomeLeader",
+                                   "LeaderExpandIsrBetterFencing",
+                                   "LeaderShrinkIsrBetterFencing",
+                                   "LeaderWrite",
+                                   "ImprovedLeaderIncHighWatermark",
+                                   "BecomeFollower",
+                                   "FollowerFetch",
+                                   "FollowerTruncate"};
+const char* const KINDS_FRL[] = {"Append", "TruncateTo", "ReplicateTo"};
+
+uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+    for (unsigned char c : s) {
+        h ^= c;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::string* inst) {
+    char buf[256];
+    switch (c.model) {
+    case KMC_IDSEQUENCE:
+        if (c.max_id < 0) return false;
+        *lay = kmc_make_layout(c.model, 0, 0, 0, 0, 0);
+        snprintf(buf, sizeof buf, "IdSequence_M%lld", (long long)c.max_id);
+        *name = buf;
+        snprintf(buf, sizeof buf, "KmcIdSequence<%lldLL>", (long long)c.max_id);
+        *inst = buf;
+        return true;
+    case KMC_FINITE_REPLICATED_LOG:
+        *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, 0, 0, c.n_log_records);
+        if (!lay->valid || c.n_replicas < 2) return false;
+        snprintf(buf, sizeof buf, "FiniteReplicatedLog_N%d_L%d_K%d", c.n_replicas, c.log_size, c.n_log_records);
+        *name = buf;
+        snprintf(buf, sizeof buf, "KmcFiniteReplicatedLog<%d,%d,%d>", c.n_replicas, c.log_size, c.n_log_records);
+        *inst = buf;
+        return true;
+    case KMC_TRUNCATE_TO_HW:
+    case KMC_KIP101:
+    case KMC_KIP279:
+    case KMC_KIP320:
+    case KMC_KIP320_FIRST_TRY:
+        *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, c.max_records, c.max_leader_epoch, 0);
+        if (!lay->valid || c.n_replicas < 2) return false;
+        snprintf(buf, sizeof buf, "%s_N%d_L%d_R%d_E%d", MODEL_NAMES[c.model], c.n_replicas, c.log_size,
+                 c.max_records, c.max_leader_epoch);
+        *name = buf;
+        snprintf(buf, sizeof buf, "KmcKafka<%d,%d,%d,%d,%d>", c.model, c.n_replicas, c.log_size, c.max_records,
+                 c.max_leader_epoch);
+        *inst = buf;
+        return true;
+    default: return false;
+    }
+}
+
+std::string strip_for_concat(const char* src) {
+    // drop '#pragma once' and the local include so the two headers can be fed to hiprtc as one file
+    std::string out, line;
+    for (const char* p = src;; ++p) {
+        if (*p == '\n' || *p == 0) {
+            if (line.rfind("#pragma once", 0) != 0 && line.rfind("#include \"kmc_layout.h\"", 0) != 0) {
+                out += line;
+            }
+            out += '\n';
+            line.clear();
+            if (*p == 0) break;
+        } else {
+            line += *p;
+        }
+    }
+    return out;
+}
+
+std::string default_cache_dir() {
+    if (const char* e = getenv("KMC_CACHE_DIR")) return e;
+    Dl_info info;
+    if (dladdr((void*)&default_cache_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t k = p.find_last_of('/');
+        if (k != std::string::npos) return p.substr(0, k) + "/kmc_cache";
+    }
+    return "./kmc_cache";
+}
+
+bool read_file(const std::string& path, std::vector<char>* out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out->resize(n > 0 ? n : 0);
+    bool ok = n > 0 && fread(out->data(), 1, n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+// Compile (or fetch from the cache) the code object specialised for cfg.
+int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<char>* code, std::string* kname) {
+    KmcLayout lay;
+    std::string name, inst;
+    if (!validate(cfg, &lay, &name, &inst))
+        return fail(KMC_E_ARG, "unsupported model/constants (model=%d N=%d L=%d R=%d E=%d K=%d): need 2<=N<=8, "
+                               "L*bits(record)<=64, E<=7", cfg.model, cfg.n_replicas, cfg.log_size,
+                    cfg.max_records, cfg.max_leader_epoch, cfg.n_log_records);
+    *kname = name;
+    std::string src = strip_for_concat(KMC_SRC_LAYOUT) + strip_for_concat(KMC_SRC_DEVICE) + "\nKMC_INSTANTIATE(" +
+                      name + ", " + inst + ")\n";
+    int rtc_major = 0, rtc_minor = 0;
+    hiprtcVersion(&rtc_major, &rtc_minor);
+    char key[64];
+    snprintf(key, sizeof key, "%016llx",
+             (unsigned long long)fnv1a(src + "|" + arch + "|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor)));
+    const std::string dir = cfg.cache_dir ? std::string(cfg.cache_dir) : default_cache_dir();
+    const std::string path = dir + "/" + name + "-" + arch + "-" + key + ".hsaco";
+    if (read_file(path, code)) return KMC_OK;
+
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "kmc_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail(KMC_E_COMPILE, "hiprtcCreateProgram failed");
+    const std::string archopt = "--offload-arch=" + arch;
+    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17"};
+    hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, 0);
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(KMC_E_COMPILE, "hiprtc failed for %s: %s\n%.1500s", name.c_str(), hiprtcGetErrorString(r), log.c_str());
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    code->resize(n);
+    hiprtcGetCode(prog, code->data());
+    hiprtcDestroyProgram(&prog);
+    // best-effort cache write (atomic rename)
+    mkdir(dir.c_str(), 0755);
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    if (FILE* f = fopen(tmp.c_str(), "wb")) {
+        bool ok = fwrite(code->data(), 1, n, f) == n;
+        fclose(f);
+        if (ok) rename(tmp.c_str(), path.c_str());
+        else unlink(tmp.c_str());
+    }
+    return KMC_OK;
+}
+
+uint64_t pow2_floor(uint64_t x) {
+    uint64_t p = 1;
+    while (p * 2 <= x) p *= 2;
+    return p;
+}
+uint64_t pow2_ceil(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p *= 2;
+    return p;
+}
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct kmc_handle {
+    kmc_config cfg{};
+    KmcLayout lay{};
+    int W = 0;
+    std::string kname;
+    hipModule_t mod = nullptr;
+    hipFunction_t f_expand = nullptr, f_insert = nullptr, f_init = nullptr, f_find = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cus = 256;
+    u64 *table = nullptr, *pred = nullptr;
+    uint64_t table_cap = 0;
+    u64* frontier[2] = {nullptr, nullptr};
+    uint64_t fcap = 0;
+    KmcLevelCtl* ctl = nullptr;       // 3 device slots: two alternating levels + one auxiliary
+    KmcLevelCtl* ctl_host = nullptr;  // pinned
+    u64* scratch = nullptr;      // device: init record / find result / enum input
+    uint64_t* scratch_host = nullptr; // pinned
+    u64* enum_out = nullptr;     // device: ENUM records
+    uint64_t enum_cap = 4096;
+    u64* send = nullptr;         // SHARDED send buffers
+    uint64_t send_cap = 0;
+    // run state
+    int cur = 0;                 // frontier[cur] holds the last completed level
+    uint64_t n_cur = 0;          // its size on this shard
+    uint64_t level = 0;          // number of completed levels
+    bool stepping = false, step_expanded = false;
+    std::vector<uint64_t> levels;
+    std::vector<uint64_t> init_words, witness;
+    bool have_witness = false;
+    kmc_result res{};
+    double t_start = 0;
+};
+
+namespace {
+
+int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid) {
+    KmcArgs args = a;
+    size_t size = sizeof(args);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, KMC_BLOCK, 1, 1, 0, h->stream, nullptr, config));
+    return KMC_OK;
+}
+
+KmcArgs base_args(kmc_handle* h, int ctl_slot) {
+    KmcArgs a{};
+    a.table = h->table;
+    a.table_mask = h->table_cap - 1;
+    a.pred = h->pred;
+    a.ctl = h->ctl + ctl_slot;
+    a.seed = h->cfg.hash_seed;
+    a.inv_mask = h->cfg.invariant_mask;
+    a.flags = h->cfg.keep_trace ? KMC_FLAG_TRACE : 0u;
+    a.nshards = (uint32_t)h->cfg.n_shards;
+    a.fin_stride = a.fout_stride = h->fcap;
+    a.fout_cap = h->fcap;
+    return a;
+}
+
+unsigned expand_grid(kmc_handle* h, uint64_t n) {
+    const uint64_t tiles = (n + 63) / 64;
+    uint64_t blocks = (tiles + KMC_WAVES - 1) / KMC_WAVES;
+    const uint64_t maxb = (uint64_t)h->n_cus * 6;  // resident blocks: 6 per CU at 79 VGPRs
+    if (blocks > maxb) blocks = maxb;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+int read_ctl(kmc_handle* h, int slot) {
+    HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl + slot, sizeof(KmcLevelCtl), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return KMC_OK;
+}
+
+int zero_ctl(kmc_handle* h, int slot) {
+    HIP_TRY(hipMemsetAsync(h->ctl + slot, 0, sizeof(KmcLevelCtl), h->stream));
+    return KMC_OK;
+}
+
+int find_state(kmc_handle* h, const u64* frontier, uint64_t n, uint64_t fp, std::vector<uint64_t>* out) {
+    KmcArgs a = base_args(h, 2);
+    a.fin = frontier;
+    a.n_in = n;
+    a.table_mask = fp;  // kmc_find_body takes the target here
+    a.send = h->scratch;
+    HIP_TRY(hipMemsetAsync(h->scratch, 0xFF, (h->W + 1) * 8, h->stream));
+    int rc = launch(h, h->f_find, a, expand_grid(h, n));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->scratch_host, h->scratch, (h->W + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->scratch_host[h->W] == ~0ull) return fail(KMC_E_STATE, "witness fingerprint not found in frontier");
+    out->assign(h->scratch_host, h->scratch_host + h->W);
+    return KMC_OK;
+}
+
+int reset_run(kmc_handle* h) {
+    HIP_TRY(hipMemsetAsync(h->table, 0, h->table_cap * 8, h->stream));
+    if (h->pred) HIP_TRY(hipMemsetAsync(h->pred, 0, h->table_cap * 8, h->stream));
+    HIP_TRY(hipMemsetAsync(h->ctl, 0, 3 * sizeof(KmcLevelCtl), h->stream));
+    h->levels.clear();
+    h->witness.clear();
+    h->have_witness = false;
+    memset(&h->res, 0, sizeof h->res);
+    h->res.violated_invariant = -1;
+    h->res.table_capacity = h->table_cap;
+    h->res.frontier_capacity = h->fcap;
+    h->res.state_words = h->W;
+    h->res.state_bits = h->lay.bits;
+    h->cur = 0;
+    h->n_cur = 0;
+    h->level = 0;
+    h->t_start = now_s();
+    return KMC_OK;
+}
+
+// Fold the device counters of the level that was just produced into the running result.
+// `produced` = states now in frontier[next]; returns true when the search must stop.
+bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, uint64_t parent_n,
+            const u64* new_frontier, uint64_t new_n, int* rc) {
+    kmc_result& r = h->res;
+    *rc = KMC_OK;
+    for (int k = 0; k < KMC_MAX_KINDS; ++k) {
+        r.generated += c.generated[k];
+        r.action_generated[k] += c.generated[k];
+    }
+    r.deadlock_states += c.deadlock_count;
+    if (c.err & KMC_ERR_TABLE_FULL) { r.verdict = KMC_V_TABLE_FULL; return true; }
+    if (c.err & (KMC_ERR_FRONTIER_FULL | KMC_ERR_SEND_FULL)) { r.verdict = KMC_V_FRONTIER_FULL; return true; }
+    if (h->cfg.check_deadlock && c.deadlock_count && r.verdict == KMC_V_OK) {
+        r.verdict = KMC_V_DEADLOCK;
+        r.violation_depth = h->level;  // depth of the deadlocked (parent) level
+        r.violation_fp = ~c.deadlock_fp_inv;
+        if (parent_frontier && h->cfg.n_shards == 1) {
+            *rc = find_state(h, parent_frontier, parent_n, r.violation_fp, &h->witness);
+            h->have_witness = *rc == KMC_OK;
+        }
+        return true;
+    }
+    if (r.violated_invariant < 0) {
+        for (int k = 0; k < 4; ++k) {
+            if ((h->cfg.invariant_mask >> k & 1u) && c.viol_count[k]) {
+                r.violated_invariant = k;
+                r.violation_depth = h->level + 1;
+                r.violation_fp = ~c.viol_fp_inv[k];
+                for (int j = 0; j < 4; ++j) r.violation_count[j] = c.viol_count[j];
+                if (new_frontier && h->cfg.n_shards == 1) {
+                    *rc = find_state(h, new_frontier, new_n, r.violation_fp, &h->witness);
+                    h->have_witness = *rc == KMC_OK;
+                }
+                break;
+            }
+        }
+        if (r.violated_invariant >= 0) {
+            r.verdict = KMC_V_INVARIANT;
+            if (!h->cfg.continue_on_violation) return true;
+        }
+    }
+    return false;
+}
+
+// Produce Init and insert it on its owner.  Leaves level = 1.
+int do_begin(kmc_handle* h) {
+    int rc = reset_run(h);
+    if (rc) return rc;
+    KmcArgs a = base_args(h, 0);
+    a.send = h->scratch;
+    if ((rc = launch(h, h->f_init, a, 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->scratch_host, h->scratch, (h->W + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->init_words.assign(h->scratch_host, h->scratch_host + h->W);
+    const uint64_t fp0 = kmc_fingerprint_of(h, h->init_words.data());
+    const bool mine = h->cfg.n_shards <= 1 || kmc_owner(fp0, (uint32_t)h->cfg.n_shards) == (uint32_t)h->cfg.shard_id;
+    if (mine) {
+        KmcArgs b = base_args(h, 0);
+        b.recv = h->scratch;
+        b.n_in = 1;
+        b.fout = h->frontier[0];
+        b.mode = KMC_MODE_LOCAL;
+        if ((rc = launch(h, h->f_insert, b, 1))) return rc;
+        h->res.generated = 1;
+    }
+    if ((rc = read_ctl(h, 0))) return rc;
+    h->n_cur = h->ctl_host->next_count;
+    h->cur = 0;
+    h->res.distinct = h->n_cur;
+    h->levels.push_back(h->n_cur);
+    bool stop = absorb(h, *h->ctl_host, nullptr, 0, h->frontier[0], h->n_cur, &rc);
+    h->level = 1;
+    h->res.depth = 1;
+    (void)stop;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* kmc_last_error(void) { return g_err.c_str(); }
+const char* kmc_model_name(int32_t m) { return m >= 0 && m <= 6 ? MODEL_NAMES[m] : "?"; }
+const char* kmc_invariant_name(int32_t i) { return i >= 0 && i < 4 ? INV_NAMES[i] : "?"; }
+int32_t kmc_action_count(int32_t model) {
+    switch (model) {
+    case KMC_IDSEQUENCE: return 1;
+    case KMC_FINITE_REPLICATED_LOG: return 3;
+    case KMC_KIP320_FIRST_TRY: return 10;
+    case KMC_TRUNCATE_TO_HW: case KMC_KIP101: case KMC_KIP279: case KMC_KIP320: return 9;
+    default: return 0;
+    }
+}
+const char* kmc_action_name(int32_t model, int32_t kind) {
+    if (kind < 0 || kind >= kmc_action_count(model)) return "?";
+    switch (model) {
+    case KMC_IDSEQUENCE: return "Next";
+    case KMC_FINITE_REPLICATED_LOG: return KINDS_FRL[kind];
+    case KMC_KIP320: return KINDS_KIP320[kind];
+    case KMC_KIP320_FIRST_TRY: return KINDS_FIRST[kind];
+    default:
+        if (kind == 7)
+            return model == KMC_TRUNCATE_TO_HW ? "BecomeFollowerTruncateToHighWatermark"
+                   : model == KMC_KIP101       ? "BecomeFollowerTruncateKip101"
+                                               : "BecomeFollowerTruncateKip279";
+        return KINDS_BASE[kind];
+    }
+}
+
+int kmc_precompile(const kmc_config* cfg, const char* arch) {
+    if (!cfg) return fail(KMC_E_ARG, "null config");
+    std::vector<char> code;
+    std::string kname;
+    return get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname);
+}
+
+void kmc_close(kmc_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->table) hipFree(h->table);
+    if (h->pred) hipFree(h->pred);
+    if (h->frontier[0]) hipFree(h->frontier[0]);
+    if (h->frontier[1]) hipFree(h->frontier[1]);
+    if (h->ctl) hipFree(h->ctl);
+    if (h->scratch) hipFree(h->scratch);
+    if (h->enum_out) hipFree(h->enum_out);
+    if (h->send) hipFree(h->send);
+    if (h->ctl_host) hipHostFree(h->ctl_host);
+    if (h->scratch_host) hipHostFree(h->scratch_host);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    if (h->mod) hipModuleUnload(h->mod);
+    delete h;
+}
+
+static int open_impl(const kmc_config* cfg, kmc_handle* h) {
+    h->cfg = *cfg;
+    if (h->cfg.n_shards < 1) h->cfg.n_shards = 1;
+    if (h->cfg.n_shards > KMC_MAX_SHARDS || h->cfg.shard_id < 0 || h->cfg.shard_id >= h->cfg.n_shards)
+        return fail(KMC_E_ARG, "bad shard configuration %d/%d", h->cfg.shard_id, h->cfg.n_shards);
+    std::string name, inst;
+    if (!validate(h->cfg, &h->lay, &name, &inst)) {
+        std::vector<char> dummy;
+        return get_code_object(h->cfg, "gfx950", &dummy, &name);  // produces the KMC_E_ARG message
+    }
+    h->W = h->lay.W;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(KMC_E_DEVICE, "no HIP device visible: this library has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(KMC_E_ARG, "device %d out of range (%d)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    std::string arch = prop.gcnArchName;
+    size_t colon = arch.find(':');
+    if (colon != std::string::npos) arch = arch.substr(0, colon);
+    h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    std::vector<char> code;
+    int rc = get_code_object(h->cfg, arch, &code, &h->kname);
+    if (rc) return rc;
+    HIP_TRY(hipModuleLoadData(&h->mod, code.data()));
+    HIP_TRY(hipModuleGetFunction(&h->f_expand, h->mod, ("kmc_expand_" + h->kname).c_str()));
+    HIP_TRY(hipModuleGetFunction(&h->f_insert, h->mod, ("kmc_insert_" + h->kname).c_str()));
+    HIP_TRY(hipModuleGetFunction(&h->f_init, h->mod, ("kmc_init_" + h->kname).c_str()));
+    HIP_TRY(hipModuleGetFunction(&h->f_find, h->mod, ("kmc_find_" + h->kname).c_str()));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+
+    // ---- sizing: table slots, frontier states, send records -------------------------------
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const double budget = 0.85 * (double)free_b;
+    const uint64_t slot_bytes = cfg->keep_trace ? 16 : 8;
+    uint64_t tcap = cfg->table_capacity ? pow2_ceil(cfg->table_capacity) : pow2_floor((uint64_t)(budget * 0.5) / slot_bytes);
+    if (tcap < 1024) tcap = 1024;
+    uint64_t fcap = cfg->frontier_capacity;
+    if (!fcap) {
+        const double share = h->cfg.n_shards > 1 ? 0.12 : 0.20;
+        fcap = (uint64_t)(budget * share) / (8ull * h->W);
+        if (fcap > tcap) fcap = tcap;
+    }
+    if (fcap < 64) fcap = 64;
+    fcap = (fcap + 63) & ~63ull;  // keep planes 512-byte aligned
+    h->table_cap = tcap;
+    h->fcap = fcap;
+    if (hipMalloc(&h->table, tcap * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate %llu table slots", (unsigned long long)tcap);
+    if (cfg->keep_trace && hipMalloc(&h->pred, tcap * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate predecessor table");
+    for (int i = 0; i < 2; ++i)
+        if (hipMalloc(&h->frontier[i], fcap * 8ull * h->W) != hipSuccess)
+            return fail(KMC_E_NOMEM, "cannot allocate frontier of %llu states", (unsigned long long)fcap);
+    HIP_TRY(hipMalloc(&h->ctl, 3 * sizeof(KmcLevelCtl)));
+    HIP_TRY(hipHostMalloc(&h->ctl_host, sizeof(KmcLevelCtl)));
+    HIP_TRY(hipMalloc(&h->scratch, 64 * 8));
+    HIP_TRY(hipHostMalloc(&h->scratch_host, 64 * 8));
+    HIP_TRY(hipMalloc(&h->enum_out, h->enum_cap * (h->W + 2) * 8ull));
+    if (h->cfg.n_shards > 1) {
+        uint64_t scap = cfg->send_capacity;
+        if (!scap) scap = (uint64_t)(budget * 0.16) / (8ull * (h->W + 1) * h->cfg.n_shards);
+        if (scap < 64) scap = 64;
+        h->send_cap = scap;
+        if (hipMalloc(&h->send, scap * (h->W + 1) * 8ull * h->cfg.n_shards) != hipSuccess)
+            return fail(KMC_E_NOMEM, "cannot allocate send buffers");
+    }
+    return KMC_OK;
+}
+
+int kmc_open(const kmc_config* cfg, kmc_handle** out) {
+    if (!cfg || !out) return fail(KMC_E_ARG, "null argument");
+    *out = nullptr;
+    kmc_handle* h = new kmc_handle();
+    int rc = open_impl(cfg, h);
+    if (rc) {
+        std::string keep = g_err;
+        kmc_close(h);
+        g_err = keep;
+        return rc;
+    }
+    *out = h;
+    return KMC_OK;
+}
+
+uint64_t kmc_state_words(kmc_handle* h) { return h ? h->W : 0; }
+
+uint64_t kmc_fingerprint_of(kmc_handle* h, const uint64_t* words) {
+    unsigned long long w[KMC_MAXW];
+    for (int k = 0; k < h->W; ++k) w[k] = words[k];
+    switch (h->W) {
+    case 1: return kmc_fingerprint<1>(w, h->cfg.hash_seed);
+    case 2: return kmc_fingerprint<2>(w, h->cfg.hash_seed);
+    case 3: return kmc_fingerprint<3>(w, h->cfg.hash_seed);
+    case 4: return kmc_fingerprint<4>(w, h->cfg.hash_seed);
+    case 5: return kmc_fingerprint<5>(w, h->cfg.hash_seed);
+    case 6: return kmc_fingerprint<6>(w, h->cfg.hash_seed);
+    case 7: return kmc_fingerprint<7>(w, h->cfg.hash_seed);
+    case 8: return kmc_fingerprint<8>(w, h->cfg.hash_seed);
+    case 9: return kmc_fingerprint<9>(w, h->cfg.hash_seed);
+    case 10: return kmc_fingerprint<10>(w, h->cfg.hash_seed);
+    case 11: return kmc_fingerprint<11>(w, h->cfg.hash_seed);
+    default: return kmc_fingerprint<12>(w, h->cfg.hash_seed);
+    }
+}
+
+uint64_t kmc_canon_bytes(kmc_handle* h) {
+    const KmcLayout& y = h->lay;
+    if (y.model == KMC_IDSEQUENCE) return 8;
+    if (y.model == KMC_FINITE_REPLICATED_LOG) return (uint64_t)y.N * (1 + y.L);
+    return (uint64_t)y.N * (5 + y.L) + 5 + 2 * (y.E + 1);
+}
+
+int kmc_unpack_state(kmc_handle* h, const uint64_t* words, uint8_t* c) {
+    const KmcLayout& y = h->lay;
+    unsigned long long w[KMC_MAXW + 1] = {0};
+    for (int k = 0; k < h->W; ++k) w[k] = words[k];
+    if (y.model == KMC_IDSEQUENCE) {
+        memcpy(c, &w[0], 8);
+        return KMC_OK;
+    }
+    if (y.model == KMC_FINITE_REPLICATED_LOG) {
+        for (int r = 0; r < y.N; ++r) {
+            uint8_t* b = c + r * (1 + y.L);
+            b[0] = (uint8_t)kmc_getbits(w, y.end_off[r], y.BO);
+            for (int o = 0; o < y.L; ++o) b[1 + o] = (uint8_t)kmc_getbits(w, y.log_off[r] + o * y.BR, y.BR);
+        }
+        return KMC_OK;
+    }
+    const int rs = 5 + y.L;
+    for (int r = 0; r < y.N; ++r) {
+        uint8_t* b = c + r * rs;
+        b[0] = (uint8_t)kmc_getbits(w, y.end_off[r], y.BO);
+        b[1] = (uint8_t)kmc_getbits(w, y.hw_off[r], y.BO);
+        b[2] = (uint8_t)kmc_getbits(w, y.ep_off[r], y.BE);
+        b[3] = (uint8_t)kmc_getbits(w, y.ldr_off[r], y.BL);
+        b[4] = (uint8_t)kmc_getbits(w, y.isr_off[r], y.BI);
+        for (int o = 0; o < y.L; ++o) {
+            const unsigned rec = (unsigned)kmc_getbits(w, y.log_off[r] + o * y.BR, y.BR);
+            // packed (id+1)<<BEr | epoch  ->  canonical 1 + id*(E+1) + epoch
+            b[5 + o] = rec == 0 ? 0 : (uint8_t)(1 + ((rec >> y.BEr) - 1) * (y.E + 1) + (rec & ((1u << y.BEr) - 1)));
+        }
+    }
+    uint8_t* g = c + y.N * rs;
+    g[0] = (uint8_t)kmc_getbits(w, y.nextrec_off, y.BNR);
+    g[1] = (uint8_t)kmc_getbits(w, y.nextep_off, y.BE);
+    g[2] = (uint8_t)kmc_getbits(w, y.qep_off, y.BE);
+    g[3] = (uint8_t)kmc_getbits(w, y.qldr_off, y.BL);
+    g[4] = (uint8_t)kmc_getbits(w, y.qisr_off, y.BI);
+    for (int e = 0; e <= y.E; ++e) {
+        g[5 + 2 * e] = (uint8_t)kmc_getbits(w, y.reqldr_off[e], y.BL);
+        g[6 + 2 * e] = (uint8_t)kmc_getbits(w, y.reqisr_off[e], y.BI);
+    }
+    return KMC_OK;
+}
+
+int kmc_pack_state(kmc_handle* h, const uint8_t* c, uint64_t* words) {
+    const KmcLayout& y = h->lay;
+    unsigned long long w[KMC_MAXW + 1] = {0};
+    if (y.model == KMC_IDSEQUENCE) {
+        memcpy(&w[0], c, 8);
+    } else if (y.model == KMC_FINITE_REPLICATED_LOG) {
+        for (int r = 0; r < y.N; ++r) {
+            const uint8_t* b = c + r * (1 + y.L);
+            kmc_setbits(w, y.end_off[r], y.BO, b[0]);
+            for (int o = 0; o < y.L; ++o) kmc_setbits(w, y.log_off[r] + o * y.BR, y.BR, b[1 + o]);
+        }
+    } else {
+        const int rs = 5 + y.L;
+        for (int r = 0; r < y.N; ++r) {
+            const uint8_t* b = c + r * rs;
+            kmc_setbits(w, y.end_off[r], y.BO, b[0]);
+            kmc_setbits(w, y.hw_off[r], y.BO, b[1]);
+            kmc_setbits(w, y.ep_off[r], y.BE, b[2]);
+            kmc_setbits(w, y.ldr_off[r], y.BL, b[3]);
+            kmc_setbits(w, y.isr_off[r], y.BI, b[4]);
+            for (int o = 0; o < y.L; ++o) {
+                const unsigned code = b[5 + o];
+                const unsigned rec = code == 0 ? 0 : ((((code - 1) / (y.E + 1)) + 1) << y.BEr) | ((code - 1) % (y.E + 1));
+                kmc_setbits(w, y.log_off[r] + o * y.BR, y.BR, rec);
+            }
+        }
+        const uint8_t* g = c + y.N * rs;
+        kmc_setbits(w, y.nextrec_off, y.BNR, g[0]);
+        kmc_setbits(w, y.nextep_off, y.BE, g[1]);
+        kmc_setbits(w, y.qep_off, y.BE, g[2]);
+        kmc_setbits(w, y.qldr_off, y.BL, g[3]);
+        kmc_setbits(w, y.qisr_off, y.BI, g[4]);
+        for (int e = 0; e <= y.E; ++e) {
+            kmc_setbits(w, y.reqldr_off[e], y.BL, g[5 + 2 * e]);
+            kmc_setbits(w, y.reqisr_off[e], y.BI, g[6 + 2 * e]);
+        }
+    }
+    for (int k = 0; k < h->W; ++k) words[k] = w[k];
+    return KMC_OK;
+}
+
+int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
+    if (!h) return fail(KMC_E_ARG, "null handle");
+    if (h->cfg.n_shards != 1) return fail(KMC_E_STATE, "kmc_run drives one GPU; use the kmc_step_* interface for shards");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    h->stepping = false;
+    int rc = do_begin(h);
+    if (rc) return rc;
+    kmc_result& r = h->res;
+    auto report = [&]() {
+        if (!cb) return;
+        kmc_level_info info{h->level, h->n_cur, r.generated, r.distinct, now_s() - h->t_start};
+        cb(&info, user);
+    };
+    report();
+    bool stop = r.verdict != KMC_V_OK && !(r.verdict == KMC_V_INVARIANT && h->cfg.continue_on_violation);
+    const uint64_t max_levels = h->cfg.max_levels ? h->cfg.max_levels : ~0ull;
+    while (!stop && h->n_cur > 0) {
+        if (h->level >= max_levels) {
+            if (r.verdict == KMC_V_OK) r.verdict = KMC_V_LEVEL_LIMIT;
+            break;
+        }
+        const int slot = (int)(h->level & 1);
+        const int nxt = h->cur ^ 1;
+        if ((rc = zero_ctl(h, slot))) return rc;
+        KmcArgs a = base_args(h, slot);
+        a.fin = h->frontier[h->cur];
+        a.n_in = h->n_cur;
+        a.fout = h->frontier[nxt];
+        a.mode = KMC_MODE_LOCAL;
+        HIP_TRY(hipEventRecord(h->ev0, h->stream));
+        if ((rc = launch(h, h->f_expand, a, expand_grid(h, h->n_cur)))) return rc;
+        HIP_TRY(hipEventRecord(h->ev1, h->stream));
+        if ((rc = read_ctl(h, slot))) return rc;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        r.seconds_expand += 1e-3 * ms;
+        r.expand_launches++;
+        const KmcLevelCtl c = *h->ctl_host;
+        const uint64_t produced = c.next_count < h->fcap ? c.next_count : h->fcap;
+        stop = absorb(h, c, h->frontier[h->cur], h->n_cur, h->frontier[nxt], produced, &rc);
+        if (rc) return rc;
+        if (r.verdict == KMC_V_DEADLOCK || r.verdict == KMC_V_TABLE_FULL || r.verdict == KMC_V_FRONTIER_FULL) {
+            r.queue_left = h->n_cur;
+            break;
+        }
+        if (produced == 0) {
+            h->n_cur = 0;
+            break;
+        }
+        h->cur = nxt;
+        h->n_cur = produced;
+        h->level++;
+        r.depth = h->level;
+        r.distinct += produced;
+        h->levels.push_back(produced);
+        report();
+    }
+    if (stop && r.verdict == KMC_V_INVARIANT) r.queue_left = h->n_cur;
+    r.n_levels = h->levels.size();
+    r.seconds_total = now_s() - h->t_start;
+    return KMC_OK;
+}
+
+int kmc_result_get(kmc_handle* h, kmc_result* out) {
+    if (!h || !out) return fail(KMC_E_ARG, "null argument");
+    h->res.n_levels = h->levels.size();
+    *out = h->res;
+    return KMC_OK;
+}
+
+uint64_t kmc_level_sizes(kmc_handle* h, uint64_t* out, uint64_t cap) {
+    if (!h) return 0;
+    for (uint64_t i = 0; i < h->levels.size() && i < cap; ++i) out[i] = h->levels[i];
+    return h->levels.size();
+}
+
+int kmc_frontier_states(kmc_handle* h, uint64_t* words, uint64_t cap_states, uint64_t* n_out) {
+    if (!h || !n_out) return fail(KMC_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const uint64_t n = h->n_cur < cap_states ? h->n_cur : cap_states;
+    *n_out = h->n_cur;
+    if (n == 0) return KMC_OK;
+    std::vector<uint64_t> plane(n);
+    for (int k = 0; k < h->W; ++k) {
+        HIP_TRY(hipMemcpy(plane.data(), h->frontier[h->cur] + (uint64_t)k * h->fcap, n * 8, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i) words[i * h->W + k] = plane[i];
+    }
+    return KMC_OK;
+}
+
+int kmc_successors(kmc_handle* h, const uint64_t* words, uint64_t* out, uint64_t cap, uint64_t* n_out) {
+    if (!h || !words || !n_out) return fail(KMC_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    // the auxiliary frontier is the scratch buffer viewed as SoA with stride 1... planes must be
+    // fin[k*stride + 0], so stride 1 puts the W words back to back
+    HIP_TRY(hipMemcpyAsync(h->scratch, words, h->W * 8, hipMemcpyHostToDevice, h->stream));
+    int rc = zero_ctl(h, 2);
+    if (rc) return rc;
+    KmcArgs a = base_args(h, 2);
+    a.fin = h->scratch;
+    a.fin_stride = 1;
+    a.n_in = 1;
+    a.mode = KMC_MODE_ENUM;
+    a.send = h->enum_out;
+    a.send_cap = h->enum_cap;
+    a.inv_mask = 0;
+    if ((rc = launch(h, h->f_expand, a, 1))) return rc;
+    if ((rc = read_ctl(h, 2))) return rc;
+    const uint64_t n = h->ctl_host->enum_count < h->enum_cap ? h->ctl_host->enum_count : h->enum_cap;
+    *n_out = n;
+    const uint64_t ncopy = n < cap ? n : cap;
+    if (ncopy && out) HIP_TRY(hipMemcpy(out, h->enum_out, ncopy * (h->W + 2) * 8, hipMemcpyDeviceToHost));
+    return KMC_OK;
+}
+
+int kmc_witness(kmc_handle* h, uint64_t* words) {
+    if (!h || !words) return fail(KMC_E_ARG, "null argument");
+    if (!h->have_witness) return fail(KMC_E_STATE, "no witness recorded");
+    for (int k = 0; k < h->W; ++k) words[k] = h->witness[k];
+    return KMC_OK;
+}
+
+// Looks fp up in the device table from the host (a few 8-byte reads); returns the slot.
+static int table_lookup(kmc_handle* h, uint64_t fp, uint64_t* slot) {
+    const uint64_t mask = h->table_cap - 1;
+    uint64_t i = fp & mask;
+    for (uint64_t probes = 0; probes <= mask; ++probes) {
+        uint64_t v = 0;
+        HIP_TRY(hipMemcpy(&v, h->table + i, 8, hipMemcpyDeviceToHost));
+        if (v == fp) {
+            *slot = i;
+            return KMC_OK;
+        }
+        if (v == 0) break;
+        i = (i + 1) & mask;
+    }
+    return fail(KMC_E_STATE, "fingerprint %016llx not in table", (unsigned long long)fp);
+}
+
+int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap, uint64_t* n_out) {
+    if (!h || !n_out) return fail(KMC_E_ARG, "null argument");
+    if (!h->pred) return fail(KMC_E_STATE, "kmc_trace needs keep_trace=1");
+    if (!h->have_witness) return fail(KMC_E_STATE, "no violation witness recorded");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    // 1. walk predecessor fingerprints back to the initial state (pred == 0)
+    std::vector<uint64_t> chain;
+    uint64_t fp = h->res.violation_fp;
+    for (uint64_t guard = 0; guard < (1u << 20); ++guard) {
+        chain.push_back(fp);
+        uint64_t slot = 0;
+        int rc = table_lookup(h, fp, &slot);
+        if (rc) return rc;
+        uint64_t p = 0;
+        HIP_TRY(hipMemcpy(&p, h->pred + slot, 8, hipMemcpyDeviceToHost));
+        if (p == 0) break;
+        fp = p;
+    }
+    // 2. replay forward from Init, picking at each step the successor with the next fingerprint
+    const uint64_t n = chain.size();
+    *n_out = n;
+    const uint64_t cb = kmc_canon_bytes(h);
+    std::vector<uint64_t> cur = h->init_words;
+    std::vector<uint64_t> succ(h->enum_cap * (h->W + 2));
+    if (kmc_fingerprint_of(h, cur.data()) != chain[n - 1]) return fail(KMC_E_STATE, "trace does not start at Init");
+    for (uint64_t step = 0; step < n; ++step) {
+        if (step < cap) {
+            if (canon_states) kmc_unpack_state(h, cur.data(), canon_states + step * cb);
+        }
+        if (step + 1 == n) break;
+        const uint64_t want = chain[n - 2 - step];
+        uint64_t ns = 0;
+        int rc = kmc_successors(h, cur.data(), succ.data(), h->enum_cap, &ns);
+        if (rc) return rc;
+        bool found = false;
+        for (uint64_t i = 0; i < ns && i < h->enum_cap; ++i) {
+            const uint64_t* rec = &succ[i * (h->W + 2)];
+            if (rec[h->W] == want) {
+                cur.assign(rec, rec + h->W);
+                if (step + 1 < cap && kinds) kinds[step + 1] = (int32_t)rec[h->W + 1];
+                found = true;
+                break;
+            }
+        }
+        if (!found) return fail(KMC_E_STATE, "trace replay lost the path at step %llu", (unsigned long long)step);
+    }
+    if (kinds && cap) kinds[0] = -1;
+    return KMC_OK;
+}
+
+// ---- level-step interface ---------------------------------------------------------------
+int kmc_step_begin(kmc_handle* h) {
+    if (!h) return fail(KMC_E_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int rc = do_begin(h);
+    h->stepping = true;
+    h->step_expanded = false;
+    return rc;
+}
+
+int kmc_step_expand(kmc_handle* h, uint64_t send_counts[KMC_MAX_SHARDS]) {
+    if (!h || !h->stepping) return fail(KMC_E_STATE, "kmc_step_begin first");
+    if (!h->send) return fail(KMC_E_STATE, "handle was opened with n_shards == 1");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int slot = (int)(h->level & 1);
+    int rc = zero_ctl(h, slot);
+    if (rc) return rc;
+    KmcArgs a = base_args(h, slot);
+    a.fin = h->frontier[h->cur];
+    a.n_in = h->n_cur;
+    a.fout = h->frontier[h->cur ^ 1];
+    a.mode = KMC_MODE_SHARDED;
+    a.send = h->send;
+    a.send_cap = h->send_cap;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    if (h->n_cur) {
+        if ((rc = launch(h, h->f_expand, a, expand_grid(h, h->n_cur)))) return rc;
+    }
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    if ((rc = read_ctl(h, slot))) return rc;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->res.seconds_expand += 1e-3 * ms;
+    h->res.expand_launches++;
+    for (int d = 0; d < KMC_MAX_SHARDS; ++d) {
+        uint64_t c = h->ctl_host->send_count[d];
+        send_counts[d] = c < h->send_cap ? c : h->send_cap;
+    }
+    h->step_expanded = true;
+    return KMC_OK;
+}
+
+int kmc_step_send_buffer(kmc_handle* h, int32_t dst, void** dev_ptr, uint64_t* record_words) {
+    if (!h || !h->send || dst < 0 || dst >= h->cfg.n_shards) return fail(KMC_E_ARG, "bad destination");
+    *dev_ptr = h->send + (uint64_t)dst * h->send_cap * (h->W + 1);
+    *record_words = h->W + 1;
+    return KMC_OK;
+}
+
+int kmc_step_insert(kmc_handle* h, const void* dev_records, uint64_t n_records) {
+    if (!h || !h->stepping || !h->step_expanded) return fail(KMC_E_STATE, "kmc_step_expand first");
+    if (n_records == 0) return KMC_OK;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int slot = (int)(h->level & 1);
+    KmcArgs a = base_args(h, slot);
+    a.recv = (const u64*)dev_records;
+    a.n_in = n_records;
+    a.fout = h->frontier[h->cur ^ 1];
+    a.mode = KMC_MODE_LOCAL;
+    uint64_t blocks = (n_records + KMC_BLOCK - 1) / KMC_BLOCK;
+    const uint64_t maxb = (uint64_t)h->n_cus * 8;
+    if (blocks > maxb) blocks = maxb;
+    return launch(h, h->f_insert, a, (unsigned)blocks);
+}
+
+int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
+    if (!h || !h->stepping || !h->step_expanded) return fail(KMC_E_STATE, "kmc_step_expand first");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int slot = (int)(h->level & 1);
+    int rc = read_ctl(h, slot);
+    if (rc) return rc;
+    const KmcLevelCtl c = *h->ctl_host;
+    const int nxt = h->cur ^ 1;
+    const uint64_t produced = c.next_count < h->fcap ? c.next_count : h->fcap;
+    absorb(h, c, h->frontier[h->cur], h->n_cur, h->frontier[nxt], produced, &rc);
+    h->cur = nxt;
+    h->n_cur = produced;
+    h->level++;
+    h->res.distinct += produced;
+    h->levels.push_back(produced);
+    h->step_expanded = false;
+    h->res.seconds_total = now_s() - h->t_start;
+    if (info) *info = kmc_level_info{h->level, produced, h->res.generated, h->res.distinct, h->res.seconds_total};
+    return rc;
+}
+
+int kmc_step_set_verdict(kmc_handle* h, int32_t verdict) {
+    if (!h) return fail(KMC_E_ARG, "null handle");
+    h->res.verdict = verdict;
+    return KMC_OK;
+}
+
+}  // extern "C"
