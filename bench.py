@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: exhaustive BFS model checking of the Kafka replication spec.
+
+A "step" is one complete exhaustive check (Init -> fixpoint) of the headline configuration
+(BASELINE.json configs[2], bound as SURVEY §8d says because KafkaReplication.tla has no Next):
+
+    root module Kip320, Replicas = {b1,b2,b3}, LogSize = 6, MaxRecords = 6, MaxLeaderEpoch = 2,
+    INVARIANTS TypeOk WeakIsr StrongIsr, CHECK_DEADLOCK FALSE, no symmetry.
+
+MaxRecords / MaxLeaderEpoch are not pinned by BASELINE.json; the C oracle exhausts this
+binding (279,753,922 distinct states, tests/golden/oracle_kip320_3_6_6_2.json), which is what
+the GPU count is checked against in the same run.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N = 1: the whole search runs on one GPU inside libkmc.so (kmc_run).
+N > 1 (launched by torch.distributed.run, one rank per GPU): the fingerprint space is
+hash-partitioned across ranks and every BFS level exchanges successors with one RCCL
+all-to-all (kafka_specification_amd/sharded.py); total work is fixed => "scaling": "strong".
+
+Prints ONE JSON line (rank 0).  `value` = distinct states per second over the whole job.
+The oracle (oracle/) is used only as the cpu_baseline leg and to check the count.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+if os.environ.get("KMC_NO_TORCH", "0") != "1":
+    import torch  # first: the process must hold ONE HIP runtime (see kafka_specification_amd/_native.py)
+else:
+    torch = None  # profiling runs on the system ROCm, without the wheel's bundled runtime
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_BPS = 8.0e12  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def headline_config():
+    from kafka_specification_amd.configs import HEADLINE
+    return dict(HEADLINE)
+
+
+def workload_name(c):
+    return (f"{c['model']} N={c['n_replicas']} LogSize={c['log_size']} MaxRecords={c['max_records']} "
+            f"MaxLeaderEpoch={c['max_leader_epoch']} inv={'+'.join(c['invariants'])} deadlock=off")
+
+
+def expected_counts(c):
+    p = os.path.join(ROOT, "tests", "golden",
+                     f"oracle_kip320_{c['n_replicas']}_{c['log_size']}_{c['max_records']}_{c['max_leader_epoch']}.json")
+    if c["model"] == "Kip320" and os.path.exists(p):
+        g = json.load(open(p))
+        return dict(distinct=g["distinct"], generated=g["generated"], depth=g["depth"])
+    return None
+
+
+def cpu_baseline(c, budget_states):
+    """The C oracle (exact-state BFS, a port — TLC itself cannot run here) on all host cores,
+    on a bounded prefix of the same workload: it stops after the BFS level that crosses
+    `budget_states` distinct states."""
+    import kmo
+    threads = os.cpu_count() or 1
+    cfg = kmo.make_config(c["model"], N=c["n_replicas"], L=c["log_size"], R=c["max_records"],
+                          E=c["max_leader_epoch"], invariants=c["invariants"], threads=threads,
+                          max_states=budget_states)
+    t0 = time.time()
+    run = kmo.Run(cfg)
+    dt = time.time() - t0
+    out = dict(value=run.distinct / max(run.seconds, 1e-9), unit="distinct states/s", cores=threads, kind="port",
+               sample=(f"first {run.depth} BFS levels of the same workload ({run.distinct} distinct states, "
+                       f"{run.seconds:.1f} s) with oracle/kmc_oracle.c, {threads} threads; "
+                       "not TLC (no JVM on this box)"),
+               seconds=round(dt, 2))
+    run.close()
+    return out
+
+
+def run_single(c, steps, warmup):
+    import kafka_specification_amd as kmc
+    cfg = kmc.CheckerConfig(**c, device=0, table_capacity=int(os.environ.get("KMC_BENCH_TABLE", 1 << 30)),
+                            frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", 1 << 26)))
+    results = []
+    with kmc.ModelChecker(cfg) as mc:
+        for _ in range(warmup):
+            mc.run()
+        if torch is not None:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            results.append(mc.run())   # kmc_run returns after its stream has drained
+        if torch is not None:
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return results, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-states", type=int, default=6_000_000, help="cpu_baseline sample size (distinct states)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--small", action="store_true", help="debug: a small configuration instead of the headline")
+    a = ap.parse_args()
+
+    c = headline_config()
+    if a.small:
+        c.update(log_size=3, max_records=3)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+
+    if a.gpus > 1 or world > 1:
+        from kafka_specification_amd.sharded import bench_sharded
+        results, dt, extra = bench_sharded(c, a.steps, a.warmup)
+        scaling, parallelism = "strong", f"fingerprint-sharded x{world}, all-to-all per BFS level"
+    else:
+        results, dt = run_single(c, a.steps, a.warmup)
+        extra = {}
+        scaling, parallelism = "strong", "1 GPU"
+    if rank != 0:
+        return
+
+    r = results[-1]
+    distinct, generated = r.distinct, r.generated
+    exp = expected_counts(c)
+    counts_match = None if exp is None else (distinct == exp["distinct"] and generated == exp["generated"]
+                                             and r.depth == exp["depth"])
+    total_states = sum(x.distinct for x in results)
+    value = total_states / dt
+    S = 8 * r.state_words
+    g = generated / max(distinct, 1)
+    alg_bytes_per_state = 2 * S + 8 * g + 8          # frontier read+write, g probes, 1 claim
+    kernel_s = sum(x.seconds_expand for x in results) / len(results)
+    launches = r.expand_launches
+    achieved = alg_bytes_per_state * distinct / max(kernel_s, 1e-12)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "distinct states/sec + time-to-exhaustive, KafkaReplication 3-broker",
+        "value": value, "unit": "distinct states/s", "n_gpus": max(a.gpus, world), "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic (fully determined by model + constants; hash seed 0)",
+        "config": {"workload": workload_name(c), "parallelism": parallelism, "state_bytes": S,
+                   "distinct_states": distinct, "states_generated": generated, "depth": r.depth,
+                   "verdict": r.verdict, "matches_oracle_golden": counts_match,
+                   "time_to_exhaustive_s": dt / a.steps, **extra},
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_BPS, "traffic": traffic,
+                     "kernel": "kmc_expand_*", "kernel_seconds_per_step": kernel_s, "launches_per_step": launches,
+                     "algorithmic_bytes_per_launch": alg_bytes_per_state * distinct / max(launches, 1),
+                     "algorithmic_bytes_per_distinct_state": alg_bytes_per_state,
+                     "note": "aggregate over the step's per-level launches (HIP events on the engine stream); "
+                             "random 8-B probes move >= one 64-B sector each, so 12.5 % useful bytes is the ceiling "
+                             "for the probe part"},
+    }
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(c, a.cpu_states)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

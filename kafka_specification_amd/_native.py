@@ -100,6 +100,16 @@ def lib():
     """The loaded libkmc.so (raises when it is missing — no fallback)."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64 /
+        # libhsa-runtime64 / libhiprtc (same SONAMEs as /opt/rocm).  If torch is loaded after
+        # libkmc.so the process ends up with two HSA runtimes and torch finds no GPU; loaded
+        # first, libkmc.so binds to torch's copies.  KMC_NO_TORCH=1 keeps the library on the
+        # system ROCm (standalone CLI use, rocprofv3 runs).
+        if os.environ.get("KMC_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         if not os.path.exists(LIB_PATH):
             raise KmcError(-1, f"{LIB_PATH} is not built; run `python __graft_entry__.py` "
                                "(or make -C kafka_specification_amd/csrc)")

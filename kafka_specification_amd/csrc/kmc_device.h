@@ -46,6 +46,14 @@ typedef unsigned int u32;
 #define KMC_MAX_SHARDS 8
 #define KMC_QCAP 128  // per-wave LDS ring capacity (successors); flush granularity is 64
 
+// tuning knobs (the host may override them per code object through KMC_JIT_DEFINES)
+#ifndef KMC_OUT_STAGE
+#define KMC_OUT_STAGE 1   // stage winners in LDS and append 64 at a time (1 atomic per 64 states)
+#endif
+#ifndef KMC_CAS_FIRST
+#define KMC_CAS_FIRST 0   // probe with atomicCAS directly instead of load-then-CAS
+#endif
+
 // One per BFS level; the host zeroes it before the level runs and reads it back after.
 struct KmcLevelCtl {
     u64 next_count;                  // states appended to the next frontier
@@ -608,45 +616,103 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
 // ========================================================================================
 // successor sink: table probe/insert + frontier append, or owner bucketing, or enumeration
 // ========================================================================================
+// Per-wave output stager: winners wait in an LDS ring (W planes x KMC_QCAP) until 64 of them
+// can be appended with ONE atomicAdd and W fully coalesced 512-byte plane stores.  (A single
+// device-scope counter saturates near 90 M atomics/s; one atomic per flush of ~20 winners
+// sat right on that limit.)
+template <int W> struct KmcStager {
+    u64* planes;   // LDS, [W][KMC_QCAP]
+    u32 head, count;  // wave-uniform
+
+    KMC_DEV void init(u64* lds) { planes = lds; head = 0; count = 0; }
+
+    KMC_DEV void drain(const KmcArgs& a, u32 n) {  // n <= 64 staged states -> next frontier
+        const u32 lane = kmc_lane();
+        u64 base = 0;
+        if (lane == 0) base = atomicAdd(&a.ctl->next_count, (u64)n);
+        base = kmc_bcast64(base, 0);
+        if (lane < n) {
+            const u32 pos = (head + lane) & (KMC_QCAP - 1);
+            const u64 idx = base + lane;
+            if (idx < a.fout_cap) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) a.fout[(u64)k * a.fout_stride + idx] = planes[k * KMC_QCAP + pos];
+            } else {
+                atomicOr(&a.ctl->err, KMC_ERR_FRONTIER_FULL);
+            }
+        }
+        head = (head + n) & (KMC_QCAP - 1);
+        count -= n;
+    }
+    KMC_DEV void push(const KmcArgs& a, bool isnew, const u64* t) {
+        const u64 m = __ballot(isnew);
+        if (m == 0) return;
+        if (isnew) {
+            const u32 pos = (head + count + kmc_rank_in(m)) & (KMC_QCAP - 1);
+#pragma unroll
+            for (int k = 0; k < W; ++k) planes[k * KMC_QCAP + pos] = t[k];
+        }
+        count += __popcll(m);
+        if (count >= 64) drain(a, 64);
+    }
+    KMC_DEV void finish(const KmcArgs& a) {
+        if (count) drain(a, count);
+    }
+};
+
 template <class M> struct KmcSink {
     static constexpr int W = M::W;
 
+    // probe/insert fp; returns true when this lane claimed the slot (the state is new)
+    static KMC_DEV bool claim(const KmcArgs& a, u64 fp, u64 meta) {
+        u64 i = fp & a.table_mask;
+        // open addressing, linear probing.  Slots only ever change 0 -> fp, so a plain
+        // (possibly stale) load can only mis-report "empty", which the CAS then corrects.
+        for (u64 probes = 0; probes <= a.table_mask; ++probes) {
+#if KMC_CAS_FIRST
+            u64 v = atomicCAS(&a.table[i], 0ull, fp);
+            if (v == 0) {
+                if (a.pred) a.pred[i] = meta;
+                return true;
+            }
+#else
+            u64 v = a.table[i];
+            if (v == 0) {
+                v = atomicCAS(&a.table[i], 0ull, fp);
+                if (v == 0) {
+                    if (a.pred) a.pred[i] = meta;
+                    return true;
+                }
+            }
+#endif
+            if (v == fp) return false;
+            i = (i + 1) & a.table_mask;
+        }
+        atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
+        return false;
+    }
+
+    static KMC_DEV void check_invariants(const KmcArgs& a, const u64* t, u64 fp) {
+        const u32 bad = M::violated(t, a.inv_mask);
+        if (bad) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (bad >> k & 1u) {
+                    atomicAdd(&a.ctl->viol_count[k], 1ull);
+                    atomicMax(&a.ctl->viol_fp_inv[k], ~fp);
+                }
+        }
+    }
+
     // Executed by the whole wave; lanes with valid=false only take part in the ballots.
-    static KMC_DEV void process(const KmcArgs& a, bool valid, const u64* t, u64 meta) {
+    static KMC_DEV void process(const KmcArgs& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta) {
         const u64 fp = kmc_fingerprint<W>(t, a.seed);
         if (a.mode == KMC_MODE_LOCAL) {
-            bool isnew = false;
-            if (valid) {
-                u64 i = fp & a.table_mask;
-                bool done = false;
-                // open addressing, linear probing.  Slots only ever change 0 -> fp, so a plain
-                // (possibly stale) load can only mis-report "empty", which the CAS then corrects.
-                for (u64 probes = 0; !done && probes <= a.table_mask; ++probes) {
-                    u64 v = a.table[i];
-                    if (v == 0) {
-                        v = atomicCAS(&a.table[i], 0ull, fp);
-                        if (v == 0) {
-                            isnew = true;
-                            done = true;
-                            if (a.pred) a.pred[i] = meta;
-                        }
-                    }
-                    if (v == fp) done = true;
-                    i = (i + 1) & a.table_mask;
-                }
-                if (!done) atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
-            }
-            if (isnew && a.inv_mask) {
-                const u32 bad = M::violated(t, a.inv_mask);
-                if (bad) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (bad >> k & 1u) {
-                            atomicAdd(&a.ctl->viol_count[k], 1ull);
-                            atomicMax(&a.ctl->viol_fp_inv[k], ~fp);
-                        }
-                }
-            }
+            const bool isnew = valid && claim(a, fp, meta);
+            if (isnew && a.inv_mask) check_invariants(a, t, fp);
+#if KMC_OUT_STAGE
+            out.push(a, isnew, t);
+#else
             const u64 m = __ballot(isnew);
             if (m) {
                 const int leader = __builtin_ctzll(m);
@@ -664,6 +730,7 @@ template <class M> struct KmcSink {
                     }
                 }
             }
+#endif
         } else if (a.mode == KMC_MODE_SHARDED) {
             if (valid) {
                 const u32 dst = kmc_owner(fp, a.nshards);
@@ -702,11 +769,14 @@ template <class M> struct KmcSink {
 
 template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     constexpr int W = M::W;
-    // per-wave successor ring: W state planes + 1 meta plane (parent fp, or kind in ENUM mode)
-    __shared__ u64 ring[KMC_WAVES][W + 1][KMC_QCAP];
+    // per-wave LDS: successor ring (W state planes + 1 meta plane: parent fp, or kind in ENUM
+    // mode) followed by the output stager's W planes
+    __shared__ u64 ring[KMC_WAVES][2 * W + 1][KMC_QCAP];
     const u32 lane = kmc_lane();
     const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, keep it scalar
     u64(*q)[KMC_QCAP] = ring[wib];
+    KmcStager<W> out;
+    out.init(&ring[wib][W + 1][0]);
     u32 head = 0, count = 0;  // wave-uniform: ring read position / occupancy
     u64 gen[M::NKINDS];
 #pragma unroll
@@ -719,7 +789,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #pragma unroll
         for (int k = 0; k < W; ++k) t[k] = q[k][pos];
         const u64 meta = q[W][pos];
-        KmcSink<M>::process(a, lane < nv, t, meta);
+        KmcSink<M>::process(a, out, lane < nv, t, meta);
         head = (head + nv) & (KMC_QCAP - 1);
         count -= nv;
     };
@@ -778,6 +848,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         }
     }
     if (count) flush(count);
+    out.finish(a);
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < M::NKINDS; ++k)
@@ -790,6 +861,9 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 // the initial state, and the receive side of the multi-GPU exchange.
 template <class M> KMC_DEV void kmc_insert_body(const KmcArgs& a) {
     constexpr int W = M::W;
+    __shared__ u64 stage[KMC_WAVES][W][KMC_QCAP];
+    KmcStager<W> out;
+    out.init(&stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0][0]);
     const u64 n = a.n_in;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u64 rounds = (n + stride - 1) / stride;
@@ -802,8 +876,9 @@ template <class M> KMC_DEV void kmc_insert_body(const KmcArgs& a) {
         const u64 meta = valid ? a.recv[idx * (u64)(W + 1) + W] : 0ull;
         KmcArgs b = a;
         b.mode = KMC_MODE_LOCAL;
-        KmcSink<M>::process(b, valid, t, meta);
+        KmcSink<M>::process(b, out, valid, t, meta);
     }
+    out.finish(a);
 }
 
 // Writes Init as one AoS record (W words + predecessor 0) at a.send.

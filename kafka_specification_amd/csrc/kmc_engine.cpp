@@ -164,13 +164,32 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
                                "L*bits(record)<=64, E<=7", cfg.model, cfg.n_replicas, cfg.log_size,
                     cfg.max_records, cfg.max_leader_epoch, cfg.n_log_records);
     *kname = name;
+    // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_CAS_FIRST=1 -DKMC_OUT_STAGE=0"
+    std::vector<std::string> defines;
+    std::string defines_key;
+    if (const char* d = getenv("KMC_JIT_DEFINES")) {
+        std::string tok;
+        for (const char* q = d;; ++q) {
+            if (*q == ' ' || *q == 0) {
+                if (!tok.empty()) { defines.push_back(tok); defines_key += tok + " "; }
+                tok.clear();
+                if (*q == 0) break;
+            } else {
+                tok += *q;
+            }
+        }
+    }
     std::string src = strip_for_concat(KMC_SRC_LAYOUT) + strip_for_concat(KMC_SRC_DEVICE) + "\nKMC_INSTANTIATE(" +
                       name + ", " + inst + ")\n";
-    int rtc_major = 0, rtc_minor = 0;
+    // The PyTorch wheel bundles its own hiprtc/comgr next to the system ROCm's; both report
+    // the same hiprtcVersion, so the HIP runtime build number is part of the cache key too.
+    int rtc_major = 0, rtc_minor = 0, hip_ver = 0;
     hiprtcVersion(&rtc_major, &rtc_minor);
+    hipRuntimeGetVersion(&hip_ver);
     char key[64];
     snprintf(key, sizeof key, "%016llx",
-             (unsigned long long)fnv1a(src + "|" + arch + "|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor)));
+             (unsigned long long)fnv1a(src + "|" + arch + "|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
+                                       "|" + std::to_string(hip_ver) + "|" + defines_key));
     const std::string dir = cfg.cache_dir ? std::string(cfg.cache_dir) : default_cache_dir();
     const std::string path = dir + "/" + name + "-" + arch + "-" + key + ".hsaco";
     if (read_file(path, code)) return KMC_OK;
@@ -179,8 +198,9 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
     if (hiprtcCreateProgram(&prog, src.c_str(), "kmc_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(KMC_E_COMPILE, "hiprtcCreateProgram failed");
     const std::string archopt = "--offload-arch=" + arch;
-    const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17"};
-    hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    std::vector<const char*> opts = {archopt.c_str(), "-O3", "-std=c++17"};
+    for (const std::string& d : defines) opts.push_back(d.c_str());
+    hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);
@@ -285,7 +305,8 @@ KmcArgs base_args(kmc_handle* h, int ctl_slot) {
 unsigned expand_grid(kmc_handle* h, uint64_t n) {
     const uint64_t tiles = (n + 63) / 64;
     uint64_t blocks = (tiles + KMC_WAVES - 1) / KMC_WAVES;
-    const uint64_t maxb = (uint64_t)h->n_cus * 6;  // resident blocks: 6 per CU at 79 VGPRs
+    static const int per_cu = getenv("KMC_BLOCKS_PER_CU") ? atoi(getenv("KMC_BLOCKS_PER_CU")) : 5;
+    const uint64_t maxb = (uint64_t)h->n_cus * (per_cu > 0 ? per_cu : 5);  // resident blocks per CU
     if (blocks > maxb) blocks = maxb;
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;

@@ -1,0 +1,9 @@
+#!/bin/sh
+# Regenerates the large-configuration golden fixtures with the C oracle (several minutes and
+# ~30 GB of RAM for 3/6/6/2).  The reference repository holds no golden vectors at all; these
+# pin the GPU engine at the headline size to the exact-state CPU oracle.
+set -e
+cd "$(dirname "$0")/../.."
+make -s -C oracle
+./oracle/kmc_oracle --model Kip320 --N 3 --L 5 --R 5 --E 2 --threads 8 --inv 7 > tests/golden/oracle_kip320_3_5_5_2.json
+./oracle/kmc_oracle --model Kip320 --N 3 --L 6 --R 6 --E 2 --threads 8 --inv 7 > tests/golden/oracle_kip320_3_6_6_2.json
