@@ -80,7 +80,7 @@ typedef struct kmc_config {
     int32_t check_deadlock;     /* TLC default is on; these bounded models need it off (-deadlock) */
     int32_t continue_on_violation; /* TLC -continue: keep exploring after the first violation */
     int32_t keep_trace;         /* keep predecessor fingerprints (8 B per table slot) for kmc_trace */
-    int32_t device;             /* HIP device ordinal */
+    int32_t device;             /* HIP device ordinal; -1 = host-only handle (pack/unpack/fingerprint only) */
     int32_t n_shards;           /* 1 = single GPU; P>1: this handle owns fingerprints with owner(fp)==shard_id */
     int32_t shard_id;
     uint64_t table_capacity;    /* fingerprint slots (rounded up to a power of two); 0 = auto from free HBM */
@@ -169,6 +169,9 @@ const char* kmc_invariant_name(int32_t index);
 int kmc_step_begin(kmc_handle* h);                       /* reset, insert Init on its owner */
 int kmc_step_expand(kmc_handle* h, uint64_t send_counts[KMC_MAX_SHARDS]);
 int kmc_step_send_buffer(kmc_handle* h, int32_t dst, void** dev_ptr, uint64_t* record_words);
+/* Let the caller own the send area (n_shards * records_per_destination * (state_words+1) uint64),
+ * e.g. a torch tensor that is handed to the collective without a copy. */
+int kmc_step_set_send_buffer(kmc_handle* h, void* dev_ptr, uint64_t records_per_destination);
 int kmc_step_insert(kmc_handle* h, const void* dev_records, uint64_t n_records);
 int kmc_step_finish(kmc_handle* h, kmc_level_info* info); /* info->new_states: this shard's next frontier */
 int kmc_step_set_verdict(kmc_handle* h, int32_t verdict); /* driver-decided global stop reason */

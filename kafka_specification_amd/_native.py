@@ -82,6 +82,7 @@ SYMBOLS = [
     ("kmc_step_begin", C.c_int, [_H]),
     ("kmc_step_expand", C.c_int, [_H, C.POINTER(C.c_uint64)]),
     ("kmc_step_send_buffer", C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("kmc_step_set_send_buffer", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("kmc_step_insert", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("kmc_step_finish", C.c_int, [_H, C.POINTER(KmcLevelInfo)]),
     ("kmc_step_set_verdict", C.c_int, [_H, C.c_int32]),

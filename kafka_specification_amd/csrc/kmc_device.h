@@ -45,6 +45,7 @@ typedef unsigned int u32;
 #define KMC_MAX_KINDS 16
 #define KMC_MAX_SHARDS 8
 #define KMC_QCAP 128  // per-wave LDS ring capacity (successors); flush granularity is 64
+#define KMC_SEGS 8    // frontier segments, each with its own append counter (block b appends to b % KMC_SEGS)
 
 // tuning knobs (the host may override them per code object through KMC_JIT_DEFINES)
 #ifndef KMC_OUT_STAGE
@@ -56,7 +57,7 @@ typedef unsigned int u32;
 
 // One per BFS level; the host zeroes it before the level runs and reads it back after.
 struct KmcLevelCtl {
-    u64 next_count;                  // states appended to the next frontier
+    u64 next_count[KMC_SEGS];        // states appended to each segment of the next frontier
     u64 generated[KMC_MAX_KINDS];    // successors generated per action kind (Next disjunct)
     u64 viol_count[4];               // new states violating invariant k
     u64 viol_fp_inv[4];              // max over violators of ~fp  (=> min fp), 0 = none
@@ -70,12 +71,15 @@ struct KmcLevelCtl {
 };
 
 struct KmcArgs {
-    const u64* fin;    // current frontier, SoA planes
+    // Frontiers are SoA: word k of the state at slot i lives at f[k*stride + i].  A frontier is
+    // KMC_SEGS dense segments; segment s occupies slots [s*seg_cap, s*seg_cap + seg_count[s]).
+    const u64* fin;    // current frontier
     u64 fin_stride;    // plane stride in states
-    u64 n_in;          // number of states in the current frontier (k_expand) / records (k_insert)
-    u64* fout;         // next frontier, SoA planes
+    u64 n_in;          // k_insert: number of records
+    u64 seg_count[KMC_SEGS];  // k_expand / k_find: states per segment of the current frontier
+    u64 seg_cap;       // slots per segment (both frontiers)
+    u64* fout;         // next frontier
     u64 fout_stride;
-    u64 fout_cap;
     u64* table;        // open-addressed fingerprint table, 0 = empty
     u64 table_mask;    // capacity-1 (capacity is a power of two)
     u64* pred;         // optional: predecessor fingerprint per table slot (trace reconstruction)
@@ -128,18 +132,23 @@ KMC_DEV void kmc_launder(u32& x) { asm volatile("" : "+v"(x)); }
 KMC_DEV void kmc_launder(u64& x) { asm volatile("" : "+v"(x)); }
 
 // 64-bit fingerprint of a packed state.  Never 0 (0 marks an empty table slot).
+// Every state word is absorbed through a full-avalanche bijection (the splitmix64 / murmur3
+// finaliser: two multiplies, three xor-shifts).  A single multiply + xor-shift per word is NOT
+// enough here: packed states are highly structured, differences that survive one weak round
+// line up with differences in the next word and produce systematic collisions (seen as 32
+// missing states out of 75,569,791 on Kip320 3/5/5/2).
+KMC_HD inline u64 kmc_mix64(u64 x) {
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
 template <int W> KMC_HD inline u64 kmc_fingerprint(const u64* w, u64 seed) {
-    u64 h = seed ^ (0x9E3779B97F4A7C15ull * (u64)(W + 1));
+    u64 h = kmc_mix64(seed + 0x9E3779B97F4A7C15ull * (u64)(W + 1));
 #pragma unroll
-    for (int k = 0; k < W; ++k) {
-        h ^= w[k];
-        h *= 0xff51afd7ed558ccdull;
-        h ^= h >> 32;
-    }
-    h *= 0xc4ceb9fe1a85ec53ull;
-    h ^= h >> 29;
-    h *= 0xbf58476d1ce4e5b9ull;
-    h ^= h >> 32;
+    for (int k = 0; k < W; ++k) h = kmc_mix64(h ^ w[k]) + 0x9E3779B97F4A7C15ull;
     return h ? h : 1ull;
 }
 KMC_HD inline u32 kmc_owner(u64 fp, u32 nshards) { return (u32)((fp >> 40) % nshards); }
@@ -628,13 +637,14 @@ template <int W> struct KmcStager {
 
     KMC_DEV void drain(const KmcArgs& a, u32 n) {  // n <= 64 staged states -> next frontier
         const u32 lane = kmc_lane();
+        const u32 seg = blockIdx.x % KMC_SEGS;
         u64 base = 0;
-        if (lane == 0) base = atomicAdd(&a.ctl->next_count, (u64)n);
+        if (lane == 0) base = atomicAdd(&a.ctl->next_count[seg], (u64)n);
         base = kmc_bcast64(base, 0);
         if (lane < n) {
             const u32 pos = (head + lane) & (KMC_QCAP - 1);
-            const u64 idx = base + lane;
-            if (idx < a.fout_cap) {
+            if (base + lane < a.seg_cap) {
+                const u64 idx = (u64)seg * a.seg_cap + base + lane;
 #pragma unroll
                 for (int k = 0; k < W; ++k) a.fout[(u64)k * a.fout_stride + idx] = planes[k * KMC_QCAP + pos];
             } else {
@@ -717,12 +727,13 @@ template <class M> struct KmcSink {
             if (m) {
                 const int leader = __builtin_ctzll(m);
                 const u32 n = __popcll(m);
+                const u32 seg = blockIdx.x % KMC_SEGS;
                 u64 base = 0;
-                if ((int)kmc_lane() == leader) base = atomicAdd(&a.ctl->next_count, (u64)n);
-                base = kmc_bcast64(base, leader);
-                const u64 idx = base + kmc_rank_in(m);
+                if ((int)kmc_lane() == leader) base = atomicAdd(&a.ctl->next_count[seg], (u64)n);
+                base = kmc_bcast64(base, leader) + kmc_rank_in(m);
+                const u64 idx = (u64)seg * a.seg_cap + base;
                 if (isnew) {
-                    if (idx < a.fout_cap) {
+                    if (base < a.seg_cap) {
 #pragma unroll
                         for (int k = 0; k < W; ++k) a.fout[(u64)k * a.fout_stride + idx] = t[k];
                     } else {
@@ -795,10 +806,21 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     };
 
     const u64 nwaves = (u64)gridDim.x * KMC_WAVES;
-    const u64 ntiles = (a.n_in + 63) >> 6;
+    u64 tstart[KMC_SEGS + 1];  // wave-uniform: first 64-state tile of each segment
+    tstart[0] = 0;
+#pragma unroll
+    for (int sg = 0; sg < KMC_SEGS; ++sg) tstart[sg + 1] = tstart[sg] + ((a.seg_count[sg] + 63) >> 6);
+    const u64 ntiles = tstart[KMC_SEGS];
     for (u64 tile = (u64)blockIdx.x * KMC_WAVES + wib; tile < ntiles; tile += nwaves) {
-        const u64 idx = (tile << 6) + lane;
-        const bool valid = idx < a.n_in;
+        u64 idx = 0;
+        bool valid = false;
+#pragma unroll
+        for (int sg = 0; sg < KMC_SEGS; ++sg)
+            if (tile >= tstart[sg] && tile < tstart[sg + 1]) {
+                const u64 j = ((tile - tstart[sg]) << 6) + lane;
+                valid = j < a.seg_count[sg];
+                idx = (u64)sg * a.seg_cap + j;
+            }
         u64 s[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) s[k] = valid ? a.fin[(u64)k * a.fin_stride + idx] : 0ull;
@@ -896,15 +918,17 @@ template <class M> KMC_DEV void kmc_init_body(const KmcArgs& a) {
 template <class M> KMC_DEV void kmc_find_body(const KmcArgs& a) {
     constexpr int W = M::W;
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; idx < a.n_in; idx += stride) {
-        u64 s[W];
+    for (int sg = 0; sg < KMC_SEGS; ++sg)
+        for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < a.seg_count[sg]; j += stride) {
+            const u64 idx = (u64)sg * a.seg_cap + j;
+            u64 s[W];
 #pragma unroll
-        for (int k = 0; k < W; ++k) s[k] = a.fin[(u64)k * a.fin_stride + idx];
-        if (kmc_fingerprint<W>(s, a.seed) == a.table_mask) {
-            for (int k = 0; k < W; ++k) a.send[k] = s[k];
-            a.send[W] = idx;
+            for (int k = 0; k < W; ++k) s[k] = a.fin[(u64)k * a.fin_stride + idx];
+            if (kmc_fingerprint<W>(s, a.seed) == a.table_mask) {
+                for (int k = 0; k < W; ++k) a.send[k] = s[k];
+                a.send[W] = idx;
+            }
         }
-    }
 }
 
 #define KMC_INSTANTIATE(NAME, ...)                                                                       \

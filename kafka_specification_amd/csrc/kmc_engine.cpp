@@ -265,9 +265,12 @@ struct kmc_handle {
     uint64_t enum_cap = 4096;
     u64* send = nullptr;         // SHARDED send buffers
     uint64_t send_cap = 0;
+    bool send_owned = true;
     // run state
     int cur = 0;                 // frontier[cur] holds the last completed level
     uint64_t n_cur = 0;          // its size on this shard
+    uint64_t seg_n[KMC_SEGS] = {0};  // ... per segment
+    uint64_t seg_cap = 0;        // slots per segment
     uint64_t level = 0;          // number of completed levels
     bool stepping = false, step_expanded = false;
     std::vector<uint64_t> levels;
@@ -298,7 +301,8 @@ KmcArgs base_args(kmc_handle* h, int ctl_slot) {
     a.flags = h->cfg.keep_trace ? KMC_FLAG_TRACE : 0u;
     a.nshards = (uint32_t)h->cfg.n_shards;
     a.fin_stride = a.fout_stride = h->fcap;
-    a.fout_cap = h->fcap;
+    a.seg_cap = h->seg_cap;
+    for (int sg = 0; sg < KMC_SEGS; ++sg) a.seg_count[sg] = h->seg_n[sg];
     return a;
 }
 
@@ -323,10 +327,22 @@ int zero_ctl(kmc_handle* h, int slot) {
     return KMC_OK;
 }
 
-int find_state(kmc_handle* h, const u64* frontier, uint64_t n, uint64_t fp, std::vector<uint64_t>* out) {
+// Segment sizes the device reported for the level it just produced (clipped to capacity).
+uint64_t produced_segments(kmc_handle* h, const KmcLevelCtl& c, uint64_t seg[KMC_SEGS]) {
+    uint64_t total = 0;
+    for (int sg = 0; sg < KMC_SEGS; ++sg) {
+        seg[sg] = c.next_count[sg] < h->seg_cap ? c.next_count[sg] : h->seg_cap;
+        total += seg[sg];
+    }
+    return total;
+}
+
+int find_state(kmc_handle* h, const u64* frontier, const uint64_t seg[KMC_SEGS], uint64_t fp,
+               std::vector<uint64_t>* out) {
     KmcArgs a = base_args(h, 2);
     a.fin = frontier;
-    a.n_in = n;
+    uint64_t n = 0;
+    for (int sg = 0; sg < KMC_SEGS; ++sg) { a.seg_count[sg] = seg[sg]; n += seg[sg]; }
     a.table_mask = fp;  // kmc_find_body takes the target here
     a.send = h->scratch;
     HIP_TRY(hipMemsetAsync(h->scratch, 0xFF, (h->W + 1) * 8, h->stream));
@@ -354,6 +370,7 @@ int reset_run(kmc_handle* h) {
     h->res.state_bits = h->lay.bits;
     h->cur = 0;
     h->n_cur = 0;
+    for (int sg = 0; sg < KMC_SEGS; ++sg) h->seg_n[sg] = 0;
     h->level = 0;
     h->t_start = now_s();
     return KMC_OK;
@@ -361,8 +378,8 @@ int reset_run(kmc_handle* h) {
 
 // Fold the device counters of the level that was just produced into the running result.
 // `produced` = states now in frontier[next]; returns true when the search must stop.
-bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, uint64_t parent_n,
-            const u64* new_frontier, uint64_t new_n, int* rc) {
+bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, const uint64_t* parent_seg,
+            const u64* new_frontier, const uint64_t* new_seg, int* rc) {
     kmc_result& r = h->res;
     *rc = KMC_OK;
     for (int k = 0; k < KMC_MAX_KINDS; ++k) {
@@ -377,7 +394,7 @@ bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, uin
         r.violation_depth = h->level;  // depth of the deadlocked (parent) level
         r.violation_fp = ~c.deadlock_fp_inv;
         if (parent_frontier && h->cfg.n_shards == 1) {
-            *rc = find_state(h, parent_frontier, parent_n, r.violation_fp, &h->witness);
+            *rc = find_state(h, parent_frontier, parent_seg, r.violation_fp, &h->witness);
             h->have_witness = *rc == KMC_OK;
         }
         return true;
@@ -390,7 +407,7 @@ bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, uin
                 r.violation_fp = ~c.viol_fp_inv[k];
                 for (int j = 0; j < 4; ++j) r.violation_count[j] = c.viol_count[j];
                 if (new_frontier && h->cfg.n_shards == 1) {
-                    *rc = find_state(h, new_frontier, new_n, r.violation_fp, &h->witness);
+                    *rc = find_state(h, new_frontier, new_seg, r.violation_fp, &h->witness);
                     h->have_witness = *rc == KMC_OK;
                 }
                 break;
@@ -426,11 +443,11 @@ int do_begin(kmc_handle* h) {
         h->res.generated = 1;
     }
     if ((rc = read_ctl(h, 0))) return rc;
-    h->n_cur = h->ctl_host->next_count;
+    h->n_cur = produced_segments(h, *h->ctl_host, h->seg_n);
     h->cur = 0;
     h->res.distinct = h->n_cur;
     h->levels.push_back(h->n_cur);
-    bool stop = absorb(h, *h->ctl_host, nullptr, 0, h->frontier[0], h->n_cur, &rc);
+    bool stop = absorb(h, *h->ctl_host, nullptr, nullptr, h->frontier[0], h->seg_n, &rc);
     h->level = 1;
     h->res.depth = 1;
     (void)stop;
@@ -478,6 +495,11 @@ int kmc_precompile(const kmc_config* cfg, const char* arch) {
 
 void kmc_close(kmc_handle* h) {
     if (!h) return;
+    if (h->cfg.device < 0 || !h->stream) {  // host-only handle, or open failed before any device work
+        if (h->mod) hipModuleUnload(h->mod);
+        delete h;
+        return;
+    }
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->table) hipFree(h->table);
@@ -487,7 +509,7 @@ void kmc_close(kmc_handle* h) {
     if (h->ctl) hipFree(h->ctl);
     if (h->scratch) hipFree(h->scratch);
     if (h->enum_out) hipFree(h->enum_out);
-    if (h->send) hipFree(h->send);
+    if (h->send && h->send_owned) hipFree(h->send);
     if (h->ctl_host) hipHostFree(h->ctl_host);
     if (h->scratch_host) hipHostFree(h->scratch_host);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -508,6 +530,7 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
         return get_code_object(h->cfg, "gfx950", &dummy, &name);  // produces the KMC_E_ARG message
     }
     h->W = h->lay.W;
+    if (cfg->device == -1) return KMC_OK;  // host-only handle: pack/unpack/fingerprint, no device work
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(KMC_E_DEVICE, "no HIP device visible: this library has no CPU fallback");
@@ -546,9 +569,10 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
         if (fcap > tcap) fcap = tcap;
     }
     if (fcap < 64) fcap = 64;
-    fcap = (fcap + 63) & ~63ull;  // keep planes 512-byte aligned
+    fcap = (fcap + 64 * KMC_SEGS - 1) / (64 * KMC_SEGS) * (64 * KMC_SEGS);  // segments start 512-byte aligned
     h->table_cap = tcap;
     h->fcap = fcap;
+    h->seg_cap = fcap / KMC_SEGS;
     if (hipMalloc(&h->table, tcap * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate %llu table slots", (unsigned long long)tcap);
     if (cfg->keep_trace && hipMalloc(&h->pred, tcap * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate predecessor table");
     for (int i = 0; i < 2; ++i)
@@ -699,6 +723,7 @@ int kmc_pack_state(kmc_handle* h, const uint8_t* c, uint64_t* words) {
 
 int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
     if (!h) return fail(KMC_E_ARG, "null handle");
+    if (!h->table) return fail(KMC_E_STATE, "host-only handle (device = -1) cannot run");
     if (h->cfg.n_shards != 1) return fail(KMC_E_STATE, "kmc_run drives one GPU; use the kmc_step_* interface for shards");
     HIP_TRY(hipSetDevice(h->cfg.device));
     h->stepping = false;
@@ -723,7 +748,6 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
         if ((rc = zero_ctl(h, slot))) return rc;
         KmcArgs a = base_args(h, slot);
         a.fin = h->frontier[h->cur];
-        a.n_in = h->n_cur;
         a.fout = h->frontier[nxt];
         a.mode = KMC_MODE_LOCAL;
         HIP_TRY(hipEventRecord(h->ev0, h->stream));
@@ -735,8 +759,9 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
         r.seconds_expand += 1e-3 * ms;
         r.expand_launches++;
         const KmcLevelCtl c = *h->ctl_host;
-        const uint64_t produced = c.next_count < h->fcap ? c.next_count : h->fcap;
-        stop = absorb(h, c, h->frontier[h->cur], h->n_cur, h->frontier[nxt], produced, &rc);
+        uint64_t new_seg[KMC_SEGS];
+        const uint64_t produced = produced_segments(h, c, new_seg);
+        stop = absorb(h, c, h->frontier[h->cur], h->seg_n, h->frontier[nxt], new_seg, &rc);
         if (rc) return rc;
         if (r.verdict == KMC_V_DEADLOCK || r.verdict == KMC_V_TABLE_FULL || r.verdict == KMC_V_FRONTIER_FULL) {
             r.queue_left = h->n_cur;
@@ -748,6 +773,7 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
         }
         h->cur = nxt;
         h->n_cur = produced;
+        for (int sg = 0; sg < KMC_SEGS; ++sg) h->seg_n[sg] = new_seg[sg];
         h->level++;
         r.depth = h->level;
         r.distinct += produced;
@@ -775,20 +801,28 @@ uint64_t kmc_level_sizes(kmc_handle* h, uint64_t* out, uint64_t cap) {
 
 int kmc_frontier_states(kmc_handle* h, uint64_t* words, uint64_t cap_states, uint64_t* n_out) {
     if (!h || !n_out) return fail(KMC_E_ARG, "null argument");
+    if (!h->table) return fail(KMC_E_STATE, "host-only handle");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const uint64_t n = h->n_cur < cap_states ? h->n_cur : cap_states;
     *n_out = h->n_cur;
     if (n == 0) return KMC_OK;
-    std::vector<uint64_t> plane(n);
-    for (int k = 0; k < h->W; ++k) {
-        HIP_TRY(hipMemcpy(plane.data(), h->frontier[h->cur] + (uint64_t)k * h->fcap, n * 8, hipMemcpyDeviceToHost));
-        for (uint64_t i = 0; i < n; ++i) words[i * h->W + k] = plane[i];
+    std::vector<uint64_t> plane(h->seg_cap);
+    uint64_t at = 0;
+    for (int sg = 0; sg < KMC_SEGS && at < n; ++sg) {
+        const uint64_t m = h->seg_n[sg] < n - at ? h->seg_n[sg] : n - at;
+        for (int k = 0; k < h->W && m; ++k) {
+            HIP_TRY(hipMemcpy(plane.data(), h->frontier[h->cur] + (uint64_t)k * h->fcap + (uint64_t)sg * h->seg_cap,
+                              m * 8, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < m; ++i) words[(at + i) * h->W + k] = plane[i];
+        }
+        at += m;
     }
     return KMC_OK;
 }
 
 int kmc_successors(kmc_handle* h, const uint64_t* words, uint64_t* out, uint64_t cap, uint64_t* n_out) {
     if (!h || !words || !n_out) return fail(KMC_E_ARG, "null argument");
+    if (!h->table) return fail(KMC_E_STATE, "host-only handle");
     HIP_TRY(hipSetDevice(h->cfg.device));
     // the auxiliary frontier is the scratch buffer viewed as SoA with stride 1... planes must be
     // fin[k*stride + 0], so stride 1 puts the W words back to back
@@ -798,7 +832,7 @@ int kmc_successors(kmc_handle* h, const uint64_t* words, uint64_t* out, uint64_t
     KmcArgs a = base_args(h, 2);
     a.fin = h->scratch;
     a.fin_stride = 1;
-    a.n_in = 1;
+    for (int sg = 0; sg < KMC_SEGS; ++sg) a.seg_count[sg] = sg == 0 ? 1 : 0;
     a.mode = KMC_MODE_ENUM;
     a.send = h->enum_out;
     a.send_cap = h->enum_cap;
@@ -890,6 +924,7 @@ int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap
 // ---- level-step interface ---------------------------------------------------------------
 int kmc_step_begin(kmc_handle* h) {
     if (!h) return fail(KMC_E_ARG, "null handle");
+    if (!h->table) return fail(KMC_E_STATE, "host-only handle (device = -1) cannot run");
     HIP_TRY(hipSetDevice(h->cfg.device));
     int rc = do_begin(h);
     h->stepping = true;
@@ -906,7 +941,6 @@ int kmc_step_expand(kmc_handle* h, uint64_t send_counts[KMC_MAX_SHARDS]) {
     if (rc) return rc;
     KmcArgs a = base_args(h, slot);
     a.fin = h->frontier[h->cur];
-    a.n_in = h->n_cur;
     a.fout = h->frontier[h->cur ^ 1];
     a.mode = KMC_MODE_SHARDED;
     a.send = h->send;
@@ -926,6 +960,16 @@ int kmc_step_expand(kmc_handle* h, uint64_t send_counts[KMC_MAX_SHARDS]) {
         send_counts[d] = c < h->send_cap ? c : h->send_cap;
     }
     h->step_expanded = true;
+    return KMC_OK;
+}
+
+int kmc_step_set_send_buffer(kmc_handle* h, void* dev_ptr, uint64_t records_per_destination) {
+    if (!h || !dev_ptr || records_per_destination == 0) return fail(KMC_E_ARG, "bad send buffer");
+    if (h->cfg.n_shards <= 1) return fail(KMC_E_STATE, "handle was opened with n_shards == 1");
+    if (h->send && h->send_owned) hipFree(h->send);
+    h->send = (u64*)dev_ptr;
+    h->send_cap = records_per_destination;
+    h->send_owned = false;
     return KMC_OK;
 }
 
@@ -960,11 +1004,14 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
     if (rc) return rc;
     const KmcLevelCtl c = *h->ctl_host;
     const int nxt = h->cur ^ 1;
-    const uint64_t produced = c.next_count < h->fcap ? c.next_count : h->fcap;
-    absorb(h, c, h->frontier[h->cur], h->n_cur, h->frontier[nxt], produced, &rc);
+    uint64_t new_seg[KMC_SEGS];
+    const uint64_t produced = produced_segments(h, c, new_seg);
+    absorb(h, c, h->frontier[h->cur], h->seg_n, h->frontier[nxt], new_seg, &rc);
     h->cur = nxt;
     h->n_cur = produced;
+    for (int sg = 0; sg < KMC_SEGS; ++sg) h->seg_n[sg] = new_seg[sg];
     h->level++;
+    if (produced) h->res.depth = h->level;
     h->res.distinct += produced;
     h->levels.push_back(produced);
     h->step_expanded = false;

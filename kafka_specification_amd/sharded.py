@@ -1,0 +1,295 @@
+"""Multi-GPU BFS: the fingerprint space is hash-partitioned across shards (one shard per GPU,
+one process per GPU) and every BFS level exchanges successor states with one all-to-all.
+
+    owner(state) = (fingerprint >> 40) % P            (csrc/kmc_device.h: kmc_owner)
+
+Per level, on every shard:  expand the local frontier, bucketing each successor into the send
+area of its owner (k_expand, mode SHARDED)  ->  all-to-all-v of packed states (W+1 words: the
+state and its predecessor fingerprint; the owner recomputes the fingerprint because it must
+later expand the state)  ->  the owner probes/inserts what it received, checks invariants on
+the winners and appends them to its next frontier (k_insert)  ->  all-reduce of a small
+statistics vector (new states, generated, violations, deadlocks, error flags) decides
+termination and the verdict identically on every rank.
+
+The level logic is written against two small interfaces so that it can be exercised without
+GPUs:
+  * an *engine* (begin / expand / insert / finish) — `HipShardEngine` drives libkmc.so's
+    kmc_step_* entry points; the CPU tests plug in an oracle-backed stand-in;
+  * an *exchange* — `DistExchange` is torch.distributed (RCCL on GPUs, gloo in the CPU
+    tests), `LoopbackExchange` routes between several engines living in one process (P
+    logical shards on one GPU; RCCL refuses two ranks on one device).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from dataclasses import replace
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as nat
+from .checker import CheckerConfig, CheckResult, ModelChecker
+
+N_STATS = 32  # [new, generated[16], viol[4], deadlocks, err_table, err_frontier, send_overflow, ...]
+
+
+class HipShardEngine:
+    """One shard on one GPU through the kmc_step_* C ABI."""
+
+    def __init__(self, cfg: CheckerConfig, shard_id: int, n_shards: int, device: int):
+        import torch
+        self.torch = torch
+        self.cfg = replace(cfg, n_shards=n_shards, shard_id=shard_id, device=device)
+        self.shard_id, self.n_shards = shard_id, n_shards
+        self.device = torch.device("cuda", device)
+        self.mc = ModelChecker(self.cfg)
+        self.lib = nat.lib()
+        self.W = self.mc.state_words
+        self.record_words = self.W + 1
+        # the send area belongs to torch so that slices of it can be handed to the collective
+        scap = cfg.send_capacity or max(1 << 16, (cfg.frontier_capacity or (1 << 22)) * 2 // n_shards)
+        self.send_cap = scap
+        self.send = torch.zeros((n_shards, scap, self.record_words), dtype=torch.int64, device=self.device)
+        nat.check(self.lib.kmc_step_set_send_buffer(self.mc.handle, C.c_void_p(self.send.data_ptr()), scap))
+        self._last = None
+
+    def close(self):
+        self.torch.cuda.synchronize(self.device)
+        self.mc.close()
+
+    def begin(self):
+        nat.check(self.lib.kmc_step_begin(self.mc.handle))
+        self._last = self.mc.result()
+        return self._stats(self._last, None, first=True)
+
+    def expand(self):
+        counts = (C.c_uint64 * nat.KMC_MAX_SHARDS)()
+        nat.check(self.lib.kmc_step_expand(self.mc.handle, counts))
+        return [self.send[d, :int(counts[d])] for d in range(self.n_shards)]
+
+    def insert(self, records):
+        n = int(records.shape[0])
+        if n:
+            assert records.is_contiguous()
+            nat.check(self.lib.kmc_step_insert(self.mc.handle, C.c_void_p(records.data_ptr()), n))
+
+    def finish(self):
+        info = nat.KmcLevelInfo()
+        nat.check(self.lib.kmc_step_finish(self.mc.handle, C.byref(info)))
+        r = self.mc.result()
+        st = self._stats(r, self._last, first=False)
+        self._last = r
+        return st
+
+    def _stats(self, r: CheckResult, prev: Optional[CheckResult], first: bool):
+        st = np.zeros(N_STATS, dtype=np.int64)
+        st[0] = r.levels[-1] if r.levels else 0
+        gen = list(r.action_generated.values())
+        pgen = list(prev.action_generated.values()) if prev else [0] * len(gen)
+        for k, g in enumerate(gen):
+            st[1 + k] = g - pgen[k]
+        if first:
+            st[1 + 15] = r.generated  # the initial state counts as generated on its owner
+        if r.violated_invariant is not None and r.violation_depth == len(r.levels) and \
+                (prev is None or prev.violated_invariant is None):
+            for k, name in enumerate(nat.INVARIANT_NAMES):
+                st[17 + k] = r.violation_count[name]
+        st[21] = r.deadlock_states - (prev.deadlock_states if prev else 0)
+        st[22] = 1 if r.verdict == "table_full" else 0
+        st[23] = 1 if r.verdict == "frontier_full" else 0
+        return st
+
+    def result(self) -> CheckResult:
+        return self.mc.result()
+
+
+class LoopbackExchange:
+    """P engines in one process; the all-to-all is a routing of tensor references."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def all_to_all(self, sends):  # sends[i][d] -> recvs[d][i]
+        return [[sends[i][d] for i in range(self.n)] for d in range(self.n)]
+
+    def all_reduce_sum(self, stats):
+        return np.sum(np.stack(stats), axis=0)
+
+    def all_reduce_max(self, x: float) -> float:
+        return x
+
+    def barrier(self):
+        pass
+
+
+class DistExchange:
+    """torch.distributed: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+    One engine per process."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.device = device if device is not None else torch.device("cpu")
+
+    def all_to_all(self, sends):
+        torch, dist = self.torch, self.dist
+        (mine,) = sends
+        words = int(mine[0].shape[1]) if mine[0].dim() == 2 else 1
+        in_counts = torch.tensor([int(t.shape[0]) for t in mine], dtype=torch.int64, device=self.device)
+        out_counts = torch.empty_like(in_counts)
+        dist.all_to_all_single(out_counts, in_counts)
+        in_split = [int(x) for x in in_counts.tolist()]
+        out_split = [int(x) for x in out_counts.tolist()]
+        send = torch.cat([t.reshape(-1, words) for t in mine], dim=0).contiguous()
+        recv = torch.empty((sum(out_split), words), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split)
+        return [[recv]]
+
+    def all_reduce_sum(self, stats):
+        torch, dist = self.torch, self.dist
+        t = torch.from_numpy(np.sum(np.stack(stats), axis=0)).to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def all_reduce_max(self, x: float) -> float:
+        torch, dist = self.torch, self.dist
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: List[str],
+                progress=None) -> CheckResult:
+    """Level-synchronous BFS over all shards.  Returns the global result (identical on every
+    rank).  `engines` are this process's shards."""
+    t0 = time.perf_counter()
+    inv_names = nat.INVARIANT_NAMES
+    levels, generated, deadlocks = [], 0, 0
+    action_generated = [0] * nat.KMC_MAX_KINDS
+    verdict, viol_inv, viol_depth, viol_count = "ok", None, 0, {n: 0 for n in inv_names}
+
+    def absorb(st, depth):
+        nonlocal generated, deadlocks, verdict, viol_inv, viol_depth, viol_count
+        new = int(st[0])
+        for k in range(15):
+            action_generated[k] += int(st[1 + k])
+            generated += int(st[1 + k])
+        generated += int(st[16])
+        deadlocks += int(st[21])
+        if st[22]:
+            verdict = "table_full"
+        elif st[23]:
+            verdict = "frontier_full"
+        if viol_inv is None:
+            counts = {n: int(st[17 + k]) for k, n in enumerate(inv_names)}
+            hit = [n for n in inv_names if n in cfg.invariants and counts[n]]
+            if hit:
+                viol_inv, viol_depth, viol_count = hit[0], depth, counts
+                verdict = "invariant"
+        return new
+
+    st = exchange.all_reduce_sum([e.begin() for e in engines])
+    new = absorb(st, 1)
+    levels.append(new)
+    depth = 1
+    if progress:
+        progress(dict(depth=depth, new_states=new, generated=generated, distinct=sum(levels)))
+    max_levels = cfg.max_levels or (1 << 62)
+    while new > 0 and depth < max_levels:
+        if verdict in ("table_full", "frontier_full") or (verdict == "invariant" and not cfg.continue_on_violation):
+            break
+        sends = [e.expand() for e in engines]
+        recvs = exchange.all_to_all(sends)
+        for e, rs in zip(engines, recvs):
+            for r in rs:
+                e.insert(r)
+        st = exchange.all_reduce_sum([e.finish() for e in engines])
+        dl_before = deadlocks
+        new = absorb(st, depth + 1)
+        if cfg.check_deadlock and deadlocks > dl_before and verdict == "ok":
+            verdict, viol_depth = "deadlock", depth
+            break
+        if new == 0:
+            break
+        depth += 1
+        levels.append(new)
+        if progress:
+            progress(dict(depth=depth, new_states=new, generated=generated, distinct=sum(levels)))
+    if depth >= max_levels and new > 0 and verdict == "ok":
+        verdict = "level_limit"
+    local = [e.result() for e in engines]
+    return CheckResult(
+        generated=generated, distinct=sum(levels), depth=len(levels),
+        queue_left=new if verdict != "ok" else 0, verdict=verdict, violated_invariant=viol_inv,
+        violation_depth=viol_depth, violation_count=viol_count, violation_fp=0, deadlock_states=deadlocks,
+        action_generated={n: action_generated[k] for k, n in enumerate(action_names)}, levels=levels,
+        table_capacity=sum(r.table_capacity for r in local), frontier_capacity=sum(r.frontier_capacity for r in local),
+        seconds_total=time.perf_counter() - t0, seconds_expand=max(r.seconds_expand for r in local),
+        expand_launches=max(r.expand_launches for r in local), state_words=local[0].state_words,
+        state_bits=local[0].state_bits)
+
+
+def check_loopback(cfg: CheckerConfig, n_shards: int, device: int = 0, progress=None) -> CheckResult:
+    """P logical shards on ONE GPU with an in-process exchange (tests the bucket / insert kernels
+    and the level logic without RCCL)."""
+    engines = [HipShardEngine(cfg, s, n_shards, device) for s in range(n_shards)]
+    try:
+        return run_sharded(engines, LoopbackExchange(n_shards), cfg, engines[0].mc.action_names(), progress)
+    finally:
+        for e in engines:
+            e.close()
+
+
+def check_distributed(cfg: CheckerConfig, progress=None) -> CheckResult:
+    """One shard per rank of the default process group (launch with torch.distributed.run)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    eng = HipShardEngine(cfg, rank, world, local)
+    try:
+        return run_sharded([eng], DistExchange(torch.device("cuda", local)), cfg, eng.mc.action_names(), progress)
+    finally:
+        eng.close()
+
+
+def bench_sharded(c: dict, steps: int, warmup: int):
+    """bench.py's N>1 leg: strong scaling of the headline check over the ranks of this job."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    per = max(1, world)
+    cfg = CheckerConfig(**c, table_capacity=int(os.environ.get("KMC_BENCH_TABLE", (1 << 30) // per * 2)),
+                        frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", (1 << 26) // per * 2)),
+                        send_capacity=int(os.environ.get("KMC_BENCH_SEND", (1 << 27) // (per * per))))
+    eng = HipShardEngine(cfg, rank, world, local)
+    ex = DistExchange(torch.device("cuda", local))
+    names = eng.mc.action_names()
+    results = []
+    try:
+        for _ in range(warmup):
+            run_sharded([eng], ex, cfg, names)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            results.append(run_sharded([eng], ex, cfg, names))
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = ex.all_reduce_max(time.perf_counter() - t0)
+    finally:
+        eng.close()
+    return results, dt, {"shards": world}

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Summarise tools/profile.sh output (rocprofv3 CSVs) for the dominant kernel kmc_expand_*:
+kernel-trace stats + PMC counters summed over the run's launches.
+usage: tools/summarize_profile.py gpurun_out/prof_<tag> [out.json]"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+d = sys.argv[1]
+out = {}
+# kernel trace
+rows = list(csv.DictReader(open(os.path.join(d, "trace", "trace_kernel_trace.csv"))))
+per = defaultdict(list)
+for r in rows:
+    per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+out["kernel_trace"] = {k: dict(calls=len(v), total_ns=sum(v), avg_ns=sum(v) / len(v), min_ns=min(v), max_ns=max(v))
+                       for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))}
+exp = [k for k in per if k.startswith("kmc_expand")][0]
+out["dominant_kernel"] = exp
+ex = [r for r in rows if r["Kernel_Name"] == exp]
+out["dominant_launch_cfg"] = {k: ex[-1].get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in ex[-1]}
+# counters
+ctr = defaultdict(float)
+for f in sorted(glob.glob(os.path.join(d, "pmc*", "pmc_counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"] == exp:
+            ctr[r["Counter_Name"]] += float(r["Counter_Value"])
+out["counters_sum_over_launches"] = dict(ctr)
+n = out["kernel_trace"][exp]["calls"]
+t = out["kernel_trace"][exp]["total_ns"] * 1e-9
+der = {}
+if "FETCH_SIZE" in ctr:
+    # rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; the guide's gfx950 correction (x2) applies
+    # to wide coalesced streaming reads only -- this kernel's reads are dominated by random 8-B
+    # probes, so both the raw and the doubled figure are given.
+    der["fetch_bytes_raw"] = ctr["FETCH_SIZE"] * 1024
+    der["fetch_bytes_x2_streaming_correction"] = 2 * ctr["FETCH_SIZE"] * 1024
+if "WRITE_SIZE" in ctr:
+    der["write_bytes_raw"] = ctr["WRITE_SIZE"] * 1024
+if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+    der["hbm_bytes_raw"] = der["fetch_bytes_raw"] + der["write_bytes_raw"]
+    der["hbm_bytes_per_launch_raw"] = der["hbm_bytes_raw"] / n
+    der["hbm_GBps_raw_over_kernel_time"] = der["hbm_bytes_raw"] / t / 1e9
+if ctr.get("TCC_HIT_sum") is not None and "TCC_MISS_sum" in ctr:
+    der["l2_hit_rate"] = ctr["TCC_HIT_sum"] / max(ctr["TCC_HIT_sum"] + ctr["TCC_MISS_sum"], 1)
+if "SQ_WAVE_CYCLES" in ctr:
+    wc = ctr["SQ_WAVE_CYCLES"]
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        if k in ctr:
+            der[k + "_frac_of_wave_cycles"] = ctr[k] / wc
+out["derived"] = der
+out["kernel_seconds_total"] = t
+out["launches"] = n
+js = json.dumps(out, indent=1)
+print(js)
+if len(sys.argv) > 2:
+    open(sys.argv[2], "w").write(js)
