@@ -1,0 +1,138 @@
+"""A reader for the subset of TLC's model-configuration (.cfg) syntax these specs need
+[TLC-recall]: CONSTANT(S), INIT, NEXT, SPECIFICATION, INVARIANT(S), CHECK_DEADLOCK, and
+`\\*` / `(* *)` comments.  SYMMETRY / CONSTRAINT / VIEW / PROPERTY are rejected: each one
+changes the set of distinct states (or asks for liveness), which this checker does not do.
+
+The reference repository ships no .cfg files (its .gitignore excludes *.toolbox), so the
+`models/*.cfg` twins in this repo are authored here; names bind to
+KafkaReplication.tla:32-36 (constants) and :101,320,334,345 (invariants).
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+from .checker import CheckerConfig
+
+KEYWORDS = {"CONSTANT", "CONSTANTS", "INIT", "NEXT", "SPECIFICATION", "INVARIANT", "INVARIANTS",
+            "CHECK_DEADLOCK", "SYMMETRY", "CONSTRAINT", "CONSTRAINTS", "ACTION_CONSTRAINT", "VIEW",
+            "PROPERTY", "PROPERTIES", "ALIAS", "POSTCONDITION"}
+UNSUPPORTED = {"SYMMETRY", "CONSTRAINT", "CONSTRAINTS", "ACTION_CONSTRAINT", "VIEW", "PROPERTY", "PROPERTIES",
+               "ALIAS", "POSTCONDITION"}
+
+
+class CfgError(ValueError):
+    pass
+
+
+@dataclass
+class ModelCfg:
+    constants: Dict[str, object] = field(default_factory=dict)
+    init: Optional[str] = None
+    next: Optional[str] = None
+    specification: Optional[str] = None
+    invariants: List[str] = field(default_factory=list)
+    check_deadlock: Optional[bool] = None
+
+
+def _strip_comments(text: str) -> str:
+    text = re.sub(r"\(\*.*?\*\)", " ", text, flags=re.S)
+    return "\n".join(line.split("\\*")[0] for line in text.splitlines())
+
+
+def _parse_value(tok: str):
+    tok = tok.strip()
+    if tok.startswith("{") and tok.endswith("}"):
+        inner = tok[1:-1].strip()
+        return [] if not inner else [_parse_value(x) for x in inner.split(",")]
+    if re.fullmatch(r"-?\d+", tok):
+        return int(tok)
+    if tok in ("TRUE", "FALSE"):
+        return tok == "TRUE"
+    if tok.startswith('"') and tok.endswith('"'):
+        return tok[1:-1]
+    return tok  # a model value
+
+
+def parse_cfg(text: str) -> ModelCfg:
+    cfg = ModelCfg()
+    toks = re.findall(r"\{[^}]*\}|\"[^\"]*\"|<-|=|[^\s=]+", _strip_comments(text))
+    i, section = 0, None
+    while i < len(toks):
+        t = toks[i]
+        if t in KEYWORDS:
+            if t in UNSUPPORTED:
+                raise CfgError(f"{t} is not supported (it changes the distinct-state count or asks for liveness)")
+            section = t
+            i += 1
+            continue
+        if section in ("CONSTANT", "CONSTANTS"):
+            if i + 2 < len(toks) + 1 and i + 1 < len(toks) and toks[i + 1] in ("=", "<-"):
+                if i + 2 >= len(toks):
+                    raise CfgError(f"constant {t} has no value")
+                cfg.constants[t] = _parse_value(toks[i + 2])
+                i += 3
+                continue
+            raise CfgError(f"expected `{t} = value` in CONSTANTS")
+        if section == "INIT":
+            cfg.init = t
+        elif section == "NEXT":
+            cfg.next = t
+        elif section == "SPECIFICATION":
+            cfg.specification = t
+        elif section in ("INVARIANT", "INVARIANTS"):
+            cfg.invariants.append(t)
+        elif section == "CHECK_DEADLOCK":
+            if t not in ("TRUE", "FALSE"):
+                raise CfgError("CHECK_DEADLOCK takes TRUE or FALSE")
+            cfg.check_deadlock = t == "TRUE"
+        else:
+            raise CfgError(f"unexpected token {t!r}")
+        i += 1
+    return cfg
+
+
+def to_checker_config(module: str, cfg: ModelCfg, **overrides) -> CheckerConfig:
+    """Bind a parsed .cfg to the lowered model of `module` (the root module's name)."""
+    from ._native import MODELS, INVARIANTS
+    if module not in MODELS:
+        raise CfgError(f"module {module!r} has no lowered model; known: {sorted(MODELS)}")
+    c = cfg.constants
+    kw: Dict[str, object] = dict(model=module)
+
+    def need(name):
+        if name not in c:
+            raise CfgError(f"constant {name} is not assigned in the .cfg")
+        return c[name]
+
+    if module == "IdSequence":
+        kw["max_id"] = int(need("MaxId"))
+        allowed_inv = {"TypeOk"}
+    elif module == "FiniteReplicatedLog":
+        reps, recs = need("Replicas"), need("LogRecords")
+        if not isinstance(reps, list) or not isinstance(recs, list):
+            raise CfgError("Replicas and LogRecords must be sets of model values")
+        need("Nil")
+        kw.update(n_replicas=len(reps), n_log_records=len(recs), log_size=int(need("LogSize")))
+        allowed_inv = {"TypeOk"}
+    else:
+        reps = need("Replicas")
+        if not isinstance(reps, list) or len(set(map(str, reps))) != len(reps):
+            raise CfgError("Replicas must be a set of distinct model values")
+        if "NONE" in map(str, reps):
+            raise CfgError('Replicas must not contain "NONE" (ASSUME None \\notin Replicas, KafkaReplication.tla:42)')
+        kw.update(n_replicas=len(reps), log_size=int(need("LogSize")), max_records=int(need("MaxRecords")),
+                  max_leader_epoch=int(need("MaxLeaderEpoch")))
+        allowed_inv = set(INVARIANTS)
+    if cfg.specification is not None and cfg.specification != "Spec":
+        raise CfgError("only SPECIFICATION Spec is known")
+    if cfg.init not in (None, "Init") or cfg.next not in (None, "Next"):
+        raise CfgError("only INIT Init / NEXT Next are known")
+    for inv in cfg.invariants:
+        if inv not in allowed_inv:
+            raise CfgError(f"unknown invariant {inv} for module {module}")
+    kw["invariants"] = tuple(cfg.invariants)
+    kw["check_deadlock"] = True if cfg.check_deadlock is None else cfg.check_deadlock  # TLC's default is TRUE
+    kw.update(overrides)
+    return CheckerConfig(**kw)

@@ -1,0 +1,48 @@
+"""Pretty-printing of canonical-byte states as TLA+ values, the way TLC prints a trace state
+(`/\\ var = value`) [TLC-recall].  The byte layout is documented in DESIGN.md §3."""
+from __future__ import annotations
+
+
+def _set(mask, names):
+    return "{" + ", ".join(names[r] for r in range(len(names)) if mask >> r & 1) + "}"
+
+
+def format_state(cfg, b: bytes) -> str:
+    m = cfg.model
+    if m == "IdSequence":
+        return f"nextId = {int.from_bytes(b[:8], 'little')}"
+    if m == "FiniteReplicatedLog":
+        N, L = cfg.n_replicas, cfg.log_size
+        reps = [f"r{r + 1}" for r in range(N)]
+        parts = []
+        for r in range(N):
+            blk = b[r * (1 + L):(r + 1) * (1 + L)]
+            recs = ", ".join("Nil" if c == 0 else f"x{c}" for c in blk[1:])
+            parts.append(f"{reps[r]} :> [endOffset |-> {blk[0]}, records |-> <<{recs}>>]")
+        return "logs = (" + " @@ ".join(parts) + ")"
+    N, L, E = cfg.n_replicas, cfg.log_size, cfg.max_leader_epoch
+    reps = [f"b{r + 1}" for r in range(N)]
+    rs = 5 + L
+
+    def ldr(x):
+        return '"NONE"' if x == 0 else reps[x - 1]
+
+    logs, states = [], []
+    for r in range(N):
+        blk = b[r * rs:(r + 1) * rs]
+        recs = ", ".join("-1" if c == 0 else f"[id |-> {(c - 1) // (E + 1)}, epoch |-> {(c - 1) % (E + 1)}]"
+                         for c in blk[5:])
+        logs.append(f"{reps[r]} :> [endOffset |-> {blk[0]}, records |-> <<{recs}>>]")
+        states.append(f"{reps[r]} :> [hw |-> {blk[1]}, leaderEpoch |-> {blk[2] - 1}, leader |-> {ldr(blk[3])}, "
+                      f"isr |-> {_set(blk[4], reps)}]")
+    g = b[N * rs:]
+    reqs = [f"[leaderEpoch |-> {e}, leader |-> {ldr(g[5 + 2 * e])}, isr |-> {_set(g[6 + 2 * e], reps)}]"
+            for e in range(g[1])]
+    return "\n".join([
+        "/\\ replicaLog = (" + " @@ ".join(logs) + ")",
+        "/\\ replicaState = (" + " @@ ".join(states) + ")",
+        f"/\\ nextRecordId = {g[0]}",
+        f"/\\ nextLeaderEpoch = {g[1]}",
+        "/\\ leaderAndIsrRequests = {" + ", ".join(reqs) + "}",
+        f"/\\ quorumState = [leaderEpoch |-> {g[2] - 1}, leader |-> {ldr(g[3])}, isr |-> {_set(g[4], reps)}]",
+    ])

@@ -1,0 +1,80 @@
+"""Host logic that needs no GPU: the .cfg reader, its binding to the lowered models, the state
+pretty-printer and the CLI's error paths."""
+import glob
+import os
+
+import pytest
+
+from kafka_specification_amd.cfg import CfgError, parse_cfg, to_checker_config
+from kafka_specification_amd.format import format_state
+from kafka_specification_amd import tlc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_headline_cfg_binds_to_the_headline_config():
+    from kafka_specification_amd.configs import HEADLINE
+    c = to_checker_config("Kip320", parse_cfg(open(os.path.join(ROOT, "models", "Kip320.cfg")).read()))
+    assert (c.model, c.n_replicas, c.log_size, c.max_records, c.max_leader_epoch) == (
+        HEADLINE["model"], HEADLINE["n_replicas"], HEADLINE["log_size"], HEADLINE["max_records"],
+        HEADLINE["max_leader_epoch"])
+    assert tuple(c.invariants) == tuple(HEADLINE["invariants"]) and c.check_deadlock is False
+
+
+def test_every_shipped_cfg_parses_and_binds():
+    for path in glob.glob(os.path.join(ROOT, "models", "*.cfg")):
+        name = os.path.splitext(os.path.basename(path))[0]
+        module = {"Kip279_5brokers": "Kip279", "Kip320_7brokers": "Kip320", "LeaderInIsr": "Kip320"}.get(name, name)
+        c = to_checker_config(module, parse_cfg(open(path).read()))
+        c.to_native()
+
+
+def test_cfg_syntax():
+    m = parse_cfg('''
+        (* block
+           comment *)
+        CONSTANT MaxId = 7   \\* trailing comment
+        SPECIFICATION Spec
+        INVARIANT TypeOk
+    ''')
+    assert m.constants == {"MaxId": 7} and m.specification == "Spec" and m.invariants == ["TypeOk"]
+    c = to_checker_config("IdSequence", m)
+    assert c.max_id == 7 and c.check_deadlock is True  # TLC checks deadlock unless told otherwise
+    m = parse_cfg("CONSTANTS Replicas = {a, b}\n LogRecords = {x}\n Nil = nil\n LogSize = 3\nCHECK_DEADLOCK FALSE")
+    c = to_checker_config("FiniteReplicatedLog", m)
+    assert (c.n_replicas, c.n_log_records, c.log_size, c.check_deadlock) == (2, 1, 3, False)
+
+
+@pytest.mark.parametrize("text,module", [
+    ("SYMMETRY Perms\nCONSTANT MaxId = 1", "IdSequence"),                      # changes the distinct-state count
+    ("CONSTANTS Replicas = {b1, NONE}\nLogSize=1\nMaxRecords=1\nMaxLeaderEpoch=1", "Kip320"),  # ASSUME :42
+    ("CONSTANTS Replicas = {b1, b2}\nLogSize=1\nMaxRecords=1", "Kip320"),     # MaxLeaderEpoch missing
+    ("CONSTANT MaxId = 1\nINVARIANT StrongIsr", "IdSequence"),
+    ("CONSTANT MaxId = 1", "AsyncIsr"),                                        # out of scope: no lowered model
+    ("CONSTANT MaxId = 1\nPROPERTY Live", "IdSequence"),
+])
+def test_cfg_rejections(text, module):
+    with pytest.raises(CfgError):
+        to_checker_config(module, parse_cfg(text))
+
+
+def test_format_state_prints_tla_values():
+    from kafka_specification_amd import CheckerConfig
+    cfg = CheckerConfig(model="Kip320", n_replicas=2, log_size=2, max_records=2, max_leader_epoch=1)
+    # b1: end 1 hw 0 epoch 0 leader b1 isr {b1,b2} records <<[id 0, epoch 0], Nil>>; b2: empty follower of nobody
+    b = bytes([1, 0, 1, 1, 3, 1, 0]) + bytes([0, 0, 0, 0, 0, 0, 0]) + bytes([1, 1, 1, 1, 3, 1, 3, 0, 0])
+    s = format_state(cfg, b)
+    assert "/\\ nextRecordId = 1" in s and "/\\ nextLeaderEpoch = 1" in s
+    assert 'b1 :> [hw |-> 0, leaderEpoch |-> 0, leader |-> b1, isr |-> {b1, b2}]' in s
+    assert 'b2 :> [hw |-> 0, leaderEpoch |-> -1, leader |-> "NONE", isr |-> {}]' in s
+    assert "records |-> <<[id |-> 0, epoch |-> 0], -1>>" in s
+    assert "leaderAndIsrRequests = {[leaderEpoch |-> 0, leader |-> b1, isr |-> {b1, b2}]}" in s
+    assert "quorumState = [leaderEpoch |-> 0, leader |-> b1, isr |-> {b1, b2}]" in s
+
+
+def test_cli_error_paths(capsys):
+    assert tlc.main([os.path.join(ROOT, "models", "Nope.tla")]) == 2          # no cfg
+    import torch
+    if not torch.cuda.is_available():
+        rc = tlc.main([os.path.join(ROOT, "models", "IdSequence.tla"), "-deadlock"])
+        assert rc == 3 and "no CPU fallback" in capsys.readouterr().err         # fails loudly without a GPU

@@ -115,3 +115,26 @@ def test_headline_seed_independence_at_medium_size():
             res.append(mc.run())
     assert res[0].distinct == res[1].distinct == 18731224
     assert res[0].levels == res[1].levels and res[0].generated == res[1].generated == 55208512
+
+
+def test_cli_prints_tlc_shaped_output(capsys):
+    from kafka_specification_amd import tlc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rc = tlc.main([os.path.join(root, "models", "FiniteReplicatedLog.tla"), "-table", "1048576", "-frontier", "262144"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "Model checking completed. No error has been found." in out
+    assert "distinct states found, 0 states left on queue." in out and "116281 distinct states found" in out
+    assert "The depth of the complete state graph search is" in out
+    rc = tlc.main([os.path.join(root, "models", "Kip279.tla"), "-table", "4194304", "-frontier", "1048576"])
+    out = capsys.readouterr().out
+    assert rc == 12 and "Error: Invariant StrongIsr is violated." in out
+    assert "Error: The behavior up to this point is:" in out and "State 1: <Initial predicate>" in out
+    assert "/\\ quorumState = [leaderEpoch |-> -1, leader |-> \"NONE\", isr |-> {b1, b2, b3}]" in out
+    rc = tlc.main([os.path.join(root, "models", "LeaderInIsr.tla"), "-config", os.path.join(root, "models", "LeaderInIsr.cfg"),
+                   "-table", "65536", "-frontier", "4096"])
+    assert rc == 2  # module name LeaderInIsr has no lowered model: the cfg must be paired with Kip320.tla
+    rc = tlc.main([os.path.join(root, "models", "Kip320.tla"), "-config", os.path.join(root, "models", "LeaderInIsr.cfg"),
+                   "-table", "65536", "-frontier", "4096"])
+    out = capsys.readouterr().out
+    assert rc == 12 and "Error: Invariant LeaderInIsr is violated by the initial state." in out
+    assert "1 states generated, 1 distinct states found" in out
