@@ -34,6 +34,7 @@ typedef unsigned int u32;
 #define KMC_MODE_LOCAL 0u    // probe/insert the local table, append winners to the next frontier
 #define KMC_MODE_SHARDED 1u  // bucket successors by owner(fp) into per-destination send buffers
 #define KMC_MODE_ENUM 2u     // write every successor (state, fp, kind) to a list: trace replay
+#define KMC_MODE_DRY 3u      // tuning aid: generate + fingerprint successors, touch no table or frontier
 
 #define KMC_ERR_FRONTIER_FULL 1u
 #define KMC_ERR_TABLE_FULL 2u
@@ -158,6 +159,7 @@ KMC_HD inline u32 kmc_owner(u64 fp, u32 nshards) { return (u32)((fp >> 40) % nsh
 // ========================================================================================
 template <long long MAXID> struct KmcIdSequence {
     static constexpr int W = 1, NKINDS = 1, NINST = 1;
+    static constexpr bool HAS_EXTRA = false;
     struct Pre { u64 nextId; };
     static KMC_DEV void init(u64* w) { w[0] = 0; }  // IdSequence.tla:37
     static KMC_DEV Pre extract(const u64* s) { return Pre{s[0]}; }
@@ -180,6 +182,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
     static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_FINITE_REPLICATED_LOG, N, L, 0, 0, K);
     static_assert(Y.valid, "FiniteReplicatedLog parameters cannot be packed");
     static constexpr int W = Y.W, NKINDS = 3;
+    static constexpr bool HAS_EXTRA = false;
     static constexpr int C_APPEND = N * K, C_TRUNC = N * L, C_REPL = N * (N - 1);
     static constexpr int NINST = C_APPEND + C_TRUNC + C_REPL;
     static constexpr u64 MR = (1ull << Y.BR) - 1;
@@ -257,6 +260,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
     static constexpr bool FIRST = MODEL == KMC_MODEL_KIP320_FIRST_TRY;
     static constexpr bool K320 = MODEL == KMC_MODEL_KIP320;
     static constexpr int NKINDS = FIRST ? 10 : 9;
+    static constexpr bool HAS_EXTRA = MODEL == KMC_MODEL_KIP279;  // Kip279.tla:47-51: two disjuncts can coincide
     static constexpr int NP = N * (N - 1);  // ordered pairs of distinct replicas
     // action instances, in the order of the Next disjuncts (the index of the disjunct is
     // the "kind"): KafkaTruncateToHighWatermark.tla:33-42, Kip101.tla:49-58, Kip279.tla:53-62,
@@ -717,6 +721,10 @@ template <class M> struct KmcSink {
     // Executed by the whole wave; lanes with valid=false only take part in the ballots.
     static KMC_DEV void process(const KmcArgs& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta) {
         const u64 fp = kmc_fingerprint<W>(t, a.seed);
+        if (a.mode == KMC_MODE_DRY) {
+            if (valid && fp == 0) atomicOr(&a.ctl->err, KMC_ERR_ENUM_FULL);  // keeps the hash alive; never true
+            return;
+        }
         if (a.mode == KMC_MODE_LOCAL) {
             const bool isnew = valid && claim(a, fp, meta);
             if (isnew && a.inv_mask) check_invariants(a, t, fp);
@@ -780,6 +788,7 @@ template <class M> struct KmcSink {
 
 template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     constexpr int W = M::W;
+    constexpr int NW = (M::NINST + 63) / 64;  // words of the per-lane "enabled instances" bitset
     // per-wave LDS: successor ring (W state planes + 1 meta plane: parent fp, or kind in ENUM
     // mode) followed by the output stager's W planes
     __shared__ u64 ring[KMC_WAVES][2 * W + 1][KMC_QCAP];
@@ -789,10 +798,8 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     KmcStager<W> out;
     out.init(&ring[wib][W + 1][0]);
     u32 head = 0, count = 0;  // wave-uniform: ring read position / occupancy
-    u64 gen[M::NKINDS];
-#pragma unroll
-    for (int k = 0; k < M::NKINDS; ++k) gen[k] = 0;
-    u64 deadlocks = 0;
+    u32 gen_lane = 0;         // lane k accumulates the successors generated by action kind k
+    u32 deadlocks = 0;
 
     auto flush = [&](u32 nv) {
         u64 t[W];
@@ -826,39 +833,71 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         for (int k = 0; k < W; ++k) s[k] = valid ? a.fin[(u64)k * a.fin_stride + idx] : 0ull;
         const u64 parent = (a.flags & KMC_FLAG_TRACE) ? kmc_fingerprint<W>(s, a.seed) : 0ull;
         typename M::Pre pre = M::extract(s);
+
+        // Pass 1 — every guard of Next in one straight-line block: no dispatch, and the compiler
+        // shares sub-terms between instances (the effects are dead code here and vanish).
+        // (32-bit halves + shift-by-literal: one v_cndmask + one v_lshl_or per instance; a
+        // 64-bit `g << i` made the compiler park sixty bit constants in VGPRs)
+        u32 en32[2 * NW];
+#pragma unroll
+        for (int h = 0; h < 2 * NW; ++h) en32[h] = 0;
+        const u32 valid01 = valid ? 1u : 0u;
+        kmc_static_for<0, M::NINST>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            u64 tt[W];
+            int kd;
+            u32 ex;
+            const u32 g01 = M::template inst<i>(pre, s, tt, kd, ex) ? valid01 : 0u;
+            en32[i >> 5] |= g01 << (i & 31);
+            kmc_launder(en32[i >> 5]);  // keep the OR chain sequential (a reassociated tree keeps every leaf live)
+        });
+        u64 en[NW];
         u32 nsucc = 0;
+#pragma unroll
+        for (int wd = 0; wd < NW; ++wd) {
+            en[wd] = ((u64)en32[2 * wd + 1] << 32) | en32[2 * wd];
+            nsucc += __popcll(en[wd]);
+        }
+
+        // Pass 2 — wave-uniform walk over the instances; only those some lane enabled dispatch
+        // to their (statically specialised) effect.
+        u64 cur = 0;
 #pragma clang loop unroll(disable)
         for (int i = 0; i < M::NINST; ++i) {
+            if ((i & 63) == 0) {
+                cur = en[0];
+#pragma unroll
+                for (int wd = 1; wd < NW; ++wd)
+                    if ((i >> 6) == wd) cur = en[wd];
+            }
+            const bool e = cur & 1ull;
+            cur >>= 1;
+            const u64 m = __ballot(e);
+            if (m == 0) continue;
+            // opaque redefinition: keeps LICM from hoisting all effects out of this loop
             M::launder(pre);
 #pragma unroll
             for (int k = 0; k < W; ++k) kmc_launder(s[k]);
-            bool en = false;
             int kind = 0;
             u32 extra = 0;
             u64 t[W];
             kmc_dispatch<0, M::NINST>(i, [&](auto I) {
-                en = M::template inst<decltype(I)::value>(pre, s, t, kind, extra);
+                (void)M::template inst<decltype(I)::value>(pre, s, t, kind, extra);
             });
-            en = en && valid;
-            const u64 m = __ballot(en);
-            if (m == 0) continue;
             const u32 n = __popcll(m);
-            u64 weight = n;
-            if (__ballot(en && extra)) {  // rare: bindings that repeat a successor
-                u32 x = en ? extra : 0u;
+            u32 weight = n;
+            if constexpr (M::HAS_EXTRA) {  // bindings that repeat a successor (TLC counts them as generated)
+                u32 x = e ? extra : 0u;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
                 weight += __builtin_amdgcn_readfirstlane(x);
             }
-#pragma unroll
-            for (int k = 0; k < M::NKINDS; ++k)
-                if (k == kind) gen[k] += weight;
-            if (en) {
+            gen_lane += (lane == (u32)kind) ? weight : 0u;
+            if (e) {
                 const u32 pos = (head + count + kmc_rank_in(m)) & (KMC_QCAP - 1);
 #pragma unroll
                 for (int k = 0; k < W; ++k) q[k][pos] = t[k];
                 q[W][pos] = a.mode == KMC_MODE_ENUM ? (u64)kind : parent;
-                ++nsucc;
             }
             count += n;
             if (count >= 64) flush(64);
@@ -871,12 +910,8 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     }
     if (count) flush(count);
     out.finish(a);
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < M::NKINDS; ++k)
-            if (gen[k]) atomicAdd(&a.ctl->generated[k], gen[k]);
-        if (deadlocks) atomicAdd(&a.ctl->deadlock_count, deadlocks);
-    }
+    if (lane < (u32)M::NKINDS && gen_lane) atomicAdd(&a.ctl->generated[lane], (u64)gen_lane);
+    if (lane == 0 && deadlocks) atomicAdd(&a.ctl->deadlock_count, (u64)deadlocks);
 }
 
 // Inserts a list of AoS records (W state words + predecessor fp) into the local table:

@@ -127,7 +127,9 @@ def test_cli_prints_tlc_shaped_output(capsys):
     assert "The depth of the complete state graph search is" in out
     rc = tlc.main([os.path.join(root, "models", "Kip279.tla"), "-table", "4194304", "-frontier", "1048576"])
     out = capsys.readouterr().out
-    assert rc == 12 and "Error: Invariant StrongIsr is violated." in out
+    o = kmo.Run(kmo.make_config("Kip279", N=3, L=2, R=2, E=2, invariants=("TypeOk", "WeakIsr", "StrongIsr")))
+    assert rc == 12 and f"Error: Invariant {o.viol_inv} is violated." in out
+    assert f"State {o.viol_depth}: <" in out and f"State {o.viol_depth + 1}: <" not in out
     assert "Error: The behavior up to this point is:" in out and "State 1: <Initial predicate>" in out
     assert "/\\ quorumState = [leaderEpoch |-> -1, leader |-> \"NONE\", isr |-> {b1, b2, b3}]" in out
     rc = tlc.main([os.path.join(root, "models", "LeaderInIsr.tla"), "-config", os.path.join(root, "models", "LeaderInIsr.cfg"),
