@@ -45,7 +45,7 @@ typedef unsigned int u32;
 
 #define KMC_MAX_KINDS 16
 #define KMC_MAX_SHARDS 8
-#define KMC_QCAP 128  // per-wave LDS ring capacity (successors); flush granularity is 64
+#define KMC_QCAP 128  // per-wave output-stager capacity (winners); drain granularity is 64
 #define KMC_SEGS 8    // frontier segments, each with its own append counter (block b appends to b % KMC_SEGS)
 
 // tuning knobs (the host may override them per code object through KMC_JIT_DEFINES)
@@ -55,6 +55,19 @@ typedef unsigned int u32;
 #ifndef KMC_CAS_FIRST
 #define KMC_CAS_FIRST 0   // probe with atomicCAS directly instead of load-then-CAS
 #endif
+#ifndef KMC_FLUSH2
+#define KMC_FLUSH2 0      // 1: drain 128 successors per flush, two independent probe chains per lane
+#endif                    //    (measured: no gain — the kernel is issue-bound, not latency-bound — and it costs registers)
+// per-wave successor ring capacity: < KMC_FLUSH_N queued before a push, <= 64 pushed at once
+#define KMC_FLUSH_N (KMC_FLUSH2 ? 128 : 64)
+#define KMC_RING (KMC_FLUSH2 ? 256 : 128)
+#define KMC_FLAG_DRY_PROBE 4u  // tuning: DRY mode also walks the (read-only) probe sequence
+#define KMC_FLAG_DRY_INV 8u    // tuning: ... and evaluates the invariants on every successor
+#define KMC_FLAG_DRY_ATOM 16u  // tuning: ... and a no-op atomicCAS on ~35 % of the probed slots
+#define KMC_FLAG_X_NOSTAGE 32u    // tuning (shadow pass only): winners are not appended
+#define KMC_FLAG_X_NOINV 64u      // tuning: skip invariants
+#define KMC_FLAG_X_PLAINSTORE 128u  // tuning: claim with a plain store instead of atomicCAS (racy, timing only)
+#define KMC_FLAG_META 2u  // the ring carries a meta plane (predecessor fp for traces / kind for ENUM)
 
 // One per BFS level; the host zeroes it before the level runs and reads it back after.
 struct KmcLevelCtl {
@@ -678,8 +691,8 @@ template <class M> struct KmcSink {
     static constexpr int W = M::W;
 
     // probe/insert fp; returns true when this lane claimed the slot (the state is new)
-    static KMC_DEV bool claim(const KmcArgs& a, u64 fp, u64 meta) {
-        u64 i = fp & a.table_mask;
+    static KMC_DEV bool claim(const KmcArgs& a, u64 fp, u64 meta) { return claim_from(a, fp, fp & a.table_mask, meta); }
+    static KMC_DEV bool claim_from(const KmcArgs& a, u64 fp, u64 i, u64 meta) {
         // open addressing, linear probing.  Slots only ever change 0 -> fp, so a plain
         // (possibly stale) load can only mis-report "empty", which the CAS then corrects.
         for (u64 probes = 0; probes <= a.table_mask; ++probes) {
@@ -692,6 +705,10 @@ template <class M> struct KmcSink {
 #else
             u64 v = a.table[i];
             if (v == 0) {
+                if (a.flags & KMC_FLAG_X_PLAINSTORE) {
+                    a.table[i] = fp;
+                    return true;
+                }
                 v = atomicCAS(&a.table[i], 0ull, fp);
                 if (v == 0) {
                     if (a.pred) a.pred[i] = meta;
@@ -718,18 +735,71 @@ template <class M> struct KmcSink {
         }
     }
 
+    // Two successors per lane.  In LOCAL mode the first probe round of both is issued
+    // back-to-back (two loads, then two CASes in flight) before either result is consumed:
+    // the kernel is bound by HBM latency, not bandwidth, so this doubles what one wave keeps
+    // in flight.
+    static KMC_DEV void process2(const KmcArgs& a, KmcStager<W>& out, bool valid0, const u64* t0, u64 meta0,
+                                 bool valid1, const u64* t1, u64 meta1) {
+        if (a.mode != KMC_MODE_LOCAL) {
+            process(a, out, valid0, t0, meta0);
+            process(a, out, valid1, t1, meta1);
+            return;
+        }
+        const u64 fp0 = kmc_fingerprint<W>(t0, a.seed), fp1 = kmc_fingerprint<W>(t1, a.seed);
+        u64 i0 = fp0 & a.table_mask, i1 = fp1 & a.table_mask;
+        bool done0 = !valid0, done1 = !valid1, new0 = false, new1 = false;
+        const u64 v0 = done0 ? ~0ull : a.table[i0];
+        const u64 v1 = done1 ? ~0ull : a.table[i1];
+        u64 w0 = v0, w1 = v1;
+        if (v0 == 0) w0 = atomicCAS(&a.table[i0], 0ull, fp0);
+        if (v1 == 0) w1 = atomicCAS(&a.table[i1], 0ull, fp1);
+        if (!done0) {
+            if (v0 == 0 && w0 == 0) { new0 = true; done0 = true; if (a.pred) a.pred[i0] = meta0; }
+            else if (w0 == fp0) done0 = true;
+            else i0 = (i0 + 1) & a.table_mask;
+        }
+        if (!done1) {
+            if (v1 == 0 && w1 == 0) { new1 = true; done1 = true; if (a.pred) a.pred[i1] = meta1; }
+            else if (w1 == fp1) done1 = true;
+            else i1 = (i1 + 1) & a.table_mask;
+        }
+        if (!done0) new0 = claim_from(a, fp0, i0, meta0);  // collision chain: the rare slow path
+        if (!done1) new1 = claim_from(a, fp1, i1, meta1);
+        if (a.inv_mask) {
+            if (new0) check_invariants(a, t0, fp0);
+            if (new1) check_invariants(a, t1, fp1);
+        }
+        out.push(a, new0, t0);
+        out.push(a, new1, t1);
+    }
+
     // Executed by the whole wave; lanes with valid=false only take part in the ballots.
     static KMC_DEV void process(const KmcArgs& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta) {
         const u64 fp = kmc_fingerprint<W>(t, a.seed);
         if (a.mode == KMC_MODE_DRY) {
-            if (valid && fp == 0) atomicOr(&a.ctl->err, KMC_ERR_ENUM_FULL);  // keeps the hash alive; never true
+            u64 acc = fp;
+            if (valid && (a.flags & KMC_FLAG_DRY_PROBE)) {  // read-only probe sequence (the table is already full)
+                u64 i = fp & a.table_mask;
+                for (u64 probes = 0; probes <= a.table_mask; ++probes) {
+                    const u64 v = a.table[i];
+                    acc ^= v;
+                    if (v == fp || v == 0) break;
+                    i = (i + 1) & a.table_mask;
+                }
+                if (a.flags & KMC_FLAG_DRY_INV) acc ^= M::violated(t, a.inv_mask);
+                // ~35 % of the probes end in a no-op CAS on the slot they found: the same atomic
+                // traffic as the real claims (311 M per 888 M probes) without changing the table
+                if ((a.flags & KMC_FLAG_DRY_ATOM) && (fp & 0xFF) < 90) acc ^= atomicCAS(&a.table[i], fp, fp);
+            }
+            if (valid && acc == 0x1234567) atomicOr(&a.ctl->err, KMC_ERR_ENUM_FULL);  // keeps the work alive
             return;
         }
         if (a.mode == KMC_MODE_LOCAL) {
             const bool isnew = valid && claim(a, fp, meta);
-            if (isnew && a.inv_mask) check_invariants(a, t, fp);
+            if (isnew && a.inv_mask && !(a.flags & KMC_FLAG_X_NOINV)) check_invariants(a, t, fp);
 #if KMC_OUT_STAGE
-            out.push(a, isnew, t);
+            if (!(a.flags & KMC_FLAG_X_NOSTAGE)) out.push(a, isnew, t);
 #else
             const u64 m = __ballot(isnew);
             if (m) {
@@ -789,26 +859,38 @@ template <class M> struct KmcSink {
 template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     constexpr int W = M::W;
     constexpr int NW = (M::NINST + 63) / 64;  // words of the per-lane "enabled instances" bitset
-    // per-wave LDS: successor ring (W state planes + 1 meta plane: parent fp, or kind in ENUM
-    // mode) followed by the output stager's W planes
-    __shared__ u64 ring[KMC_WAVES][2 * W + 1][KMC_QCAP];
+    // per-wave dynamic LDS: successor ring (W state planes of KMC_RING entries, plus one meta
+    // plane — parent fp, or kind in ENUM mode — only when KMC_FLAG_META) followed by the output
+    // stager's W planes of KMC_QCAP entries.  The host sizes it (kmc_expand_lds_bytes).
+    extern __shared__ __attribute__((aligned(16))) u64 kmc_lds[];
     const u32 lane = kmc_lane();
     const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, keep it scalar
-    u64(*q)[KMC_QCAP] = ring[wib];
+    const bool has_meta = (a.flags & KMC_FLAG_META) != 0;
+    const u32 ring_planes = W + (has_meta ? 1u : 0u);
+    u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + W * KMC_QCAP);  // q[k*KMC_RING + pos]
     KmcStager<W> out;
-    out.init(&ring[wib][W + 1][0]);
+    out.init(q + ring_planes * KMC_RING);
     u32 head = 0, count = 0;  // wave-uniform: ring read position / occupancy
     u32 gen_lane = 0;         // lane k accumulates the successors generated by action kind k
     u32 deadlocks = 0;
 
-    auto flush = [&](u32 nv) {
-        u64 t[W];
-        const u32 pos = (head + lane) & (KMC_QCAP - 1);
+    auto flush = [&](u32 nv) {  // nv <= KMC_FLUSH_N queued successors leave the ring
+        u64 t0[W];
+        const u32 pos0 = (head + lane) & (KMC_RING - 1);
 #pragma unroll
-        for (int k = 0; k < W; ++k) t[k] = q[k][pos];
-        const u64 meta = q[W][pos];
-        KmcSink<M>::process(a, out, lane < nv, t, meta);
-        head = (head + nv) & (KMC_QCAP - 1);
+        for (int k = 0; k < W; ++k) t0[k] = q[k * KMC_RING + pos0];
+        const u64 meta0 = has_meta ? q[W * KMC_RING + pos0] : 0ull;
+#if KMC_FLUSH2
+        u64 t1[W];
+        const u32 pos1 = (head + 64 + lane) & (KMC_RING - 1);
+#pragma unroll
+        for (int k = 0; k < W; ++k) t1[k] = q[k * KMC_RING + pos1];
+        const u64 meta1 = has_meta ? q[W * KMC_RING + pos1] : 0ull;
+        KmcSink<M>::process2(a, out, lane < nv, t0, meta0, lane + 64 < nv, t1, meta1);
+#else
+        KmcSink<M>::process(a, out, lane < nv, t0, meta0);
+#endif
+        head = (head + nv) & (KMC_RING - 1);
         count -= nv;
     };
 
@@ -894,13 +976,13 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             }
             gen_lane += (lane == (u32)kind) ? weight : 0u;
             if (e) {
-                const u32 pos = (head + count + kmc_rank_in(m)) & (KMC_QCAP - 1);
+                const u32 pos = (head + count + kmc_rank_in(m)) & (KMC_RING - 1);
 #pragma unroll
-                for (int k = 0; k < W; ++k) q[k][pos] = t[k];
-                q[W][pos] = a.mode == KMC_MODE_ENUM ? (u64)kind : parent;
+                for (int k = 0; k < W; ++k) q[k * KMC_RING + pos] = t[k];
+                if (has_meta) q[W * KMC_RING + pos] = a.mode == KMC_MODE_ENUM ? (u64)kind : parent;
             }
             count += n;
-            if (count >= 64) flush(64);
+            if (count >= KMC_FLUSH_N) flush(KMC_FLUSH_N);
         }
         const u64 dm = __ballot(valid && nsucc == 0);
         if (dm) {
@@ -908,10 +990,15 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             if (valid && nsucc == 0) atomicMax(&a.ctl->deadlock_fp_inv, ~kmc_fingerprint<W>(s, a.seed));
         }
     }
-    if (count) flush(count);
+    while (count) flush(count < KMC_FLUSH_N ? count : KMC_FLUSH_N);
     out.finish(a);
     if (lane < (u32)M::NKINDS && gen_lane) atomicAdd(&a.ctl->generated[lane], (u64)gen_lane);
     if (lane == 0 && deadlocks) atomicAdd(&a.ctl->deadlock_count, (u64)deadlocks);
+}
+
+// dynamic LDS bytes k_expand needs for a state of W words
+KMC_HD inline unsigned kmc_expand_lds_bytes(int W, bool has_meta) {
+    return (unsigned)(KMC_WAVES * ((W + (has_meta ? 1 : 0)) * KMC_RING + W * KMC_QCAP) * 8);
 }
 
 // Inserts a list of AoS records (W state words + predecessor fp) into the local table:
@@ -966,8 +1053,11 @@ template <class M> KMC_DEV void kmc_find_body(const KmcArgs& a) {
         }
 }
 
+#ifndef KMC_MIN_WAVES
+#define KMC_MIN_WAVES 5   // __launch_bounds__ second argument for k_expand: minimum waves per SIMD
+#endif
 #define KMC_INSTANTIATE(NAME, ...)                                                                       \
-    extern "C" __global__ __launch_bounds__(KMC_BLOCK) void kmc_expand_##NAME(KmcArgs a) {               \
+    extern "C" __global__ __launch_bounds__(KMC_BLOCK, KMC_MIN_WAVES) void kmc_expand_##NAME(KmcArgs a) { \
         kmc_expand_body<__VA_ARGS__>(a);                                                                 \
     }                                                                                                    \
     extern "C" __global__ __launch_bounds__(KMC_BLOCK) void kmc_insert_##NAME(KmcArgs a) {               \

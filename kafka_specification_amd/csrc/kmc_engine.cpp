@@ -254,7 +254,7 @@ struct kmc_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cus = 256;
     int blocks_per_cu = 4;  // k_expand residency, from the occupancy query at open
-    u64 *table = nullptr, *pred = nullptr;
+    u64 *table = nullptr, *pred = nullptr, *table2 = nullptr;
     uint64_t table_cap = 0;
     u64* frontier[2] = {nullptr, nullptr};
     uint64_t fcap = 0;
@@ -286,9 +286,15 @@ namespace {
 
 int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid) {
     KmcArgs args = a;
+    unsigned lds = 0;
+    if (f == h->f_expand) {  // k_expand carves its rings out of dynamic LDS
+        const bool meta = (args.flags & KMC_FLAG_TRACE) || args.mode == KMC_MODE_ENUM;
+        if (meta) args.flags |= KMC_FLAG_META;
+        lds = kmc_expand_lds_bytes(h->W, meta);
+    }
     size_t size = sizeof(args);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, KMC_BLOCK, 1, 1, 0, h->stream, nullptr, config));
+    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, KMC_BLOCK, 1, 1, lds, h->stream, nullptr, config));
     return KMC_OK;
 }
 
@@ -509,6 +515,7 @@ void kmc_close(kmc_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->table) hipFree(h->table);
     if (h->pred) hipFree(h->pred);
+    if (h->table2) hipFree(h->table2);
     if (h->frontier[0]) hipFree(h->frontier[0]);
     if (h->frontier[1]) hipFree(h->frontier[1]);
     if (h->ctl) hipFree(h->ctl);
@@ -557,7 +564,8 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     HIP_TRY(hipModuleGetFunction(&h->f_init, h->mod, ("kmc_init_" + h->kname).c_str()));
     HIP_TRY(hipModuleGetFunction(&h->f_find, h->mod, ("kmc_find_" + h->kname).c_str()));
     int occ = 0;
-    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->f_expand, KMC_BLOCK, 0) == hipSuccess && occ > 0)
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->f_expand, KMC_BLOCK,
+                                                           kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0)) == hipSuccess && occ > 0)
         h->blocks_per_cu = occ > 8 ? 8 : occ;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&h->ev0));
@@ -758,6 +766,23 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
         a.fin = h->frontier[h->cur];
         a.fout = h->frontier[nxt];
         a.mode = KMC_MODE_LOCAL;
+        static const int shadow = getenv("KMC_SHADOW") ? atoi(getenv("KMC_SHADOW")) : 0;
+        if (shadow) {  // tuning aid: the identical level first runs on a copy of the table, with KMC_XFLAGS applied
+            if (!h->table2) HIP_TRY(hipMalloc(&h->table2, h->table_cap * 8));
+            HIP_TRY(hipMemcpyAsync(h->table2, h->table, h->table_cap * 8, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipMemsetAsync(h->ctl + 2, 0, sizeof(KmcLevelCtl), h->stream));
+            KmcArgs x = a;
+            x.table = h->table2;
+            x.ctl = h->ctl + 2;
+            x.flags |= getenv("KMC_XFLAGS") ? (uint32_t)atoi(getenv("KMC_XFLAGS")) : 0u;
+            HIP_TRY(hipEventRecord(h->ev0, h->stream));
+            if ((rc = launch(h, h->f_expand, x, expand_grid(h, h->n_cur)))) return rc;
+            HIP_TRY(hipEventRecord(h->ev1, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            float xms = 0;
+            HIP_TRY(hipEventElapsedTime(&xms, h->ev0, h->ev1));
+            h->dry_seconds += 1e-3 * xms;
+        }
         HIP_TRY(hipEventRecord(h->ev0, h->stream));
         if ((rc = launch(h, h->f_expand, a, expand_grid(h, h->n_cur)))) return rc;
         HIP_TRY(hipEventRecord(h->ev1, h->stream));
@@ -767,10 +792,13 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
         r.seconds_expand += 1e-3 * ms;
         r.expand_launches++;
         const KmcLevelCtl c = *h->ctl_host;
-        static const bool dry = getenv("KMC_DRYRUN") && atoi(getenv("KMC_DRYRUN"));
-        if (dry) {  // tuning aid: time the same level again without any table/frontier traffic
-            KmcArgs d = a;
+        static const int dry = getenv("KMC_DRYRUN") ? atoi(getenv("KMC_DRYRUN")) : 0;
+        if (dry) {  // tuning aid: time the same level again without table writes / frontier traffic
+            KmcArgs d = a;  // 1: no table access at all, 2: + read-only probes, 3: + invariants on every successor
             d.mode = KMC_MODE_DRY;
+            if (dry >= 2) d.flags |= KMC_FLAG_DRY_PROBE;
+            if (dry == 3) d.flags |= KMC_FLAG_DRY_INV;
+            if (dry == 4) d.flags |= KMC_FLAG_DRY_ATOM;
             d.ctl = h->ctl + 2;
             HIP_TRY(hipEventRecord(h->ev0, h->stream));
             if ((rc = launch(h, h->f_expand, d, expand_grid(h, h->n_cur)))) return rc;
@@ -805,7 +833,7 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
     r.n_levels = h->levels.size();
     r.seconds_total = now_s() - h->t_start;
     if (h->dry_seconds > 0) {
-        fprintf(stderr, "[kmc] dry-run expand (no table/frontier traffic): %.3f ms vs real %.3f ms\n",
+        fprintf(stderr, "[kmc] dry/shadow expand: %.3f ms vs real %.3f ms\n",
                 1e3 * h->dry_seconds, 1e3 * r.seconds_expand);
         h->dry_seconds = 0;
     }
