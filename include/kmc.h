@@ -67,6 +67,7 @@ extern "C" {
 
 #define KMC_MAX_KINDS 16
 #define KMC_MAX_SHARDS 8
+#define KMC_SEND_SUBS 8     /* sub-buffers per destination in the send area (spreads the append counters) */
 
 typedef struct kmc_config {
     int32_t model;              /* KMC_* model id */
@@ -85,7 +86,7 @@ typedef struct kmc_config {
     int32_t shard_id;
     uint64_t table_capacity;    /* fingerprint slots (rounded up to a power of two); 0 = auto from free HBM */
     uint64_t frontier_capacity; /* states per frontier buffer; 0 = auto */
-    uint64_t send_capacity;     /* n_shards>1: records per destination per level; 0 = auto */
+    uint64_t send_capacity;     /* n_shards>1: records per (destination, sub-buffer) per level; 0 = auto */
     uint64_t hash_seed;         /* results must not depend on it (collisions aside) */
     uint64_t max_levels;        /* 0 = unlimited (internal cap 4096) */
     const char* cache_dir;      /* compiled-kernel cache; NULL = $KMC_CACHE_DIR or <libdir>/kmc_cache */
@@ -167,11 +168,12 @@ const char* kmc_invariant_name(int32_t index);
  * buffers) -> the caller exchanges the buffers (RCCL all-to-all-v) -> kmc_step_insert on each
  * received buffer -> kmc_step_finish.  All pointers are device pointers on cfg->device. */
 int kmc_step_begin(kmc_handle* h);                       /* reset, insert Init on its owner */
-int kmc_step_expand(kmc_handle* h, uint64_t send_counts[KMC_MAX_SHARDS]);
-int kmc_step_send_buffer(kmc_handle* h, int32_t dst, void** dev_ptr, uint64_t* record_words);
-/* Let the caller own the send area (n_shards * records_per_destination * (state_words+1) uint64),
- * e.g. a torch tensor that is handed to the collective without a copy. */
-int kmc_step_set_send_buffer(kmc_handle* h, void* dev_ptr, uint64_t records_per_destination);
+/* send_counts: KMC_MAX_SHARDS * KMC_SEND_SUBS entries, [destination][sub-buffer] */
+int kmc_step_expand(kmc_handle* h, uint64_t* send_counts);
+int kmc_step_send_buffer(kmc_handle* h, int32_t dst, int32_t sub, void** dev_ptr, uint64_t* record_words);
+/* Let the caller own the send area: [n_shards][KMC_SEND_SUBS][records_per_sub_buffer] records of
+ * (state_words+1) uint64, e.g. a torch tensor whose slices are handed to the collective. */
+int kmc_step_set_send_buffer(kmc_handle* h, void* dev_ptr, uint64_t records_per_sub_buffer);
 int kmc_step_insert(kmc_handle* h, const void* dev_records, uint64_t n_records);
 int kmc_step_finish(kmc_handle* h, kmc_level_info* info); /* info->new_states: this shard's next frontier */
 int kmc_step_set_verdict(kmc_handle* h, int32_t verdict); /* driver-decided global stop reason */

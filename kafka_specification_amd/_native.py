@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libkmc.so")
 
 KMC_MAX_KINDS = 16
 KMC_MAX_SHARDS = 8
+KMC_SEND_SUBS = 8
 
 MODELS = {
     "IdSequence": 0,
@@ -81,7 +82,7 @@ SYMBOLS = [
     ("kmc_invariant_name", C.c_char_p, [C.c_int32]),
     ("kmc_step_begin", C.c_int, [_H]),
     ("kmc_step_expand", C.c_int, [_H, C.POINTER(C.c_uint64)]),
-    ("kmc_step_send_buffer", C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("kmc_step_send_buffer", C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     ("kmc_step_set_send_buffer", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("kmc_step_insert", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("kmc_step_finish", C.c_int, [_H, C.POINTER(KmcLevelInfo)]),

@@ -77,7 +77,7 @@ struct KmcLevelCtl {
     u64 viol_fp_inv[4];              // max over violators of ~fp  (=> min fp), 0 = none
     u64 deadlock_count;              // expanded states without any successor
     u64 deadlock_fp_inv;
-    u64 send_count[KMC_MAX_SHARDS];  // SHARDED: records bucketed per destination
+    u64 send_count[KMC_MAX_SHARDS][KMC_SEGS];  // SHARDED: records bucketed per (destination, sub-buffer)
     u64 enum_count;                  // ENUM: records written
     u64 inserted;                    // table claims (== next_count unless the frontier overflowed)
     u32 err;
@@ -99,13 +99,15 @@ struct KmcArgs {
     u64* pred;         // optional: predecessor fingerprint per table slot (trace reconstruction)
     KmcLevelCtl* ctl;
     u64 seed;
-    u64* send;         // SHARDED: [shard][send_cap] AoS records of W+1 words (state, parent fp)
-    u64 send_cap;      //          also the ENUM output list: records of W+2 words (state, fp, kind)
+    u64* send;         // SHARDED: [shard][KMC_SEGS][send_cap] AoS records of W+1 words (state, parent fp);
+    u64 send_cap;      //   block b fills sub-buffer b % KMC_SEGS.  ENUM: one list of W+2-word records (state, fp, kind)
     const u64* recv;   // k_insert input: AoS records of W+1 words
     u32 inv_mask;
     u32 mode;
     u32 flags;
     u32 nshards;
+    u32 shard;         // this handle's shard id (SHARDED mode keeps its own successors local)
+    u32 pad_;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -821,16 +823,33 @@ template <class M> struct KmcSink {
             }
 #endif
         } else if (a.mode == KMC_MODE_SHARDED) {
-            if (valid) {
-                const u32 dst = kmc_owner(fp, a.nshards);
-                const u64 pos = atomicAdd(&a.ctl->send_count[dst], 1ull);
-                if (pos < a.send_cap) {
-                    u64* rec = a.send + ((u64)dst * a.send_cap + pos) * (u64)(W + 1);
+            // successors this shard owns take the local path at once (probe, claim, stage): only
+            // the (P-1)/P that belong elsewhere travel
+            const u32 dst = valid ? kmc_owner(fp, a.nshards) : ~0u;
+            const bool isnew = dst == a.shard && claim(a, fp, meta);
+            if (isnew && a.inv_mask) check_invariants(a, t, fp);
+            out.push(a, isnew, t);
+            // bucket the rest by owner: one wave-aggregated atomicAdd per destination present in this batch
+            const u32 sub = blockIdx.x % KMC_SEGS;
+            for (u32 d = 0; d < a.nshards; ++d) {  // wave-uniform
+                if (d == a.shard) continue;
+                const bool mine = dst == d;
+                const u64 m = __ballot(mine);
+                if (m == 0) continue;
+                const int leader = __builtin_ctzll(m);
+                u64 base = 0;
+                if ((int)kmc_lane() == leader) base = atomicAdd(&a.ctl->send_count[d][sub], (u64)__popcll(m));
+                base = kmc_bcast64(base, leader);
+                if (mine) {
+                    const u64 pos = base + kmc_rank_in(m);
+                    if (pos < a.send_cap) {
+                        u64* rec = a.send + (((u64)d * KMC_SEGS + sub) * a.send_cap + pos) * (u64)(W + 1);
 #pragma unroll
-                    for (int k = 0; k < W; ++k) rec[k] = t[k];
-                    rec[W] = meta;
-                } else {
-                    atomicOr(&a.ctl->err, KMC_ERR_SEND_FULL);
+                        for (int k = 0; k < W; ++k) rec[k] = t[k];
+                        rec[W] = meta;
+                    } else {
+                        atomicOr(&a.ctl->err, KMC_ERR_SEND_FULL);
+                    }
                 }
             }
         } else {  // KMC_MODE_ENUM

@@ -308,6 +308,7 @@ KmcArgs base_args(kmc_handle* h, int ctl_slot) {
     a.inv_mask = h->cfg.invariant_mask;
     a.flags = h->cfg.keep_trace ? KMC_FLAG_TRACE : 0u;
     a.nshards = (uint32_t)h->cfg.n_shards;
+    a.shard = (uint32_t)h->cfg.shard_id;
     a.fin_stride = a.fout_stride = h->fcap;
     a.seg_cap = h->seg_cap;
     for (int sg = 0; sg < KMC_SEGS; ++sg) a.seg_count[sg] = h->seg_n[sg];
@@ -601,10 +602,10 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     HIP_TRY(hipMalloc(&h->enum_out, h->enum_cap * (h->W + 2) * 8ull));
     if (h->cfg.n_shards > 1) {
         uint64_t scap = cfg->send_capacity;
-        if (!scap) scap = (uint64_t)(budget * 0.16) / (8ull * (h->W + 1) * h->cfg.n_shards);
+        if (!scap) scap = (uint64_t)(budget * 0.16) / (8ull * (h->W + 1) * h->cfg.n_shards * KMC_SEGS);
         if (scap < 64) scap = 64;
-        h->send_cap = scap;
-        if (hipMalloc(&h->send, scap * (h->W + 1) * 8ull * h->cfg.n_shards) != hipSuccess)
+        h->send_cap = scap;  // records per (destination, sub-buffer)
+        if (hipMalloc(&h->send, scap * (h->W + 1) * 8ull * h->cfg.n_shards * KMC_SEGS) != hipSuccess)
             return fail(KMC_E_NOMEM, "cannot allocate send buffers");
     }
     return KMC_OK;
@@ -986,9 +987,9 @@ int kmc_step_begin(kmc_handle* h) {
     return rc;
 }
 
-int kmc_step_expand(kmc_handle* h, uint64_t send_counts[KMC_MAX_SHARDS]) {
+int kmc_step_expand(kmc_handle* h, uint64_t* send_counts /* [KMC_MAX_SHARDS][KMC_SEND_SUBS] */) {
     if (!h || !h->stepping) return fail(KMC_E_STATE, "kmc_step_begin first");
-    if (!h->send) return fail(KMC_E_STATE, "handle was opened with n_shards == 1");
+    if (!h->send) return fail(KMC_E_STATE, "no send area: open with n_shards > 1 or call kmc_step_set_send_buffer");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const int slot = (int)(h->level & 1);
     int rc = zero_ctl(h, slot);
@@ -1009,27 +1010,29 @@ int kmc_step_expand(kmc_handle* h, uint64_t send_counts[KMC_MAX_SHARDS]) {
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->res.seconds_expand += 1e-3 * ms;
     h->res.expand_launches++;
-    for (int d = 0; d < KMC_MAX_SHARDS; ++d) {
-        uint64_t c = h->ctl_host->send_count[d];
-        send_counts[d] = c < h->send_cap ? c : h->send_cap;
-    }
+    for (int d = 0; d < KMC_MAX_SHARDS; ++d)
+        for (int sb = 0; sb < KMC_SEGS; ++sb) {
+            uint64_t c = h->ctl_host->send_count[d][sb];
+            send_counts[d * KMC_SEGS + sb] = c < h->send_cap ? c : h->send_cap;
+        }
     h->step_expanded = true;
     return KMC_OK;
 }
 
-int kmc_step_set_send_buffer(kmc_handle* h, void* dev_ptr, uint64_t records_per_destination) {
+int kmc_step_set_send_buffer(kmc_handle* h, void* dev_ptr, uint64_t records_per_sub_buffer) {
+    const uint64_t records_per_destination = records_per_sub_buffer;
     if (!h || !dev_ptr || records_per_destination == 0) return fail(KMC_E_ARG, "bad send buffer");
-    if (h->cfg.n_shards <= 1) return fail(KMC_E_STATE, "handle was opened with n_shards == 1");
-    if (h->send && h->send_owned) hipFree(h->send);
+    if (h->send && h->send_owned) hipFree(h->send);  // n_shards == 1 is allowed: one destination, itself
     h->send = (u64*)dev_ptr;
     h->send_cap = records_per_destination;
     h->send_owned = false;
     return KMC_OK;
 }
 
-int kmc_step_send_buffer(kmc_handle* h, int32_t dst, void** dev_ptr, uint64_t* record_words) {
-    if (!h || !h->send || dst < 0 || dst >= h->cfg.n_shards) return fail(KMC_E_ARG, "bad destination");
-    *dev_ptr = h->send + (uint64_t)dst * h->send_cap * (h->W + 1);
+int kmc_step_send_buffer(kmc_handle* h, int32_t dst, int32_t sub, void** dev_ptr, uint64_t* record_words) {
+    if (!h || !h->send || dst < 0 || dst >= h->cfg.n_shards || sub < 0 || sub >= KMC_SEGS)
+        return fail(KMC_E_ARG, "bad destination / sub-buffer");
+    *dev_ptr = h->send + ((uint64_t)dst * KMC_SEGS + sub) * h->send_cap * (h->W + 1);
     *record_words = h->W + 1;
     return KMC_OK;
 }

@@ -48,10 +48,12 @@ class HipShardEngine:
         self.lib = nat.lib()
         self.W = self.mc.state_words
         self.record_words = self.W + 1
-        # the send area belongs to torch so that slices of it can be handed to the collective
-        scap = cfg.send_capacity or max(1 << 16, (cfg.frontier_capacity or (1 << 22)) * 2 // n_shards)
+        # the send area belongs to torch so that slices of it can be handed to the collective:
+        # [destination][sub-buffer][record]; block b of k_expand fills sub-buffer b % KMC_SEND_SUBS
+        subs = nat.KMC_SEND_SUBS
+        scap = cfg.send_capacity or max(1 << 13, (cfg.frontier_capacity or (1 << 22)) * 4 // (n_shards * subs))
         self.send_cap = scap
-        self.send = torch.zeros((n_shards, scap, self.record_words), dtype=torch.int64, device=self.device)
+        self.send = torch.zeros((n_shards, subs, scap, self.record_words), dtype=torch.int64, device=self.device)
         nat.check(self.lib.kmc_step_set_send_buffer(self.mc.handle, C.c_void_p(self.send.data_ptr()), scap))
         self._last = None
 
@@ -65,9 +67,12 @@ class HipShardEngine:
         return self._stats(self._last, None, first=True)
 
     def expand(self):
-        counts = (C.c_uint64 * nat.KMC_MAX_SHARDS)()
+        """-> per destination, the list of filled sub-buffer slices (each a contiguous [n, W+1] view)."""
+        subs = nat.KMC_SEND_SUBS
+        counts = (C.c_uint64 * (nat.KMC_MAX_SHARDS * subs))()
         nat.check(self.lib.kmc_step_expand(self.mc.handle, counts))
-        return [self.send[d, :int(counts[d])] for d in range(self.n_shards)]
+        return [[self.send[d, sb, :int(counts[d * subs + sb])] for sb in range(subs) if counts[d * subs + sb]]
+                for d in range(self.n_shards)]
 
     def insert(self, records):
         n = int(records.shape[0])
@@ -111,8 +116,8 @@ class LoopbackExchange:
     def __init__(self, n):
         self.n = n
 
-    def all_to_all(self, sends):  # sends[i][d] -> recvs[d][i]
-        return [[sends[i][d] for i in range(self.n)] for d in range(self.n)]
+    def all_to_all(self, sends):  # sends[i][d] = chunks from shard i for shard d  ->  recvs[d] = all chunks for d
+        return [[c for i in range(self.n) for c in _chunks(sends[i][d])] for d in range(self.n)]
 
     def all_reduce_sum(self, stats):
         return np.sum(np.stack(stats), axis=0)
@@ -136,19 +141,39 @@ class DistExchange:
         self.rank = dist.get_rank()
         self.device = device if device is not None else torch.device("cpu")
 
+    # all_to_all_single corrupts messages above 2 GiB on this RCCL / torch build (probe:
+    # tools/a2a_probe.py — half of a 2.24 GiB message arrives wrong), so a level's exchange is
+    # cut into rounds of at most ROUND_BYTES per rank.
+    ROUND_BYTES = 1 << 30
+
     def all_to_all(self, sends):
         torch, dist = self.torch, self.dist
-        (mine,) = sends
-        words = int(mine[0].shape[1]) if mine[0].dim() == 2 else 1
-        in_counts = torch.tensor([int(t.shape[0]) for t in mine], dtype=torch.int64, device=self.device)
-        out_counts = torch.empty_like(in_counts)
-        dist.all_to_all_single(out_counts, in_counts)
-        in_split = [int(x) for x in in_counts.tolist()]
-        out_split = [int(x) for x in out_counts.tolist()]
-        send = torch.cat([t.reshape(-1, words) for t in mine], dim=0).contiguous()
-        recv = torch.empty((sum(out_split), words), dtype=send.dtype, device=send.device)
-        dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split)
-        return [[recv]]
+        (mine,) = sends  # one engine per process: mine[d] = chunks for destination d
+        P, me = self.world, self.rank
+        chunks = [_chunks(x) for x in mine]
+        words = next((int(c.shape[1]) for cs in chunks for c in cs), 1)
+        dtype = next((c.dtype for cs in chunks for c in cs), torch.int64)
+        cnt = torch.tensor([sum(int(c.shape[0]) for c in cs) for cs in chunks], dtype=torch.int64, device=self.device)
+        rows = [torch.empty_like(cnt) for _ in range(P)]
+        dist.all_gather(rows, cnt)                       # (gloo has no all_gather_into_tensor)
+        allc = torch.stack(rows).cpu()                   # allc[s][d]: records s sends to d
+        per_dst = [torch.cat(cs, dim=0) if len(cs) > 1 else (cs[0] if cs else torch.empty((0, words), dtype=dtype,
+                   device=self.device)) for cs in chunks]
+        budget = max(1, self.ROUND_BYTES // (words * 8 * P))  # records per (source, destination) per round
+        rounds = max(1, -(-int(allc.max().item()) // budget))
+        out = []
+        for r in range(rounds):
+            in_split = [int(min(max(int(allc[me][d]) - r * budget, 0), budget)) for d in range(P)]
+            out_split = [int(min(max(int(allc[s][me]) - r * budget, 0), budget)) for s in range(P)]
+            send = torch.cat([per_dst[d][r * budget:r * budget + in_split[d]] for d in range(P)], dim=0).contiguous()
+            recv = torch.empty((sum(out_split), words), dtype=dtype, device=self.device)
+            dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split)
+            out.append(recv)
+        if self.device.type == "cuda":
+            # libkmc launches k_insert on its own stream: the collective (torch / RCCL streams) must
+            # have landed before the engine reads the receive buffers
+            torch.cuda.synchronize(self.device)
+        return [out]
 
     def all_reduce_sum(self, stats):
         torch, dist = self.torch, self.dist
@@ -164,6 +189,11 @@ class DistExchange:
 
     def barrier(self):
         self.dist.barrier()
+
+
+def _chunks(x):
+    """A destination's payload is one tensor or a list of tensors."""
+    return list(x) if isinstance(x, (list, tuple)) else [x]
 
 
 def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: List[str],
@@ -272,9 +302,11 @@ def bench_sharded(c: dict, steps: int, warmup: int):
     local = int(os.environ.get("LOCAL_RANK", rank))
     torch.cuda.set_device(local)
     per = max(1, world)
-    cfg = CheckerConfig(**c, table_capacity=int(os.environ.get("KMC_BENCH_TABLE", (1 << 30) // per * 2)),
-                        frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", (1 << 26) // per * 2)),
-                        send_capacity=int(os.environ.get("KMC_BENCH_SEND", (1 << 27) // (per * per))))
+    # per rank: table for its 1/P of the states at load <= 0.5, frontier for its share of the widest
+    # level (2.6e7 states) with 2x slack, send sub-buffers for its share of that level's successors
+    cfg = CheckerConfig(**c, table_capacity=int(os.environ.get("KMC_BENCH_TABLE", max(1 << 27, (1 << 30) // per))),
+                        frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", max(1 << 23, (1 << 26) // per))),
+                        send_capacity=int(os.environ.get("KMC_BENCH_SEND", max(1 << 18, (1 << 25) // (per * per)))))
     eng = HipShardEngine(cfg, rank, world, local)
     ex = DistExchange(torch.device("cuda", local))
     names = eng.mc.action_names()

@@ -140,3 +140,29 @@ def test_cli_prints_tlc_shaped_output(capsys):
     out = capsys.readouterr().out
     assert rc == 12 and "Error: Invariant LeaderInIsr is violated by the initial state." in out
     assert "1 states generated, 1 distinct states found" in out
+
+
+def test_rccl_single_rank_process_group_matches_oracle():
+    """The real torch.distributed/RCCL exchange (world_size 1 is all one GPU allows): exercises
+    DistExchange, the stream hand-over between RCCL and libkmc, and kmc_step_* at a size where
+    levels span many send-buffer tiles."""
+    import torch
+    import torch.distributed as dist
+    from kafka_specification_amd.sharded import check_distributed
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.cuda.set_device(0)
+        o = kmo.Run(kmo.make_config("Kip320", N=3, L=3, R=3, E=2, invariants=("TypeOk",), threads=8))
+        cfg = CheckerConfig(model="Kip320", n_replicas=3, log_size=3, max_records=3, max_leader_epoch=2,
+                            table_capacity=1 << 24, frontier_capacity=1 << 21, send_capacity=1 << 22)
+        r = check_distributed(cfg)
+        assert (r.verdict, r.distinct, r.generated, r.depth) == (o.verdict, o.distinct, o.generated, o.depth)
+        assert r.levels == o.levels
+    finally:
+        if created:
+            dist.destroy_process_group()

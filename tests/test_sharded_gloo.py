@@ -99,14 +99,17 @@ def _names(cfg):
     return [f"a{k}" for k in range(n)]
 
 
-def _worker(rank, world, port, cfg_kw, out):
+def _worker(rank, world, port, cfg_kw, out, round_bytes=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         cfg = CheckerConfig(**cfg_kw)
         eng = OracleShardEngine(cfg, rank, world)
-        r = run_sharded([eng], DistExchange(torch.device("cpu")), cfg, _names(cfg))
+        ex = DistExchange(torch.device("cpu"))
+        if round_bytes:
+            ex.ROUND_BYTES = round_bytes   # force the > 2 GiB work-around's multi-round path
+        r = run_sharded([eng], ex, cfg, _names(cfg))
         out[rank] = dict(distinct=r.distinct, generated=r.generated, depth=r.depth, levels=r.levels, verdict=r.verdict,
                          viol=r.violated_invariant, viol_depth=r.violation_depth, viol_count=r.violation_count,
                          deadlocks=r.deadlock_states, actions=list(r.action_generated.values()),
@@ -121,10 +124,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_world(cfg_kw, world=2):
+def _run_world(cfg_kw, world=2, round_bytes=None):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), cfg_kw, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), cfg_kw, out, round_bytes), nprocs=world, join=True)
     return dict(out)
 
 
@@ -155,3 +158,12 @@ def test_loopback_exchange_three_shards_in_process():
     r = run_sharded(engines, LoopbackExchange(3), cfg, _names(cfg))
     o = kmo.Run(kmo.make_config("Kip101", N=2, L=2, R=2, E=1))
     assert (r.distinct, r.generated, r.levels, r.verdict) == (o.distinct, o.generated, o.levels, o.verdict)
+
+
+def test_exchange_in_many_small_rounds():
+    # ROUND_BYTES small enough that every busy level needs several all_to_all rounds (the
+    # production value is 1 GiB because RCCL corrupts messages above 2 GiB on this stack)
+    kw = dict(model="Kip320", n_replicas=2, log_size=2, max_records=2, max_leader_epoch=2, invariants=("TypeOk",))
+    out = _run_world(kw, world=2, round_bytes=16 * 8 * 2 * 8)  # 8 records per pair per round
+    o = kmo.Run(kmo.make_config("Kip320", N=2, L=2, R=2, E=2))
+    assert out[0]["levels"] == o.levels and out[0]["generated"] == o.generated and out[0]["verdict"] == "ok"
