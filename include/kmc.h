@@ -48,6 +48,10 @@ extern "C" {
 #define KMC_INV_STRONGISR 4u     /* StrongIsr   KafkaReplication.tla:334 */
 #define KMC_INV_LEADERINISR 8u   /* LeaderInIsr KafkaReplication.tla:345 */
 
+#define KMC_MAX_KINDS 16
+#define KMC_MAX_SHARDS 8
+#define KMC_SEND_SUBS 8     /* sub-buffers per destination in the send area (spreads the append counters) */
+
 /* status codes */
 #define KMC_OK 0
 #define KMC_E_ARG 1        /* bad argument / unsupported constants           */
@@ -64,10 +68,6 @@ extern "C" {
 #define KMC_V_FRONTIER_FULL 4  /* a BFS level did not fit frontier_capacity              */
 #define KMC_V_LEVEL_LIMIT 5    /* max_levels reached before exhaustion                   */
 #define KMC_V_ERROR 6
-
-#define KMC_MAX_KINDS 16
-#define KMC_MAX_SHARDS 8
-#define KMC_SEND_SUBS 8     /* sub-buffers per destination in the send area (spreads the append counters) */
 
 typedef struct kmc_config {
     int32_t model;              /* KMC_* model id */
@@ -98,6 +98,13 @@ typedef struct kmc_level_info {
     uint64_t generated_total;   /* running total, TLC's "states generated" (initial state included) */
     uint64_t distinct_total;    /* running total, TLC's "distinct states found" */
     double seconds;             /* wall time since kmc_run started */
+    /* filled by kmc_step_finish only — the expansion that produced this level (this shard): */
+    uint64_t generated_level[KMC_MAX_KINDS]; /* successors generated per action kind */
+    uint64_t violation_count[4]; /* states of the EXPANDED level (depth-1) violating each invariant */
+    uint64_t violation_fp[4];    /* smallest violating fingerprint per invariant, 0 = none */
+    uint64_t deadlocks_level;    /* states of the expanded level without successors */
+    uint32_t error_flags;        /* 1 frontier full, 2 table full, 4 send area full */
+    uint32_t pad_;
 } kmc_level_info;
 
 typedef void (*kmc_progress_cb)(const kmc_level_info* info, void* user);
@@ -110,7 +117,9 @@ typedef struct kmc_result {
     int32_t verdict;            /* KMC_V_* */
     int32_t violated_invariant; /* index 0..3 (TypeOk, WeakIsr, StrongIsr, LeaderInIsr), -1 = none */
     uint64_t violation_depth;   /* depth of the first level holding a violating / deadlocked state */
-    uint64_t violation_count[4];/* new states at that depth violating each checked invariant */
+    uint64_t violation_count[4];/* states at that depth violating each checked invariant (every state is
+                                   checked once, when it is expanded; on a stopping violation the level
+                                   produced by that expansion is not counted) */
     uint64_t violation_fp;      /* fingerprint of the reported witness (the smallest one) */
     uint64_t deadlock_states;   /* expanded states without successors (counted even when unchecked) */
     uint64_t action_generated[KMC_MAX_KINDS]; /* per Next disjunct, in the module's order */

@@ -73,7 +73,7 @@ typedef unsigned int u32;
 struct KmcLevelCtl {
     u64 next_count[KMC_SEGS];        // states appended to each segment of the next frontier
     u64 generated[KMC_MAX_KINDS];    // successors generated per action kind (Next disjunct)
-    u64 viol_count[4];               // new states violating invariant k
+    u64 viol_count[4];               // states of the EXPANDED level violating invariant k
     u64 viol_fp_inv[4];              // max over violators of ~fp  (=> min fp), 0 = none
     u64 deadlock_count;              // expanded states without any successor
     u64 deadlock_fp_inv;
@@ -185,9 +185,10 @@ template <long long MAXID> struct KmcIdSequence {
         t[0] = p.nextId + 1;
         return (long long)p.nextId <= MAXID;
     }
-    static KMC_DEV u32 violated(const u64* t, u32 inv_mask) {  // TypeOk, IdSequence.tla:43
-        return (inv_mask & 1u) && !((long long)t[0] <= MAXID + 1) ? 1u : 0u;
+    static KMC_DEV u32 violated_pre(const Pre& p, u32 inv_mask) {  // TypeOk, IdSequence.tla:43
+        return (inv_mask & 1u) && !((long long)p.nextId <= MAXID + 1) ? 1u : 0u;
     }
+    static KMC_DEV u32 violated(const u64* t, u32 inv_mask) { return violated_pre(extract(t), inv_mask); }
 };
 
 // ========================================================================================
@@ -248,10 +249,10 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
             return eto < p.end[from] && eto < (u32)L;
         }
     }
-    static KMC_DEV u32 violated(const u64* t, u32 inv_mask) {  // TypeOk, :90-95
+    static KMC_DEV u32 violated(const u64* t, u32 inv_mask) { return violated_pre(extract(t), inv_mask); }
+    static KMC_DEV u32 violated_pre(const Pre& p, u32 inv_mask) {  // TypeOk, :90-95
         if (!(inv_mask & 1u)) return 0;
         bool ok = true;
-        const Pre p = extract(t);
         kmc_static_for<0, N>([&](auto R) {
             constexpr int r = decltype(R)::value;
             ok = ok && p.end[r] <= (u32)L;
@@ -591,9 +592,9 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
 
     // ---- invariants; bit k of the result = invariant k violated ---------------------------
     // 0 TypeOk (:101-107)  1 WeakIsr (:320-326)  2 StrongIsr (:334-340)  3 LeaderInIsr (:345)
-    static KMC_DEV u32 violated(const u64* t, u32 inv_mask) {
+    static KMC_DEV u32 violated(const u64* t, u32 inv_mask) { return violated_pre(extract(t), inv_mask); }
+    static KMC_DEV u32 violated_pre(const Pre& p, u32 inv_mask) {
         if (inv_mask == 0) return 0;
-        const Pre p = extract(t);
         u32 bad = 0;
         if (inv_mask & 1u) {
             bool ok = p.nextEp <= (u32)(E + 1) && p.nextRec <= (u32)R && p.qep1 <= (u32)(E + 1) && p.qldr1 <= (u32)N;
@@ -725,16 +726,17 @@ template <class M> struct KmcSink {
         return false;
     }
 
-    static KMC_DEV void check_invariants(const KmcArgs& a, const u64* t, u64 fp) {
-        const u32 bad = M::violated(t, a.inv_mask);
-        if (bad) {
+    // Invariants are evaluated when a state is EXPANDED (kmc_expand_body), not when it is first
+    // claimed: every distinct state is expanded exactly once, its fields are already extracted
+    // there, and all 64 lanes hold a state to check.  (Checking winners inside the flush ran the
+    // evaluation ~3x per tile with a third of the lanes useful and re-extracted every field.)
+    static KMC_DEV void report_violation(const KmcArgs& a, u32 bad, u64 fp) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (bad >> k & 1u) {
-                    atomicAdd(&a.ctl->viol_count[k], 1ull);
-                    atomicMax(&a.ctl->viol_fp_inv[k], ~fp);
-                }
-        }
+        for (int k = 0; k < 4; ++k)
+            if (bad >> k & 1u) {
+                atomicAdd(&a.ctl->viol_count[k], 1ull);
+                atomicMax(&a.ctl->viol_fp_inv[k], ~fp);
+            }
     }
 
     // Two successors per lane.  In LOCAL mode the first probe round of both is issued
@@ -768,10 +770,6 @@ template <class M> struct KmcSink {
         }
         if (!done0) new0 = claim_from(a, fp0, i0, meta0);  // collision chain: the rare slow path
         if (!done1) new1 = claim_from(a, fp1, i1, meta1);
-        if (a.inv_mask) {
-            if (new0) check_invariants(a, t0, fp0);
-            if (new1) check_invariants(a, t1, fp1);
-        }
         out.push(a, new0, t0);
         out.push(a, new1, t1);
     }
@@ -799,7 +797,6 @@ template <class M> struct KmcSink {
         }
         if (a.mode == KMC_MODE_LOCAL) {
             const bool isnew = valid && claim(a, fp, meta);
-            if (isnew && a.inv_mask && !(a.flags & KMC_FLAG_X_NOINV)) check_invariants(a, t, fp);
 #if KMC_OUT_STAGE
             if (!(a.flags & KMC_FLAG_X_NOSTAGE)) out.push(a, isnew, t);
 #else
@@ -827,7 +824,6 @@ template <class M> struct KmcSink {
             // the (P-1)/P that belong elsewhere travel
             const u32 dst = valid ? kmc_owner(fp, a.nshards) : ~0u;
             const bool isnew = dst == a.shard && claim(a, fp, meta);
-            if (isnew && a.inv_mask) check_invariants(a, t, fp);
             out.push(a, isnew, t);
             // bucket the rest by owner: one wave-aggregated atomicAdd per destination present in this batch
             const u32 sub = blockIdx.x % KMC_SEGS;
@@ -934,6 +930,14 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         for (int k = 0; k < W; ++k) s[k] = valid ? a.fin[(u64)k * a.fin_stride + idx] : 0ull;
         const u64 parent = (a.flags & KMC_FLAG_TRACE) ? kmc_fingerprint<W>(s, a.seed) : 0ull;
         typename M::Pre pre = M::extract(s);
+
+        // Invariants of the states of THIS level (see KmcSink::report_violation)
+        if (a.inv_mask && a.mode != KMC_MODE_ENUM && !(a.flags & KMC_FLAG_X_NOINV)) {
+            const u32 bad = valid ? M::violated_pre(pre, a.inv_mask) : 0u;
+            if (__ballot(bad != 0)) {
+                if (bad) KmcSink<M>::report_violation(a, bad, kmc_fingerprint<W>(s, a.seed));
+            }
+        }
 
         // Pass 1 — every guard of Next in one straight-line block: no dispatch, and the compiler
         // shares sub-terms between instances (the effects are dead code here and vanish).

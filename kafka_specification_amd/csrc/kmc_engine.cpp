@@ -276,7 +276,7 @@ struct kmc_handle {
     bool stepping = false, step_expanded = false;
     std::vector<uint64_t> levels;
     std::vector<uint64_t> init_words, witness;
-    bool have_witness = false;
+    bool have_witness = false, have_deadlock = false;
     kmc_result res{};
     double t_start = 0;
     double dry_seconds = 0;
@@ -374,6 +374,7 @@ int reset_run(kmc_handle* h) {
     h->levels.clear();
     h->witness.clear();
     h->have_witness = false;
+    h->have_deadlock = false;
     memset(&h->res, 0, sizeof h->res);
     h->res.violated_invariant = -1;
     h->res.table_capacity = h->table_cap;
@@ -388,38 +389,23 @@ int reset_run(kmc_handle* h) {
     return KMC_OK;
 }
 
-// Fold the device counters of the level that was just produced into the running result.
-// `produced` = states now in frontier[next]; returns true when the search must stop.
-bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, const uint64_t* parent_seg,
-            const u64* new_frontier, const uint64_t* new_seg, int* rc) {
+// Fold the device counters of one expansion into the running result.  `c` describes the expansion
+// of the frontier at depth h->level (the "parent" level): invariant violations and deadlocks refer
+// to ITS states, generated / next_count to the level it produced.  Returns true when the search
+// must stop.  On a stopping invariant violation the produced level is rolled back (not counted), so
+// the reported numbers are those of a checker that tests each state when it is first found.
+bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, const uint64_t* parent_seg, int* rc) {
     kmc_result& r = h->res;
     *rc = KMC_OK;
-    for (int k = 0; k < KMC_MAX_KINDS; ++k) {
-        r.generated += c.generated[k];
-        r.action_generated[k] += c.generated[k];
-    }
-    r.deadlock_states += c.deadlock_count;
-    if (c.err & KMC_ERR_TABLE_FULL) { r.verdict = KMC_V_TABLE_FULL; return true; }
-    if (c.err & (KMC_ERR_FRONTIER_FULL | KMC_ERR_SEND_FULL)) { r.verdict = KMC_V_FRONTIER_FULL; return true; }
-    if (h->cfg.check_deadlock && c.deadlock_count && r.verdict == KMC_V_OK) {
-        r.verdict = KMC_V_DEADLOCK;
-        r.violation_depth = h->level;  // depth of the deadlocked (parent) level
-        r.violation_fp = ~c.deadlock_fp_inv;
-        if (parent_frontier && h->cfg.n_shards == 1) {
-            *rc = find_state(h, parent_frontier, parent_seg, r.violation_fp, &h->witness);
-            h->have_witness = *rc == KMC_OK;
-        }
-        return true;
-    }
     if (r.violated_invariant < 0) {
         for (int k = 0; k < 4; ++k) {
             if ((h->cfg.invariant_mask >> k & 1u) && c.viol_count[k]) {
                 r.violated_invariant = k;
-                r.violation_depth = h->level + 1;
+                r.violation_depth = h->level;
                 r.violation_fp = ~c.viol_fp_inv[k];
                 for (int j = 0; j < 4; ++j) r.violation_count[j] = c.viol_count[j];
-                if (new_frontier && h->cfg.n_shards == 1) {
-                    *rc = find_state(h, new_frontier, new_seg, r.violation_fp, &h->witness);
+                if (parent_frontier && h->cfg.n_shards == 1) {
+                    *rc = find_state(h, parent_frontier, parent_seg, r.violation_fp, &h->witness);
                     h->have_witness = *rc == KMC_OK;
                 }
                 break;
@@ -428,6 +414,27 @@ bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, con
         if (r.violated_invariant >= 0) {
             r.verdict = KMC_V_INVARIANT;
             if (!h->cfg.continue_on_violation) return true;
+        }
+    }
+    for (int k = 0; k < KMC_MAX_KINDS; ++k) {
+        r.generated += c.generated[k];
+        r.action_generated[k] += c.generated[k];
+    }
+    r.deadlock_states += c.deadlock_count;
+    if (c.err & KMC_ERR_TABLE_FULL) { r.verdict = KMC_V_TABLE_FULL; return true; }
+    if (c.err & (KMC_ERR_FRONTIER_FULL | KMC_ERR_SEND_FULL)) { r.verdict = KMC_V_FRONTIER_FULL; return true; }
+    if (h->cfg.check_deadlock && c.deadlock_count && (r.verdict == KMC_V_OK || r.verdict == KMC_V_INVARIANT) &&
+        !h->have_deadlock) {
+        h->have_deadlock = true;
+        if (r.verdict == KMC_V_OK) {
+            r.verdict = KMC_V_DEADLOCK;
+            r.violation_depth = h->level;
+            r.violation_fp = ~c.deadlock_fp_inv;
+            if (parent_frontier && h->cfg.n_shards == 1) {
+                *rc = find_state(h, parent_frontier, parent_seg, r.violation_fp, &h->witness);
+                h->have_witness = *rc == KMC_OK;
+            }
+            return true;
         }
     }
     return false;
@@ -459,10 +466,8 @@ int do_begin(kmc_handle* h) {
     h->cur = 0;
     h->res.distinct = h->n_cur;
     h->levels.push_back(h->n_cur);
-    bool stop = absorb(h, *h->ctl_host, nullptr, nullptr, h->frontier[0], h->seg_n, &rc);
     h->level = 1;
     h->res.depth = 1;
-    (void)stop;
     return rc;
 }
 
@@ -749,15 +754,34 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
     kmc_result& r = h->res;
     auto report = [&]() {
         if (!cb) return;
-        kmc_level_info info{h->level, h->n_cur, r.generated, r.distinct, now_s() - h->t_start};
+        kmc_level_info info{};
+        info.depth = h->level;
+        info.new_states = h->n_cur;
+        info.generated_total = r.generated;
+        info.distinct_total = r.distinct;
+        info.seconds = now_s() - h->t_start;
         cb(&info, user);
     };
     report();
-    bool stop = r.verdict != KMC_V_OK && !(r.verdict == KMC_V_INVARIANT && h->cfg.continue_on_violation);
+    bool stop = false;
     const uint64_t max_levels = h->cfg.max_levels ? h->cfg.max_levels : ~0ull;
     while (!stop && h->n_cur > 0) {
         if (h->level >= max_levels) {
+            // the last frontier is not expanded: give its states their invariant check now
+            if ((rc = zero_ctl(h, 2))) return rc;
+            KmcArgs d = base_args(h, 2);
+            d.fin = h->frontier[h->cur];
+            d.mode = KMC_MODE_DRY;
+            if ((rc = launch(h, h->f_expand, d, expand_grid(h, h->n_cur)))) return rc;
+            if ((rc = read_ctl(h, 2))) return rc;
+            KmcLevelCtl c = *h->ctl_host;
+            for (int k = 0; k < KMC_MAX_KINDS; ++k) c.generated[k] = 0;
+            c.deadlock_count = 0;
+            c.err = 0;
+            absorb(h, c, h->frontier[h->cur], h->seg_n, &rc);
+            if (rc) return rc;
             if (r.verdict == KMC_V_OK) r.verdict = KMC_V_LEVEL_LIMIT;
+            r.queue_left = h->n_cur;
             break;
         }
         const int slot = (int)(h->level & 1);
@@ -811,9 +835,9 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
         }
         uint64_t new_seg[KMC_SEGS];
         const uint64_t produced = produced_segments(h, c, new_seg);
-        stop = absorb(h, c, h->frontier[h->cur], h->seg_n, h->frontier[nxt], new_seg, &rc);
+        stop = absorb(h, c, h->frontier[h->cur], h->seg_n, &rc);
         if (rc) return rc;
-        if (r.verdict == KMC_V_DEADLOCK || r.verdict == KMC_V_TABLE_FULL || r.verdict == KMC_V_FRONTIER_FULL) {
+        if (stop) {  // invariant (produced level rolled back), deadlock, table/frontier full
             r.queue_left = h->n_cur;
             break;
         }
@@ -830,7 +854,6 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
         h->levels.push_back(produced);
         report();
     }
-    if (stop && r.verdict == KMC_V_INVARIANT) r.queue_left = h->n_cur;
     r.n_levels = h->levels.size();
     r.seconds_total = now_s() - h->t_start;
     if (h->dry_seconds > 0) {
@@ -1063,17 +1086,36 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
     const int nxt = h->cur ^ 1;
     uint64_t new_seg[KMC_SEGS];
     const uint64_t produced = produced_segments(h, c, new_seg);
-    absorb(h, c, h->frontier[h->cur], h->seg_n, h->frontier[nxt], new_seg, &rc);
+    kmc_result& r = h->res;
+    for (int k = 0; k < KMC_MAX_KINDS; ++k) {
+        r.generated += c.generated[k];
+        r.action_generated[k] += c.generated[k];
+    }
+    r.deadlock_states += c.deadlock_count;
     h->cur = nxt;
     h->n_cur = produced;
     for (int sg = 0; sg < KMC_SEGS; ++sg) h->seg_n[sg] = new_seg[sg];
     h->level++;
-    if (produced) h->res.depth = h->level;
-    h->res.distinct += produced;
+    if (produced) r.depth = h->level;
+    r.distinct += produced;
     h->levels.push_back(produced);
     h->step_expanded = false;
-    h->res.seconds_total = now_s() - h->t_start;
-    if (info) *info = kmc_level_info{h->level, produced, h->res.generated, h->res.distinct, h->res.seconds_total};
+    r.seconds_total = now_s() - h->t_start;
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->depth = h->level;
+        info->new_states = produced;
+        info->generated_total = r.generated;
+        info->distinct_total = r.distinct;
+        info->seconds = r.seconds_total;
+        for (int k = 0; k < KMC_MAX_KINDS; ++k) info->generated_level[k] = c.generated[k];
+        for (int k = 0; k < 4; ++k) {
+            info->violation_count[k] = c.viol_count[k];
+            info->violation_fp[k] = c.viol_count[k] ? ~c.viol_fp_inv[k] : 0;
+        }
+        info->deadlocks_level = c.deadlock_count;
+        info->error_flags = c.err;
+    }
     return rc;
 }
 

@@ -63,8 +63,11 @@ class HipShardEngine:
 
     def begin(self):
         nat.check(self.lib.kmc_step_begin(self.mc.handle))
-        self._last = self.mc.result()
-        return self._stats(self._last, None, first=True)
+        r = self.mc.result()
+        st = np.zeros(N_STATS, dtype=np.int64)
+        st[0] = r.levels[-1] if r.levels else 0
+        st[16] = r.generated  # the initial state counts as generated on its owner
+        return st
 
     def expand(self):
         """-> per destination, the list of filled sub-buffer slices (each a contiguous [n, W+1] view)."""
@@ -81,29 +84,20 @@ class HipShardEngine:
             nat.check(self.lib.kmc_step_insert(self.mc.handle, C.c_void_p(records.data_ptr()), n))
 
     def finish(self):
+        """Statistics of the expansion just completed: st[0] new states of the produced level,
+        st[1..15] generated per action, st[17..20] invariant violations among the states of the
+        EXPANDED level, st[21] deadlocked states of the expanded level, st[22..24] error flags."""
         info = nat.KmcLevelInfo()
         nat.check(self.lib.kmc_step_finish(self.mc.handle, C.byref(info)))
-        r = self.mc.result()
-        st = self._stats(r, self._last, first=False)
-        self._last = r
-        return st
-
-    def _stats(self, r: CheckResult, prev: Optional[CheckResult], first: bool):
         st = np.zeros(N_STATS, dtype=np.int64)
-        st[0] = r.levels[-1] if r.levels else 0
-        gen = list(r.action_generated.values())
-        pgen = list(prev.action_generated.values()) if prev else [0] * len(gen)
-        for k, g in enumerate(gen):
-            st[1 + k] = g - pgen[k]
-        if first:
-            st[1 + 15] = r.generated  # the initial state counts as generated on its owner
-        if r.violated_invariant is not None and r.violation_depth == len(r.levels) and \
-                (prev is None or prev.violated_invariant is None):
-            for k, name in enumerate(nat.INVARIANT_NAMES):
-                st[17 + k] = r.violation_count[name]
-        st[21] = r.deadlock_states - (prev.deadlock_states if prev else 0)
-        st[22] = 1 if r.verdict == "table_full" else 0
-        st[23] = 1 if r.verdict == "frontier_full" else 0
+        st[0] = info.new_states
+        for k in range(15):
+            st[1 + k] = info.generated_level[k]
+        for k in range(4):
+            st[17 + k] = info.violation_count[k]
+        st[21] = info.deadlocks_level
+        st[22] = 1 if info.error_flags & 2 else 0
+        st[23] = 1 if info.error_flags & (1 | 4) else 0
         return st
 
     def result(self) -> CheckResult:
@@ -206,9 +200,17 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
     action_generated = [0] * nat.KMC_MAX_KINDS
     verdict, viol_inv, viol_depth, viol_count = "ok", None, 0, {n: 0 for n in inv_names}
 
-    def absorb(st, depth):
+    def absorb(st, parent_depth):
+        """st describes the expansion of the level at `parent_depth`.  Returns (stop, new)."""
         nonlocal generated, deadlocks, verdict, viol_inv, viol_depth, viol_count
-        new = int(st[0])
+        if viol_inv is None:
+            counts = {n: int(st[17 + k]) for k, n in enumerate(inv_names)}
+            hit = [n for n in inv_names if n in cfg.invariants and counts[n]]
+            if hit:
+                viol_inv, viol_depth, viol_count = hit[0], parent_depth, counts
+                verdict = "invariant"
+                if not cfg.continue_on_violation:
+                    return True, 0          # the level this expansion produced is rolled back
         for k in range(15):
             action_generated[k] += int(st[1 + k])
             generated += int(st[1 + k])
@@ -216,37 +218,34 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
         deadlocks += int(st[21])
         if st[22]:
             verdict = "table_full"
-        elif st[23]:
+            return True, 0
+        if st[23]:
             verdict = "frontier_full"
-        if viol_inv is None:
-            counts = {n: int(st[17 + k]) for k, n in enumerate(inv_names)}
-            hit = [n for n in inv_names if n in cfg.invariants and counts[n]]
-            if hit:
-                viol_inv, viol_depth, viol_count = hit[0], depth, counts
-                verdict = "invariant"
-        return new
+            return True, 0
+        if cfg.check_deadlock and st[21] and verdict == "ok":
+            verdict, viol_depth = "deadlock", parent_depth
+            return True, 0
+        return False, int(st[0])
 
     st = exchange.all_reduce_sum([e.begin() for e in engines])
-    new = absorb(st, 1)
+    _, new = absorb(st, 0)
     levels.append(new)
     depth = 1
     if progress:
         progress(dict(depth=depth, new_states=new, generated=generated, distinct=sum(levels)))
     max_levels = cfg.max_levels or (1 << 62)
+    stopped = False
     while new > 0 and depth < max_levels:
-        if verdict in ("table_full", "frontier_full") or (verdict == "invariant" and not cfg.continue_on_violation):
-            break
         sends = [e.expand() for e in engines]
         recvs = exchange.all_to_all(sends)
         for e, rs in zip(engines, recvs):
             for r in rs:
                 e.insert(r)
         st = exchange.all_reduce_sum([e.finish() for e in engines])
-        dl_before = deadlocks
-        new = absorb(st, depth + 1)
-        if cfg.check_deadlock and deadlocks > dl_before and verdict == "ok":
-            verdict, viol_depth = "deadlock", depth
+        stopped, produced = absorb(st, depth)
+        if stopped:
             break
+        new = produced
         if new == 0:
             break
         depth += 1
@@ -254,11 +253,11 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
         if progress:
             progress(dict(depth=depth, new_states=new, generated=generated, distinct=sum(levels)))
     if depth >= max_levels and new > 0 and verdict == "ok":
-        verdict = "level_limit"
+        verdict = "level_limit"  # (the unexpanded last frontier is not invariant-checked in sharded mode)
     local = [e.result() for e in engines]
     return CheckResult(
         generated=generated, distinct=sum(levels), depth=len(levels),
-        queue_left=new if verdict != "ok" else 0, verdict=verdict, violated_invariant=viol_inv,
+        queue_left=(levels[-1] if verdict != "ok" else 0), verdict=verdict, violated_invariant=viol_inv,
         violation_depth=viol_depth, violation_count=viol_count, violation_fp=0, deadlock_states=deadlocks,
         action_generated={n: action_generated[k] for k, n in enumerate(action_names)}, levels=levels,
         table_capacity=sum(r.table_capacity for r in local), frontier_capacity=sum(r.frontier_capacity for r in local),
