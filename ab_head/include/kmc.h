@@ -1,0 +1,193 @@
+/* kmc.h — C ABI of the MI355X-native explicit-state model checker for the Kafka replication
+ * TLA+ specs (hachikuji/kafka-specification).
+ *
+ * What this boundary replaces.  The reference repository is ten .tla files; the engine that
+ * checks them is TLC (tla2tools.jar), which is NOT part of /root/reference, so there is no
+ * reference FFI to cite line by line.  The reference-side "interface" is the set of operator
+ * names a TLC .cfg binds:
+ *     INIT Init                       KafkaReplication.tla:109
+ *     NEXT Next                       KafkaTruncateToHighWatermark.tla:33, Kip101.tla:49,
+ *                                     Kip279.tla:53, Kip320.tla:150, Kip320FirstTry.tla:159,
+ *                                     FiniteReplicatedLog.tla:115, IdSequence.tla:39
+ *     INVARIANTS TypeOk WeakIsr StrongIsr LeaderInIsr
+ *                                     KafkaReplication.tla:101,320,334,345
+ *     CONSTANTS Replicas LogSize MaxRecords MaxLeaderEpoch     KafkaReplication.tla:32-36
+ *               (LogRecords, Nil: FiniteReplicatedLog.tla:22-26; MaxId: IdSequence.tla:22)
+ * and the TLC classes this library stands in for are [TLC-recall, unverifiable here]:
+ *     tlc2.tool.fp.FPSet.put(long) / contains / size   -> the HBM fingerprint table
+ *     tlc2.tool.queue.IStateQueue.sEnqueue / sDequeue   -> the frontier arrays
+ *     tlc2.tool.Worker.run()                            -> kmc_run's per-level kernels
+ *     tlc2.tool.ModelChecker (extends AbstractChecker)  -> kmc_open / kmc_run / kmc_result
+ * The ABI is coarse-grained on purpose: one call runs the whole BFS on the device (a JNI call
+ * per fingerprint would be slower than TLC's own FPSet).  INTEGRATION.md shows the JNI stub.
+ *
+ * Conventions: plain C structs, caller-owned buffers, integer status returns (0 = OK), no
+ * exceptions, no global state except the last-open error string; one host thread drives one
+ * handle.  The library fails loudly (KMC_E_*) when no HIP device / compiler is available:
+ * there is no CPU fallback.
+ */
+#ifndef KMC_H
+#define KMC_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* models (root modules) */
+#define KMC_IDSEQUENCE 0              /* IdSequence.tla            constants: max_id            */
+#define KMC_FINITE_REPLICATED_LOG 1   /* FiniteReplicatedLog.tla   n_replicas, log_size, n_log_records */
+#define KMC_TRUNCATE_TO_HW 2          /* KafkaTruncateToHighWatermark.tla                      */
+#define KMC_KIP101 3                  /* Kip101.tla                                            */
+#define KMC_KIP279 4                  /* Kip279.tla                                            */
+#define KMC_KIP320 5                  /* Kip320.tla                                            */
+#define KMC_KIP320_FIRST_TRY 6        /* Kip320FirstTry.tla                                    */
+
+/* invariant bits (invariant_mask) */
+#define KMC_INV_TYPEOK 1u        /* TypeOk      KafkaReplication.tla:101 / FiniteReplicatedLog.tla:95 / IdSequence.tla:43 */
+#define KMC_INV_WEAKISR 2u       /* WeakIsr     KafkaReplication.tla:320 */
+#define KMC_INV_STRONGISR 4u     /* StrongIsr   KafkaReplication.tla:334 */
+#define KMC_INV_LEADERINISR 8u   /* LeaderInIsr KafkaReplication.tla:345 */
+
+#define KMC_MAX_KINDS 16
+#define KMC_MAX_SHARDS 8
+#define KMC_SEND_SUBS 8     /* sub-buffers per destination in the send area (spreads the append counters) */
+
+/* status codes */
+#define KMC_OK 0
+#define KMC_E_ARG 1        /* bad argument / unsupported constants           */
+#define KMC_E_DEVICE 2     /* no usable HIP device, or a HIP call failed     */
+#define KMC_E_COMPILE 3    /* hiprtc could not specialise the kernels        */
+#define KMC_E_NOMEM 4      /* device allocation failed                       */
+#define KMC_E_STATE 5      /* call out of order                              */
+
+/* verdicts */
+#define KMC_V_OK 0             /* "Model checking completed. No error has been found." */
+#define KMC_V_INVARIANT 1      /* an invariant of invariant_mask is violated            */
+#define KMC_V_DEADLOCK 2       /* check_deadlock and a state has no successor            */
+#define KMC_V_TABLE_FULL 3     /* fingerprint table exhausted                            */
+#define KMC_V_FRONTIER_FULL 4  /* a BFS level did not fit frontier_capacity              */
+#define KMC_V_LEVEL_LIMIT 5    /* max_levels reached before exhaustion                   */
+#define KMC_V_ERROR 6
+
+typedef struct kmc_config {
+    int32_t model;              /* KMC_* model id */
+    int32_t n_replicas;         /* |Replicas|              (KafkaReplication.tla:33), <= 8 */
+    int32_t log_size;           /* LogSize                 (:34) */
+    int32_t max_records;        /* MaxRecords              (:35); record ids 0..MaxRecords-1 (:78) */
+    int32_t max_leader_epoch;   /* MaxLeaderEpoch          (:36); epochs 0..MaxLeaderEpoch (:77), <= 7 */
+    int32_t n_log_records;      /* |LogRecords| for FiniteReplicatedLog standalone (FiniteReplicatedLog.tla:24) */
+    int64_t max_id;             /* MaxId for IdSequence standalone (IdSequence.tla:22) */
+    uint32_t invariant_mask;    /* KMC_INV_* bits to check on every new state */
+    int32_t check_deadlock;     /* TLC default is on; these bounded models need it off (-deadlock) */
+    int32_t continue_on_violation; /* TLC -continue: keep exploring after the first violation */
+    int32_t keep_trace;         /* keep predecessor fingerprints (8 B per table slot) for kmc_trace */
+    int32_t device;             /* HIP device ordinal; -1 = host-only handle (pack/unpack/fingerprint only) */
+    int32_t n_shards;           /* 1 = single GPU; P>1: this handle owns fingerprints with owner(fp)==shard_id */
+    int32_t shard_id;
+    uint64_t table_capacity;    /* fingerprint slots (rounded up to a power of two); 0 = auto from free HBM */
+    uint64_t frontier_capacity; /* states per frontier buffer; 0 = auto */
+    uint64_t send_capacity;     /* n_shards>1: records per (destination, sub-buffer) per level; 0 = auto */
+    uint64_t hash_seed;         /* results must not depend on it (collisions aside) */
+    uint64_t max_levels;        /* 0 = unlimited (internal cap 4096) */
+    const char* cache_dir;      /* compiled-kernel cache; NULL = $KMC_CACHE_DIR or <libdir>/kmc_cache */
+} kmc_config;
+
+typedef struct kmc_level_info {
+    uint64_t depth;             /* 1-based: the initial state is depth 1 */
+    uint64_t new_states;        /* distinct states first seen at this depth (this shard) */
+    uint64_t generated_total;   /* running total, TLC's "states generated" (initial state included) */
+    uint64_t distinct_total;    /* running total, TLC's "distinct states found" */
+    double seconds;             /* wall time since kmc_run started */
+    /* filled by kmc_step_finish only — the expansion that produced this level (this shard): */
+    uint64_t generated_level[KMC_MAX_KINDS]; /* successors generated per action kind */
+    uint64_t violation_count[4]; /* states of the EXPANDED level (depth-1) violating each invariant */
+    uint64_t violation_fp[4];    /* smallest violating fingerprint per invariant, 0 = none */
+    uint64_t deadlocks_level;    /* states of the expanded level without successors */
+    uint32_t error_flags;        /* 1 frontier full, 2 table full, 4 send area full */
+    uint32_t pad_;
+} kmc_level_info;
+
+typedef void (*kmc_progress_cb)(const kmc_level_info* info, void* user);
+
+typedef struct kmc_result {
+    uint64_t generated;         /* states generated (every satisfying binding; initial state included) */
+    uint64_t distinct;          /* distinct states found */
+    uint64_t depth;             /* "The depth of the complete state graph search" */
+    uint64_t queue_left;        /* states left on the frontier when the run stopped */
+    int32_t verdict;            /* KMC_V_* */
+    int32_t violated_invariant; /* index 0..3 (TypeOk, WeakIsr, StrongIsr, LeaderInIsr), -1 = none */
+    uint64_t violation_depth;   /* depth of the first level holding a violating / deadlocked state */
+    uint64_t violation_count[4];/* states at that depth violating each checked invariant (every state is
+                                   checked once, when it is expanded; on a stopping violation the level
+                                   produced by that expansion is not counted) */
+    uint64_t violation_fp;      /* fingerprint of the reported witness (the smallest one) */
+    uint64_t deadlock_states;   /* expanded states without successors (counted even when unchecked) */
+    uint64_t action_generated[KMC_MAX_KINDS]; /* per Next disjunct, in the module's order */
+    uint64_t n_levels;
+    uint64_t table_capacity, frontier_capacity;
+    double seconds_total;       /* wall time of kmc_run */
+    double seconds_expand;      /* sum of k_expand kernel durations (HIP events on the engine stream) */
+    uint64_t expand_launches;
+    uint64_t state_words;       /* W: 64-bit words per packed state */
+    uint64_t state_bits;
+} kmc_result;
+
+typedef struct kmc_handle kmc_handle;
+
+/* Compile (or load from cache) the kernels specialised for cfg's constants, allocate the
+ * table and frontiers on cfg->device.  On failure *out is NULL and kmc_last_error() explains. */
+int kmc_open(const kmc_config* cfg, kmc_handle** out);
+/* Compile-and-cache only; needs no GPU (used by the build step).  arch NULL = "gfx950". */
+int kmc_precompile(const kmc_config* cfg, const char* arch);
+/* Whole breadth-first search on the device; cb (may be NULL) is called once per level. */
+int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user);
+int kmc_result_get(kmc_handle* h, kmc_result* out);
+/* Per-level sizes of the last run: fills up to cap entries, returns the number of levels. */
+uint64_t kmc_level_sizes(kmc_handle* h, uint64_t* out, uint64_t cap);
+void kmc_close(kmc_handle* h);
+const char* kmc_last_error(void);
+
+/* --- states as data ---------------------------------------------------------------------
+ * Packed states are state_words little-endian uint64 (layout: csrc/kmc_layout.h).  The
+ * "canonical bytes" form is one byte per field (documented in oracle/kmc_oracle.c and
+ * DESIGN.md) and is what traces are returned in. */
+uint64_t kmc_state_words(kmc_handle* h);
+uint64_t kmc_canon_bytes(kmc_handle* h);
+int kmc_unpack_state(kmc_handle* h, const uint64_t* words, uint8_t* canon);
+int kmc_pack_state(kmc_handle* h, const uint8_t* canon, uint64_t* words);
+uint64_t kmc_fingerprint_of(kmc_handle* h, const uint64_t* words);
+/* Copy the current frontier (the last completed level) to the host as packed AoS records. */
+int kmc_frontier_states(kmc_handle* h, uint64_t* words, uint64_t cap_states, uint64_t* n_out);
+/* All successors of one packed state, straight from the device kernels: writes up to cap
+ * records of (state_words + 2) uint64: state, fingerprint, action kind. */
+int kmc_successors(kmc_handle* h, const uint64_t* words, uint64_t* out, uint64_t cap, uint64_t* n_out);
+/* Counterexample of the last run (needs keep_trace): canonical-byte states from the initial
+ * state to the witness, with the action kind that produced each (-1 for the initial state). */
+int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap, uint64_t* n_out);
+/* The witness of the reported violation / deadlock as a packed state. */
+int kmc_witness(kmc_handle* h, uint64_t* words);
+
+const char* kmc_model_name(int32_t model);
+const char* kmc_action_name(int32_t model, int32_t kind);
+int32_t kmc_action_count(int32_t model);
+const char* kmc_invariant_name(int32_t index);
+
+/* --- level-step interface for the multi-GPU driver (n_shards > 1) ---------------------------
+ * One BFS level = kmc_step_expand (bucket successors by owner into per-destination send
+ * buffers) -> the caller exchanges the buffers (RCCL all-to-all-v) -> kmc_step_insert on each
+ * received buffer -> kmc_step_finish.  All pointers are device pointers on cfg->device. */
+int kmc_step_begin(kmc_handle* h);                       /* reset, insert Init on its owner */
+/* send_counts: KMC_MAX_SHARDS * KMC_SEND_SUBS entries, [destination][sub-buffer] */
+int kmc_step_expand(kmc_handle* h, uint64_t* send_counts);
+int kmc_step_send_buffer(kmc_handle* h, int32_t dst, int32_t sub, void** dev_ptr, uint64_t* record_words);
+/* Let the caller own the send area: [n_shards][KMC_SEND_SUBS][records_per_sub_buffer] records of
+ * (state_words+1) uint64, e.g. a torch tensor whose slices are handed to the collective. */
+int kmc_step_set_send_buffer(kmc_handle* h, void* dev_ptr, uint64_t records_per_sub_buffer);
+int kmc_step_insert(kmc_handle* h, const void* dev_records, uint64_t n_records);
+int kmc_step_finish(kmc_handle* h, kmc_level_info* info); /* info->new_states: this shard's next frontier */
+int kmc_step_set_verdict(kmc_handle* h, int32_t verdict); /* driver-decided global stop reason */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

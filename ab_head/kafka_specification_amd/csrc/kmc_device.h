@@ -55,19 +55,9 @@ typedef unsigned int u32;
 #ifndef KMC_CAS_FIRST
 #define KMC_CAS_FIRST 0   // probe with atomicCAS directly instead of load-then-CAS
 #endif
-#ifndef KMC_PROFILE
-#define KMC_PROFILE 0     // 1: per-phase s_memtime accounting into KmcLevelCtl::prof (costs ~10 %)
-#endif
-#if KMC_PROFILE
-#define KMC_T(var) const u64 var = __builtin_amdgcn_s_memtime()
-#define KMC_TADD(slot, t0, t1) prof_acc[slot] += (t1) - (t0)
-#else
-#define KMC_T(var)
-#define KMC_TADD(slot, t0, t1)
-#endif
 #ifndef KMC_FLUSH2
 #define KMC_FLUSH2 0      // 1: drain 128 successors per flush, two independent probe chains per lane
-#endif                    //    (measured: no gain — the extra registers cost a wave per SIMD)
+#endif                    //    (measured: no gain — the kernel is issue-bound, not latency-bound — and it costs registers)
 // per-wave successor ring capacity: < KMC_FLUSH_N queued before a push, <= 64 pushed at once
 #define KMC_FLUSH_N (KMC_FLUSH2 ? 128 : 64)
 #define KMC_RING (KMC_FLUSH2 ? 256 : 128)
@@ -77,7 +67,6 @@ typedef unsigned int u32;
 #define KMC_FLAG_X_NOSTAGE 32u    // tuning (shadow pass only): winners are not appended
 #define KMC_FLAG_X_NOINV 64u      // tuning: skip invariants
 #define KMC_FLAG_X_PLAINSTORE 128u  // tuning: claim with a plain store instead of atomicCAS (racy, timing only)
-#define KMC_FLAG_DRY_RAND 256u  // tuning: DRY mode does one load from an uncorrelated random table slot
 #define KMC_FLAG_META 2u  // the ring carries a meta plane (predecessor fp for traces / kind for ENUM)
 
 // One per BFS level; the host zeroes it before the level runs and reads it back after.
@@ -91,7 +80,6 @@ struct KmcLevelCtl {
     u64 send_count[KMC_MAX_SHARDS][KMC_SEGS];  // SHARDED: records bucketed per (destination, sub-buffer)
     u64 enum_count;                  // ENUM: records written
     u64 inserted;                    // table claims (== next_count unless the frontier overflowed)
-    u64 prof[8];                     // KMC_PROFILE: summed per-wave s_memtime ticks per phase (tuning aid)
     u32 err;
     u32 pad;
 };
@@ -126,10 +114,6 @@ struct KmcArgs {
 // small compile-time helpers
 // ----------------------------------------------------------------------------------------
 template <int V> struct KmcIC { static constexpr int value = V; };
-// a replica's whole log as one register value: 32-bit when it fits (integer VALU ops on 64-bit
-// values cost two to four times a 32-bit one on this chip), else 64-bit
-template <bool FITS32> struct KmcLogWord { using type = u64; };
-template <> struct KmcLogWord<true> { using type = u32; };
 
 template <int LO, int HI, class F> KMC_DEV void kmc_static_for(F&& f) {
     if constexpr (LO < HI) {
@@ -160,17 +144,6 @@ KMC_DEV u32 kmc_min(u32 a, u32 b) { return a < b ? a : b; }
 // Opaque redefinition: stops LICM from hoisting every action instance's guard/effect out of
 // the instance loop (they only depend on the loop-invariant state), which would keep all of
 // them live at once and cost the kernel its occupancy.
-// Guards are evaluated in the VALU/VGPR domain: g stays an opaque 0/1 integer and every term is
-// `cond ? g : 0` (v_cmp + v_cndmask).  Plain bool chains become 64-bit lane masks in SGPRs, and
-// sixty guards sharing sub-predicates kept ~50 of those alive at once (127+ SGPR spills, and the
-// scalar unit was the busiest pipe of the kernel).
-KMC_DEV u32 kmc_and(u32 g, bool c) {
-    u32 r = c ? g : 0u;
-    asm volatile("" : "+v"(r));  // opaque: stops the fold back into select(c1 & c2, ...) = SGPR mask logic
-    return r;
-}
-KMC_DEV u32 kmc_bit(u32 m, int k) { return (m >> k) & 1u; }
-KMC_DEV u32 kmc_bit64(u64 m, int k) { return (u32)(m >> k) & 1u; }
 KMC_DEV void kmc_launder(u32& x) { asm volatile("" : "+v"(x)); }
 KMC_DEV void kmc_launder(u64& x) { asm volatile("" : "+v"(x)); }
 
@@ -206,11 +179,11 @@ template <long long MAXID> struct KmcIdSequence {
     static KMC_DEV void init(u64* w) { w[0] = 0; }  // IdSequence.tla:37
     static KMC_DEV Pre extract(const u64* s) { return Pre{s[0]}; }
     static KMC_DEV void launder(Pre& p) { kmc_launder(p.nextId); }
-    template <int I> static KMC_DEV u32 inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
+    template <int I> static KMC_DEV bool inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
         // Next == \E id \in IdSet : NextId(id)   (IdSequence.tla:39, NextId :30-33)
         kind = 0; extra = 0;
         t[0] = p.nextId + 1;
-        return (long long)p.nextId <= MAXID ? 1u : 0u;
+        return (long long)p.nextId <= MAXID;
     }
     static KMC_DEV u32 violated_pre(const Pre& p, u32 inv_mask) {  // TypeOk, IdSequence.tla:43
         return (inv_mask & 1u) && !((long long)p.nextId <= MAXID + 1) ? 1u : 0u;
@@ -246,7 +219,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
     static KMC_DEV void launder(Pre& p) {
         for (int r = 0; r < N; ++r) { kmc_launder(p.end[r]); kmc_launder(p.logv[r]); }
     }
-    template <int I> static KMC_DEV u32 inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
+    template <int I> static KMC_DEV bool inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
         extra = 0;
         for (int k = 0; k < W; ++k) t[k] = s[k];
         if constexpr (I < C_APPEND) {
@@ -256,7 +229,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
             const u32 end = p.end[r];
             kmc_setbits(t, Y.log_off[r], Y.BR * L, p.logv[r] | ((u64)rec << (end * Y.BR)));
             kmc_setbits(t, Y.end_off[r], Y.BO, end + 1);
-            return end < (u32)L ? 1u : 0u;
+            return end < (u32)L;
         } else if constexpr (I < C_APPEND + C_TRUNC) {
             // \E offset \in Offsets : TruncateTo(replica, offset)   (:117, :105-109)
             constexpr int J = I - C_APPEND, r = J / L, o = J % L;
@@ -264,7 +237,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
             constexpr u64 keep = (o * Y.BR >= 64) ? ~0ull : ((1ull << (o * Y.BR)) - 1ull);
             kmc_setbits(t, Y.log_off[r], Y.BR * L, p.logv[r] & keep);
             kmc_setbits(t, Y.end_off[r], Y.BO, o);
-            return (u32)o <= p.end[r] ? 1u : 0u;
+            return (u32)o <= p.end[r];
         } else {
             // \E other # replica : ReplicateTo(replica, other)   (:118, :111-113)
             constexpr int J = I - C_APPEND - C_TRUNC, from = J / (N - 1), q = J % (N - 1), to = q + (q >= from);
@@ -273,7 +246,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
             const u64 rec = (p.logv[from] >> (eto * Y.BR)) & MR;
             kmc_setbits(t, Y.log_off[to], Y.BR * L, p.logv[to] | (rec << (eto * Y.BR)));
             kmc_setbits(t, Y.end_off[to], Y.BO, eto + 1);
-            return (eto < p.end[from] && eto < (u32)L) ? 1u : 0u;
+            return eto < p.end[from] && eto < (u32)L;
         }
     }
     static KMC_DEV u32 violated(const u64* t, u32 inv_mask) { return violated_pre(extract(t), inv_mask); }
@@ -320,23 +293,15 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
     static constexpr int B9 = B8 + NP;              // FollowerTruncate (Kip320FirstTry only)
     static constexpr int NINST = B9 + (FIRST ? NP : 0);
 
-    using LogT = typename KmcLogWord<(Y.BR * L <= 32)>::type;
-    static constexpr LogT MR = (LogT)((1ull << Y.BR) - 1);    // one record
+    static constexpr u64 MR = (1ull << Y.BR) - 1;    // one record
     static constexpr u32 MEr = (1u << Y.BEr) - 1;    // record.epoch
     static constexpr u32 FULL = (1u << N) - 1;
 
     struct Pre {
         u32 end[N], hw[N], ep1[N], ldr1[N], isr[N];
-        LogT logv[N];
+        u64 logv[N];
         u32 nextRec, nextEp, qep1, qldr1, qisr;
         u32 rldr1[E + 1], risr[E + 1];
-        // shared sub-predicates of the guards, as opaque integers (see kmc_and)
-        u32 one;    // 1
-        u32 epok;   // nextLeaderEpoch <= MaxLeaderEpoch            (LeaderEpochSeq!NextId, IdSequence.tla:31)
-        u32 pm;     // bit l: ReplicaPresumesLeadership(l)          (KafkaReplication.tla:126)
-        u32 tm;     // bit l: IsTrueLeader(l)                       (:128-131)
-        u32 hm;     // bit l: HasHighWatermarkReachedCurrentEpoch(l) (Kip320.tla:87-92)
-        u64 fm;     // bit l*N+f: IsFollowingLeaderEpoch(l, f)      (Kip320.tla:39-42)
     };
 
     static KMC_DEV void init(u64* w) {  // Init, KafkaReplication.tla:109-120
@@ -348,7 +313,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
         Pre p;
         kmc_static_for<0, N>([&](auto RR) {
             constexpr int r = decltype(RR)::value;
-            p.logv[r] = (LogT)kmc_getbits(s, Y.log_off[r], Y.BR * L);
+            p.logv[r] = kmc_getbits(s, Y.log_off[r], Y.BR * L);
             p.end[r] = (u32)kmc_getbits(s, Y.end_off[r], Y.BO);
             p.hw[r] = (u32)kmc_getbits(s, Y.hw_off[r], Y.BO);
             p.ep1[r] = (u32)kmc_getbits(s, Y.ep_off[r], Y.BE);
@@ -365,23 +330,6 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             p.rldr1[e] = (u32)kmc_getbits(s, Y.reqldr_off[e], Y.BL);
             p.risr[e] = (u32)kmc_getbits(s, Y.reqisr_off[e], Y.BI);
         });
-        p.one = 1u;
-        p.epok = p.nextEp <= (u32)E ? 1u : 0u;
-        p.pm = 0; p.tm = 0; p.hm = 0; p.fm = 0;
-        kmc_static_for<0, N>([&](auto LL) {
-            constexpr int l = decltype(LL)::value;
-            const u32 pres = presumes<l>(p) ? 1u : 0u;
-            p.pm |= pres << l;
-            p.tm |= (is_true_leader<l>(p) ? 1u : 0u) << l;
-            if constexpr (K320 || FIRST) p.hm |= (hw_reached_epoch<l>(p) ? 1u : 0u) << l;
-            if constexpr (K320)
-                kmc_static_for<0, N>([&](auto FF) {
-                    constexpr int f = decltype(FF)::value;
-                    p.fm |= (u64)(following_epoch<l, f>(p) ? 1u : 0u) << (l * N + f);
-                });
-        });
-        kmc_launder(p.one); kmc_launder(p.epok); kmc_launder(p.pm); kmc_launder(p.tm); kmc_launder(p.hm);
-        kmc_launder(p.fm);
         return p;
     }
 
@@ -394,16 +342,14 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
         kmc_launder(p.nextRec); kmc_launder(p.nextEp); kmc_launder(p.qep1); kmc_launder(p.qldr1); kmc_launder(p.qisr);
 #pragma unroll
         for (int e = 0; e <= E; ++e) { kmc_launder(p.rldr1[e]); kmc_launder(p.risr[e]); }
-        kmc_launder(p.one); kmc_launder(p.epok); kmc_launder(p.pm); kmc_launder(p.tm); kmc_launder(p.hm);
-        kmc_launder(p.fm);
     }
 
     // ---- log helpers (FiniteReplicatedLog.tla as instantiated at KafkaReplication.tla:84) ----
-    static KMC_DEV u32 rec_at(LogT logv, u32 o) { return (u32)((logv >> (o * Y.BR)) & MR); }
+    static KMC_DEV u32 rec_at(u64 logv, u32 o) { return (u32)((logv >> (o * Y.BR)) & MR); }
     static KMC_DEV u32 rec_epoch(u32 rec) { return rec & MEr; }
-    static KMC_DEV LogT keep_below(u32 off) {  // mask of the slots < off
+    static KMC_DEV u64 keep_below(u32 off) {  // mask of the slots < off
         const u32 sh = off * Y.BR;
-        return sh >= 8 * sizeof(LogT) ? (LogT)~(LogT)0 : (LogT)((((LogT)1) << sh) - (LogT)1);
+        return sh >= 64 ? ~0ull : ((1ull << sh) - 1ull);
     }
     // TruncateTo(replica, off) for off <= end (FiniteReplicatedLog.tla:105-109)
     template <int r> static KMC_DEV void truncate(u64* t, const Pre& p, u32 off) {
@@ -467,7 +413,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
     }
     // FirstNonMatchingOffsetFromTail(leader, follower) (Kip279.tla:27-45)
     template <int l, int f> static KMC_DEV u32 first_non_matching(const Pre& p) {
-        const LogT x = p.logv[l] ^ p.logv[f];
+        const u64 x = p.logv[l] ^ p.logv[f];
         const u32 lim = kmc_min(p.end[l], p.end[f]);  // leader empty => no match => 0
         u32 best = 0;
         kmc_static_for<0, L>([&](auto O) {
@@ -493,7 +439,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
     // ---- one action instance: guard + effect ---------------------------------------------
     // Returns "enabled"; when enabled, t holds the successor.  `extra` reports additional
     // satisfying bindings that yield the same successor (TLC counts them as generated).
-    template <int I> static KMC_DEV u32 inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
+    template <int I> static KMC_DEV bool inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
         extra = 0;
 #pragma unroll
         for (int k = 0; k < W; ++k) t[k] = s[k];
@@ -502,9 +448,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             constexpr int r = I - B0;
             kind = 0;
             controller_update(t, p, r + 1, p.qisr);
-            u32 g = p.epok & kmc_bit(p.qisr, r);
-            g = kmc_and(g, p.qldr1 != (u32)(r + 1));
-            return g;
+            return (p.qisr >> r & 1u) && p.qldr1 != (u32)(r + 1) && p.nextEp <= (u32)E;
         } else if constexpr (I < B2) {
             // ControllerShrinkIsr (:158-168), three mutually exclusive cases per replica
             constexpr int r = I - B1;
@@ -514,7 +458,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             const u32 newLdr1 = is_ldr ? 0u : p.qldr1;
             const u32 newIsr = (is_ldr && only) ? p.qisr : (p.qisr & ~(1u << r));
             controller_update(t, p, newLdr1, newIsr);
-            return kmc_and(p.epok, is_ldr || (p.qisr >> r & 1u));
+            return (is_ldr || (p.qisr >> r & 1u)) && p.nextEp <= (u32)E;
         } else if constexpr (I < B3) {
             // BecomeLeader (:186-195): request e names leader l
             constexpr int J = I - B2, e = J / N, l = J % N;
@@ -522,26 +466,20 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             kmc_setbits(t, Y.ep_off[l], Y.BE, e + 1);
             kmc_setbits(t, Y.ldr_off[l], Y.BL, l + 1);
             kmc_setbits(t, Y.isr_off[l], Y.BI, p.risr[e]);
-            u32 g = kmc_and(p.one, p.rldr1[e] == (u32)(l + 1));
-            g = kmc_and(g, (u32)e < p.nextEp);
-            g = kmc_and(g, (u32)(e + 1) > p.ep1[l]);
-            return g;
+            return (u32)e < p.nextEp && p.rldr1[e] == (u32)(l + 1) && (u32)(e + 1) > p.ep1[l];
         } else if constexpr (I < B4) {
             constexpr int J = I - B3, l = J / N, r = J % N;
             kind = 3;
             const u32 isr = p.isr[l];
             quorum_update<l>(t, isr | (1u << r));
-            u32 g = kmc_bit(p.tm, l) & kmc_bit(~isr, r);
+            bool g = !(isr >> r & 1u) && is_true_leader<l>(p);
             if constexpr (K320) {  // FencedLeaderExpandIsr (Kip320.tla:110-117)
-                g &= kmc_bit64(p.fm, l * N + r) & kmc_bit(p.hm, l);
-                g = kmc_and(g, p.hw[l] <= p.end[r]);  // HasFollowerReachedHighWatermark :94-98
+                g = g && following_epoch<l, r>(p) && p.hw[l] <= p.end[r] /* HasFollowerReachedHighWatermark :94-98 */
+                    && hw_reached_epoch<l>(p);
             } else if constexpr (FIRST) {  // LeaderExpandIsrBetterFencing (Kip320FirstTry.tla:134-141)
-                g &= kmc_bit(p.hm, l);
-                g = kmc_and(g, caught_up_epoch<l, r>(p, p.hw[l]));
-            } else {  // LeaderExpandIsr (KafkaReplication.tla:248-254); IsFollowerCaughtUp :219-225
-                g = kmc_and(g, p.ldr1[r] == (u32)(l + 1));
-                g = kmc_and(g, p.hw[l] <= p.end[l]);
-                g = kmc_and(g, p.hw[l] <= p.end[r]);
+                g = g && caught_up_epoch<l, r>(p, p.hw[l]) && hw_reached_epoch<l>(p);
+            } else {  // LeaderExpandIsr (KafkaReplication.tla:248-254)
+                g = g && caught_up<l, r>(p, p.hw[l]);
             }
             return g;
         } else if constexpr (I < B5) {
@@ -549,13 +487,13 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             kind = 4;
             const u32 isr = p.isr[l];
             quorum_update<l>(t, isr & ~(1u << r));
-            u32 g = kmc_bit(p.tm, l) & kmc_bit(isr, r);
+            bool g = (isr >> r & 1u) && is_true_leader<l>(p);
             if constexpr (K320) {  // FencedLeaderShrinkIsr (Kip320.tla:78-85)
-                g = kmc_and(g, kmc_bit64(p.fm, l * N + r) == 0u || p.end[r] < p.end[l]);
+                g = g && (!following_epoch<l, r>(p) || p.end[r] < p.end[l]);
             } else if constexpr (FIRST) {  // LeaderShrinkIsrBetterFencing (Kip320FirstTry.tla:114-120)
-                g = kmc_and(g, !caught_up_epoch<l, r>(p, p.end[l]));
+                g = g && !caught_up_epoch<l, r>(p, p.end[l]);
             } else {  // LeaderShrinkIsr (KafkaReplication.tla:233-239)
-                g = kmc_and(g, !caught_up<l, r>(p, p.end[l]));
+                g = g && !caught_up<l, r>(p, p.end[l]);
             }
             return g;
         } else if constexpr (I < B6) {
@@ -563,42 +501,34 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             constexpr int r = I - B5;
             kind = 5;
             const u32 end = p.end[r];
-            const LogT rec = (LogT)(((p.nextRec + 1) << Y.BEr) | (p.ep1[r] - 1));
-            kmc_setbits(t, Y.log_off[r], Y.BR * L, (LogT)(p.logv[r] | (LogT)(rec << (end * Y.BR))));
+            const u64 rec = ((u64)(p.nextRec + 1) << Y.BEr) | (u64)(p.ep1[r] - 1);
+            kmc_setbits(t, Y.log_off[r], Y.BR * L, p.logv[r] | (rec << (end * Y.BR)));
             kmc_setbits(t, Y.end_off[r], Y.BO, end + 1);
             kmc_setbits(t, Y.nextrec_off, Y.BNR, p.nextRec + 1);
-            u32 g = kmc_bit(p.pm, r);
-            g = kmc_and(g, p.nextRec <= (u32)(R - 1));
-            g = kmc_and(g, end < (u32)L);
-            return g;
+            return presumes<r>(p) && p.nextRec <= (u32)(R - 1) && end < (u32)L;
         } else if constexpr (I < B7) {
             constexpr int l = I - B6;
             kind = 6;
             const u32 hw = p.hw[l];
             kmc_setbits(t, Y.hw_off[l], Y.BO, hw + 1);
-            u32 g;
+            bool g;
             if constexpr (K320) {  // FencedLeaderIncHighWatermark (Kip320.tla:63-70)
-                g = kmc_and(p.one, hw < p.end[l]);
+                g = hw < p.end[l];
                 kmc_static_for<0, N>([&](auto F) {
                     constexpr int f = decltype(F)::value;
-                    // f \in isr  =>  IsFollowingLeaderEpoch(l, f) /\ HasOffset(f, hw)
-                    const u32 in = kmc_bit(p.isr[l], f);
-                    g &= (in ^ 1u) | kmc_bit64(p.fm, l * N + f);
-                    g = kmc_and(g, in == 0u || hw < p.end[f]);
+                    if (p.isr[l] >> f & 1u) g = g && following_epoch<l, f>(p) && hw < p.end[f];
                 });
             } else if constexpr (FIRST) {  // ImprovedLeaderIncHighWatermark (Kip320FirstTry.tla:90-97)
-                g = kmc_bit(p.pm, l);
-                g = kmc_and(g, hw < p.end[l]);
+                g = presumes<l>(p) && hw < p.end[l];
                 kmc_static_for<0, N>([&](auto F) {
                     constexpr int f = decltype(F)::value;
-                    g = kmc_and(g, !(p.isr[l] >> f & 1u) || caught_up_epoch<l, f>(p, hw + 1));
+                    if (p.isr[l] >> f & 1u) g = g && caught_up_epoch<l, f>(p, hw + 1);
                 });
             } else {  // LeaderIncHighWatermark (KafkaReplication.tla:264-271)
-                g = kmc_bit(p.pm, l);
-                g = kmc_and(g, hw <= (u32)(L - 1));
+                g = presumes<l>(p) && hw <= (u32)(L - 1);
                 kmc_static_for<0, N>([&](auto F) {
                     constexpr int f = decltype(F)::value;
-                    g = kmc_and(g, !(p.isr[l] >> f & 1u) || (p.ldr1[f] == (u32)(l + 1) && hw < p.end[f]));
+                    if (p.isr[l] >> f & 1u) g = g && p.ldr1[f] == (u32)(l + 1) && hw < p.end[f];
                 });
             }
             return g;
@@ -608,9 +538,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             constexpr int J = I - B7, pr = J / (E + 1), e = J % (E + 1);
             constexpr int l = pr / (N - 1), q = pr % (N - 1), r = q + (q >= l);
             kind = 7;
-            u32 g = kmc_and(p.one, p.rldr1[e] == (u32)(l + 1));
-            g = kmc_and(g, (u32)e < p.nextEp);
-            g = kmc_and(g, (u32)(e + 1) > p.ep1[r]);
+            bool g = (u32)e < p.nextEp && p.rldr1[e] == (u32)(l + 1) && (u32)(e + 1) > p.ep1[r];
             kmc_setbits(t, Y.ep_off[r], Y.BE, e + 1);
             kmc_setbits(t, Y.ldr_off[r], Y.BL, l + 1);
             kmc_setbits(t, Y.isr_off[r], Y.BI, p.risr[e]);
@@ -629,12 +557,9 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
                     // BecomeFollowerTruncateKip279 (Kip279.tla:47-51) / FencedBecomeFollowerAndTruncate (Kip320.tla:134-148)
                     off = first_non_matching<l, r>(p);
                     if constexpr (MODEL == KMC_MODEL_KIP279) extra = p.end[r] == 0 ? 1u : 0u;  // both disjuncts fire
-                    if constexpr (K320) {
-                        g &= kmc_bit(p.pm, l);
-                        g = kmc_and(g, p.ep1[l] == (u32)(e + 1));
-                    }
+                    if constexpr (K320) g = g && presumes<l>(p) && p.ep1[l] == (u32)(e + 1);
                 }
-                g = kmc_and(g, off <= p.end[r]);  // TruncateTo is disabled, not clamped (FiniteReplicatedLog.tla:106)
+                g = g && off <= p.end[r];  // TruncateTo is disabled, not clamped (FiniteReplicatedLog.tla:106)
                 truncate<r>(t, p, off);
                 kmc_setbits(t, Y.hw_off[r], Y.BO, kmc_min(off, p.hw[r]));  // BecomeFollowerAndTruncateTo (:281-294)
             }
@@ -645,18 +570,14 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             constexpr int J = I - B8, l = J / (N - 1), q = J % (N - 1), f = q + (q >= l);
             kind = 8;
             const u32 ef = p.end[f];
-            const LogT rec = (LogT)rec_at(p.logv[l], ef);
-            kmc_setbits(t, Y.log_off[f], Y.BR * L, (LogT)(p.logv[f] | (LogT)(rec << (ef * Y.BR))));
+            const u64 rec = rec_at(p.logv[l], ef);
+            kmc_setbits(t, Y.log_off[f], Y.BR * L, p.logv[f] | (rec << (ef * Y.BR)));
             kmc_setbits(t, Y.end_off[f], Y.BO, ef + 1);
             kmc_setbits(t, Y.hw_off[f], Y.BO, kmc_min(p.hw[l], ef + 1));
-            u32 g = kmc_and(p.one, ef < p.end[l]);
-            g = kmc_and(g, ef < (u32)L);
-            if constexpr (K320) g &= kmc_bit64(p.fm, l * N + f);
-            else if constexpr (FIRST) g = kmc_and(g, caught_up_epoch<l, f>(p, ef));
-            else {
-                g &= kmc_bit(p.pm, l);
-                g = kmc_and(g, p.ldr1[f] == (u32)(l + 1));
-            }
+            bool g = ef < p.end[l] && ef < (u32)L;
+            if constexpr (K320) g = g && following_epoch<l, f>(p);
+            else if constexpr (FIRST) g = g && caught_up_epoch<l, f>(p, ef);
+            else g = g && presumes<l>(p) && p.ldr1[f] == (u32)(l + 1);
             return g;
         } else {
             // FollowerTruncate (Kip320FirstTry.tla:75-82)
@@ -665,11 +586,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             const u32 off = first_non_matching<l, f>(p);
             truncate<f>(t, p, off);
             kmc_setbits(t, Y.hw_off[f], Y.BO, kmc_min(off, p.hw[f]));
-            u32 g = kmc_bit(p.pm, l);
-            g = kmc_and(g, p.ldr1[f] == (u32)(l + 1));
-            g = kmc_and(g, needs_truncation<f, l>(p));
-            g = kmc_and(g, off <= p.end[f]);
-            return g;
+            return presumes<l>(p) && p.ldr1[f] == (u32)(l + 1) && needs_truncation<f, l>(p) && off <= p.end[f];
         }
     }
 
@@ -735,9 +652,6 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
 template <int W> struct KmcStager {
     u64* planes;   // LDS, [W][KMC_QCAP]
     u32 head, count;  // wave-uniform
-#if KMC_PROFILE
-    u64* prof;     // the wave's phase accumulators (5 = fingerprint, 6 = probe/claim)
-#endif
 
     KMC_DEV void init(u64* lds) { planes = lds; head = 0; count = 0; }
 
@@ -865,9 +779,7 @@ template <class M> struct KmcSink {
         const u64 fp = kmc_fingerprint<W>(t, a.seed);
         if (a.mode == KMC_MODE_DRY) {
             u64 acc = fp;
-            if (valid && (a.flags & KMC_FLAG_DRY_RAND)) {  // ONE load from an unrelated random slot per successor
-                acc ^= a.table[kmc_mix64(fp ^ 0xABCDEF12345ull) & a.table_mask];
-            } else if (valid && (a.flags & KMC_FLAG_DRY_PROBE)) {  // read-only probe sequence (the table is already full)
+            if (valid && (a.flags & KMC_FLAG_DRY_PROBE)) {  // read-only probe sequence (the table is already full)
                 u64 i = fp & a.table_mask;
                 for (u64 probes = 0; probes <= a.table_mask; ++probes) {
                     const u64 v = a.table[i];
@@ -884,9 +796,6 @@ template <class M> struct KmcSink {
             return;
         }
         if (a.mode == KMC_MODE_LOCAL) {
-            // (A per-wave LDS filter of recently resolved fingerprints was tried here to skip
-            // duplicate probes: only 4.9 % of the successors hit it — duplicates are not local to
-            // a wave — so it was dropped.)
             const bool isnew = valid && claim(a, fp, meta);
 #if KMC_OUT_STAGE
             if (!(a.flags & KMC_FLAG_X_NOSTAGE)) out.push(a, isnew, t);
@@ -976,14 +885,9 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + W * KMC_QCAP);  // q[k*KMC_RING + pos]
     KmcStager<W> out;
     out.init(q + ring_planes * KMC_RING);
-    u32 head = 0, count = 0;  // wave-uniform: ring read position / number of QUEUED successors
+    u32 head = 0, count = 0;  // wave-uniform: ring read position / occupancy
     u32 gen_lane = 0;         // lane k accumulates the successors generated by action kind k
     u32 deadlocks = 0;
-#if KMC_PROFILE
-    u64 prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 0 load+extract+inv 1 guards 2 effects+push 3 flush 4 tail 7 total
-    const u64 t_kernel0 = __builtin_amdgcn_s_memtime();
-    out.prof = prof_acc;
-#endif
 
     auto flush = [&](u32 nv) {  // nv <= KMC_FLUSH_N queued successors leave the ring
         u64 t0[W];
@@ -1005,26 +909,22 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         count -= nv;
     };
 
-    // Segment by segment; within a segment the 64-state tiles are dealt round-robin to all waves
-    // of the grid.  (One flat tile index over all segments needed their prefix sums live in
-    // SGPRs for the whole kernel.)
-    const u32 nwaves = gridDim.x * KMC_WAVES;
-    const u32 wave0 = blockIdx.x * KMC_WAVES + wib;
-#pragma clang loop unroll(disable)
-    for (int sg = 0; sg < KMC_SEGS; ++sg) {
-    const u64 seg_n = a.seg_count[sg];
-    const u64 seg_base = (u64)sg * a.seg_cap;
-    const u64 seg_tiles = (seg_n + 63) >> 6;
-    // rotate the starting wave per segment so that short segments do not always land on the same waves
-    const u32 first = (wave0 + nwaves - (u32)((sg * 977u) % nwaves)) % nwaves;
-#pragma clang loop unroll(disable)
-    for (u64 tile = first; tile < seg_tiles; tile += nwaves) {
-        const u64 j = (tile << 6) + lane;
-        const bool valid = j < seg_n;
-        const u64 idx = seg_base + j;
-        KMC_T(tp0);
-        // (prefetching the next tile's words here was measured: no gain — the extra live registers
-        // spill under the 96-VGPR budget that 5 waves/SIMD need)
+    const u64 nwaves = (u64)gridDim.x * KMC_WAVES;
+    u64 tstart[KMC_SEGS + 1];  // wave-uniform: first 64-state tile of each segment
+    tstart[0] = 0;
+#pragma unroll
+    for (int sg = 0; sg < KMC_SEGS; ++sg) tstart[sg + 1] = tstart[sg] + ((a.seg_count[sg] + 63) >> 6);
+    const u64 ntiles = tstart[KMC_SEGS];
+    for (u64 tile = (u64)blockIdx.x * KMC_WAVES + wib; tile < ntiles; tile += nwaves) {
+        u64 idx = 0;
+        bool valid = false;
+#pragma unroll
+        for (int sg = 0; sg < KMC_SEGS; ++sg)
+            if (tile >= tstart[sg] && tile < tstart[sg + 1]) {
+                const u64 j = ((tile - tstart[sg]) << 6) + lane;
+                valid = j < a.seg_count[sg];
+                idx = (u64)sg * a.seg_cap + j;
+            }
         u64 s[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) s[k] = valid ? a.fin[(u64)k * a.fin_stride + idx] : 0ull;
@@ -1039,8 +939,6 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             }
         }
 
-        KMC_T(tp1);
-        KMC_TADD(0, tp0, tp1);
         // Pass 1 — every guard of Next in one straight-line block: no dispatch, and the compiler
         // shares sub-terms between instances (the effects are dead code here and vanish).
         // (32-bit halves + shift-by-literal: one v_cndmask + one v_lshl_or per instance; a
@@ -1054,30 +952,30 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             u64 tt[W];
             int kd;
             u32 ex;
-            const u32 g01 = M::template inst<i>(pre, s, tt, kd, ex) & valid01;
+            const u32 g01 = M::template inst<i>(pre, s, tt, kd, ex) ? valid01 : 0u;
             en32[i >> 5] |= g01 << (i & 31);
             kmc_launder(en32[i >> 5]);  // keep the OR chain sequential (a reassociated tree keeps every leaf live)
         });
+        u64 en[NW];
         u32 nsucc = 0;
 #pragma unroll
-        for (int h = 0; h < 2 * NW; ++h) nsucc += __popc(en32[h]);
+        for (int wd = 0; wd < NW; ++wd) {
+            en[wd] = ((u64)en32[2 * wd + 1] << 32) | en32[2 * wd];
+            nsucc += __popcll(en[wd]);
+        }
 
-        KMC_T(tp2);
-        KMC_TADD(1, tp1, tp2);
         // Pass 2 — wave-uniform walk over the instances; only those some lane enabled dispatch
-        // to their (statically specialised) effect.  (A fall-through `switch` that only dispatches
-        // when resuming after a flush cut the branches 5x and was no faster: the kernel is bound by
-        // per-wave latency (compute chain + exposed memory waits), not by issue or branch counts.)
-        u32 cur = 0;
+        // to their (statically specialised) effect.
+        u64 cur = 0;
 #pragma clang loop unroll(disable)
         for (int i = 0; i < M::NINST; ++i) {
-            if ((i & 31) == 0) {
-                cur = en32[0];
+            if ((i & 63) == 0) {
+                cur = en[0];
 #pragma unroll
-                for (int h = 1; h < 2 * NW; ++h)
-                    if ((i >> 5) == h) cur = en32[h];
+                for (int wd = 1; wd < NW; ++wd)
+                    if ((i >> 6) == wd) cur = en[wd];
             }
-            const bool e = cur & 1u;
+            const bool e = cur & 1ull;
             cur >>= 1;
             const u64 m = __ballot(e);
             if (m == 0) continue;
@@ -1107,32 +1005,16 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
                 if (has_meta) q[W * KMC_RING + pos] = a.mode == KMC_MODE_ENUM ? (u64)kind : parent;
             }
             count += n;
-            if (count >= KMC_FLUSH_N) {
-                KMC_T(tf0);
-                flush(KMC_FLUSH_N);
-                KMC_T(tf1);
-                KMC_TADD(3, tf0, tf1);
-            }
+            if (count >= KMC_FLUSH_N) flush(KMC_FLUSH_N);
         }
-        KMC_T(tp3);
-        KMC_TADD(2, tp2, tp3);
         const u64 dm = __ballot(valid && nsucc == 0);
         if (dm) {
             deadlocks += __popcll(dm);
             if (valid && nsucc == 0) atomicMax(&a.ctl->deadlock_fp_inv, ~kmc_fingerprint<W>(s, a.seed));
         }
     }
-    }
-    KMC_T(tt0);
     while (count) flush(count < KMC_FLUSH_N ? count : KMC_FLUSH_N);
     out.finish(a);
-    KMC_T(tt1);
-    KMC_TADD(4, tt0, tt1);
-#if KMC_PROFILE
-    prof_acc[7] = __builtin_amdgcn_s_memtime() - t_kernel0;
-    if (lane == 0)
-        for (int k = 0; k < 8; ++k) atomicAdd(&a.ctl->prof[k], prof_acc[k]);
-#endif
     if (lane < (u32)M::NKINDS && gen_lane) atomicAdd(&a.ctl->generated[lane], (u64)gen_lane);
     if (lane == 0 && deadlocks) atomicAdd(&a.ctl->deadlock_count, (u64)deadlocks);
 }
@@ -1149,10 +1031,6 @@ template <class M> KMC_DEV void kmc_insert_body(const KmcArgs& a) {
     __shared__ u64 stage[KMC_WAVES][W][KMC_QCAP];
     KmcStager<W> out;
     out.init(&stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0][0]);
-#if KMC_PROFILE
-    u64 prof_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    out.prof = prof_dummy;
-#endif
     const u64 n = a.n_in;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u64 rounds = (n + stride - 1) / stride;

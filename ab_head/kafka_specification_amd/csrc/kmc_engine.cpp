@@ -280,7 +280,6 @@ struct kmc_handle {
     kmc_result res{};
     double t_start = 0;
     double dry_seconds = 0;
-    uint64_t prof[8] = {0}, prof_dry[8] = {0};
 };
 
 namespace {
@@ -574,12 +573,6 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->f_expand, KMC_BLOCK,
                                                            kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0)) == hipSuccess && occ > 0)
         h->blocks_per_cu = occ > 8 ? 8 : occ;
-    {   // the occupancy query may admit a block more than really fits when LDS is the limit
-        // (5 x 32 KiB = all 160 KiB was reported resident, ran as 4 + a queued 5th: 69 ms vs 55 ms)
-        const unsigned lds = kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0);
-        const int by_lds = (int)((160u * 1024u - 1024u) / (lds ? lds : 1u));
-        if (by_lds >= 1 && h->blocks_per_cu > by_lds) h->blocks_per_cu = by_lds;
-    }
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
@@ -824,7 +817,6 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
         r.seconds_expand += 1e-3 * ms;
         r.expand_launches++;
         const KmcLevelCtl c = *h->ctl_host;
-        for (int k = 0; k < 8; ++k) h->prof[k] += c.prof[k];
         static const int dry = getenv("KMC_DRYRUN") ? atoi(getenv("KMC_DRYRUN")) : 0;
         if (dry) {  // tuning aid: time the same level again without table writes / frontier traffic
             KmcArgs d = a;  // 1: no table access at all, 2: + read-only probes, 3: + invariants on every successor
@@ -832,7 +824,6 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
             if (dry >= 2) d.flags |= KMC_FLAG_DRY_PROBE;
             if (dry == 3) d.flags |= KMC_FLAG_DRY_INV;
             if (dry == 4) d.flags |= KMC_FLAG_DRY_ATOM;
-            if (dry == 5) d.flags |= KMC_FLAG_DRY_RAND;
             d.ctl = h->ctl + 2;
             HIP_TRY(hipEventRecord(h->ev0, h->stream));
             if ((rc = launch(h, h->f_expand, d, expand_grid(h, h->n_cur)))) return rc;
@@ -841,10 +832,6 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
             float dms = 0;
             HIP_TRY(hipEventElapsedTime(&dms, h->ev0, h->ev1));
             h->dry_seconds += 1e-3 * dms;
-            KmcLevelCtl dc;
-            HIP_TRY(hipMemcpy(&dc, h->ctl + 2, sizeof dc, hipMemcpyDeviceToHost));
-            for (int k = 0; k < 8; ++k) h->prof_dry[k] += dc.prof[k];
-            HIP_TRY(hipMemsetAsync(h->ctl + 2, 0, sizeof(KmcLevelCtl), h->stream));
         }
         uint64_t new_seg[KMC_SEGS];
         const uint64_t produced = produced_segments(h, c, new_seg);
@@ -869,22 +856,6 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
     }
     r.n_levels = h->levels.size();
     r.seconds_total = now_s() - h->t_start;
-    if (h->prof[7]) {
-        const double tot = (double)h->prof[7];
-        fprintf(stderr, "[kmc] per-wave ticks: load+extract+inv %.1f%%  guards %.1f%%  effects+push(incl flush) %.1f%%  "
-                        "of which flush %.1f%%  tail %.1f%%  (total %.3g ticks)\n",
-                100 * h->prof[0] / tot, 100 * h->prof[1] / tot, 100 * h->prof[2] / tot, 100 * h->prof[3] / tot,
-                100 * h->prof[4] / tot, tot);
-        for (int k = 0; k < 8; ++k) h->prof[k] = 0;
-    }
-    if (h->prof_dry[7]) {
-        const double tot = (double)h->prof_dry[7];
-        fprintf(stderr, "[kmc] DRY per-wave ticks: load+extract+inv %.1f%%  guards %.1f%%  effects+push(incl flush) %.1f%%  "
-                        "of which flush %.1f%%  tail %.1f%%  (total %.3g ticks)\n",
-                100 * h->prof_dry[0] / tot, 100 * h->prof_dry[1] / tot, 100 * h->prof_dry[2] / tot,
-                100 * h->prof_dry[3] / tot, 100 * h->prof_dry[4] / tot, tot);
-        for (int k = 0; k < 8; ++k) h->prof_dry[k] = 0;
-    }
     if (h->dry_seconds > 0) {
         fprintf(stderr, "[kmc] dry/shadow expand: %.3f ms vs real %.3f ms\n",
                 1e3 * h->dry_seconds, 1e3 * r.seconds_expand);

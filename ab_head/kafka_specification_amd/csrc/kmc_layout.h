@@ -1,0 +1,133 @@
+// kmc_layout.h — bit-packed state vector layouts for the Kafka replication specs.
+//
+// Shared verbatim by the host engine (runtime parameters) and by the device code (the same
+// constexpr function evaluated at compile time for one specialised (model,N,L,R,E)), so the
+// two can never disagree.  Self-contained: no includes (it is also fed to hiprtc).
+//
+// Kafka-family state vector (`vars`, KafkaReplication.tla:75), tight sequential packing,
+// least-significant bit first, fields may straddle 64-bit words:
+//   for r in Replicas:  log[r]     L records x BR bits      replicaLog[r].records (FiniteReplicatedLog.tla:42)
+//                                  record = 0 (Nil) | ((id+1) << BEr | epoch)    LogRecords, KafkaReplication.tla:82
+//   for r in Replicas:  end[r] BO  replicaLog[r].endOffset   (FiniteReplicatedLog.tla:41)
+//                       hw[r]  BO  replicaState[r].hw        (KafkaReplication.tla:96)
+//                       ep[r]  BE  replicaState[r].leaderEpoch + 1   (Nil = -1 -> 0)   (:97, :39)
+//                       ldr[r] BL  replicaState[r].leader: 0 = None, else index+1      (:98, :38)
+//                       isr[r] N   replicaState[r].isr bitmask                          (:99)
+//   nextRecordId BNR (:78) | nextLeaderEpoch BE (:77) | quorumState: ep BE, ldr BL, isr N (:87-89)
+//   for e in 0..E: request with leaderEpoch e: ldr BL, isr N   (zero while e >= nextLeaderEpoch)
+// leaderAndIsrRequests is a set, but ControllerUpdateIsr (KafkaReplication.tla:138-145) is its
+// only writer and always adds the record whose leaderEpoch equals the old nextLeaderEpoch, so
+// the set is in bijection with this epoch-indexed array.  Unwritten log slots are 0
+// (FiniteReplicatedLog.tla:93,108), so equal states have equal bits.
+//
+// FiniteReplicatedLog standalone: for r: log[r] (L x BK bits, record = 0 Nil | 1..K), then
+// for r: end[r] (BO).   IdSequence standalone: one 64-bit word = nextId.
+#pragma once
+
+#define KMC_MAXN 8
+#define KMC_MAXE1 8
+#define KMC_MAXW 12
+
+#define KMC_MODEL_IDSEQUENCE 0
+#define KMC_MODEL_FINITE_REPLICATED_LOG 1
+#define KMC_MODEL_TRUNCATE_TO_HW 2
+#define KMC_MODEL_KIP101 3
+#define KMC_MODEL_KIP279 4
+#define KMC_MODEL_KIP320 5
+#define KMC_MODEL_KIP320_FIRST_TRY 6
+
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+#define KMC_HD __host__ __device__
+#else
+#define KMC_HD
+#endif
+
+// number of bits needed for values 0..nvalues-1
+KMC_HD constexpr int kmc_bits_for(long long nvalues) {
+    int b = 0;
+    while ((1ll << b) < nvalues) ++b;
+    return b;
+}
+
+struct KmcLayout {
+    int model, N, L, R, E, K;
+    int BO, BR, BEr, BId, BE, BL, BI, BNR;  // field widths
+    int log_off[KMC_MAXN], end_off[KMC_MAXN], hw_off[KMC_MAXN], ep_off[KMC_MAXN], ldr_off[KMC_MAXN],
+        isr_off[KMC_MAXN];
+    int nextrec_off, nextep_off, qep_off, qldr_off, qisr_off;
+    int reqldr_off[KMC_MAXE1], reqisr_off[KMC_MAXE1];
+    int bits, W;
+    int valid;  // 0 when the parameters cannot be packed (see kmc_make_layout)
+};
+
+KMC_HD constexpr KmcLayout kmc_make_layout(int model, int N, int L, int R, int E, int K) {
+    KmcLayout y{};
+    y.model = model; y.N = N; y.L = L; y.R = R; y.E = E; y.K = K;
+    y.valid = 0;
+    if (model == KMC_MODEL_IDSEQUENCE) {
+        y.bits = 64; y.W = 1; y.valid = 1;
+        return y;
+    }
+    if (N < 1 || N > KMC_MAXN || L < 1) return y;
+    int pos = 0;
+    y.BO = kmc_bits_for(L + 1);
+    if (model == KMC_MODEL_FINITE_REPLICATED_LOG) {
+        if (K < 1) return y;
+        y.BR = kmc_bits_for(K + 1);
+        if (y.BR * L > 64) return y;
+        for (int r = 0; r < N; ++r) { y.log_off[r] = pos; pos += y.BR * L; }
+        for (int r = 0; r < N; ++r) { y.end_off[r] = pos; pos += y.BO; }
+        y.bits = pos; y.W = (pos + 63) / 64;
+        y.valid = y.W >= 1 && y.W <= KMC_MAXW;
+        return y;
+    }
+    if (R < 1 || E < 0 || E + 1 > KMC_MAXE1) return y;
+    y.BEr = kmc_bits_for(E + 1);      // record.epoch in 0..E
+    y.BId = kmc_bits_for(R + 1);      // record.id+1 in 1..R, 0 reserved for Nil
+    y.BR = y.BEr + y.BId;
+    if (y.BR * L > 64) return y;      // one log must fit one 64-bit lane value
+    y.BE = kmc_bits_for(E + 2);       // leaderEpoch+1 in 0..E+1 ; nextLeaderEpoch in 0..E+1
+    y.BL = kmc_bits_for(N + 1);
+    y.BI = N;
+    y.BNR = kmc_bits_for(R + 1);      // nextRecordId in 0..R
+    for (int r = 0; r < N; ++r) { y.log_off[r] = pos; pos += y.BR * L; }
+    for (int r = 0; r < N; ++r) {
+        y.end_off[r] = pos; pos += y.BO;
+        y.hw_off[r] = pos; pos += y.BO;
+        y.ep_off[r] = pos; pos += y.BE;
+        y.ldr_off[r] = pos; pos += y.BL;
+        y.isr_off[r] = pos; pos += y.BI;
+    }
+    y.nextrec_off = pos; pos += y.BNR;
+    y.nextep_off = pos; pos += y.BE;
+    y.qep_off = pos; pos += y.BE;
+    y.qldr_off = pos; pos += y.BL;
+    y.qisr_off = pos; pos += y.BI;
+    for (int e = 0; e <= E; ++e) {
+        y.reqldr_off[e] = pos; pos += y.BL;
+        y.reqisr_off[e] = pos; pos += y.BI;
+    }
+    y.bits = pos; y.W = (pos + 63) / 64;
+    y.valid = y.W >= 1 && y.W <= KMC_MAXW;
+    return y;
+}
+
+// Generic bit-field access on a packed state.  With compile-time `off`/`bits` (the device
+// path after unrolling) every branch below folds away.
+KMC_HD inline unsigned long long kmc_getbits(const unsigned long long* w, int off, int bits) {
+    if (bits == 0) return 0ull;
+    const int i = off >> 6, s = off & 63;
+    unsigned long long v = w[i] >> s;
+    if (s + bits > 64) v |= w[i + 1] << (64 - s);
+    return bits >= 64 ? v : (v & ((1ull << bits) - 1ull));
+}
+KMC_HD inline void kmc_setbits(unsigned long long* w, int off, int bits, unsigned long long val) {
+    if (bits == 0) return;
+    const int i = off >> 6, s = off & 63;
+    const unsigned long long m = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+    w[i] = (w[i] & ~(m << s)) | ((val & m) << s);
+    if (s + bits > 64) {
+        const int lo = 64 - s;  // bits already written into word i
+        w[i + 1] = (w[i + 1] & ~(m >> lo)) | ((val & m) >> lo);
+    }
+}

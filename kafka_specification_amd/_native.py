@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmc.so")
+LIB_PATH = os.environ.get("KMC_LIB_PATH") or os.path.join(_HERE, "libkmc.so")  # override: A/B two builds
 
 KMC_MAX_KINDS = 16
 KMC_MAX_SHARDS = 8

@@ -1,0 +1,58 @@
+// Random-access roofline of one MI355X for the seen-set's access pattern: 8-byte accesses at
+// uniformly random slots of an 8 GiB table (each moves one 64-byte sector).
+//   mode 0: dependent random loads            (latency-bound per lane, many lanes)
+//   mode 1: 4 independent random loads / lane (memory-level parallelism x4)
+//   mode 2: random atomicCAS(0 -> x) on a zeroed table, one per lane-iteration
+//   mode 3: load, then atomicCAS when the slot was empty (the claim sequence)
+// Prints G accesses/s.  Build: hipcc --offload-arch=gfx950 -O3 randbench.hip -o randbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 mix(u64 x) { x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31; return x; }
+__global__ __launch_bounds__(256) void k(u64* table, u64 mask, int iters, int mode, u64* sink) {
+    u64 x = mix(blockIdx.x * 256ull + threadIdx.x + 12345);
+    u64 acc = 0;
+    if (mode == 0) {
+        for (int i = 0; i < iters; ++i) { x = mix(x + table[x & mask]); }
+        acc = x;
+    } else if (mode == 1) {
+        for (int i = 0; i < iters; i += 4) {
+            u64 a = mix(x + 1), b = mix(x + 2), c = mix(x + 3), d = mix(x + 4);
+            u64 va = table[a & mask], vb = table[b & mask], vc = table[c & mask], vd = table[d & mask];
+            x = mix(x ^ va ^ vb ^ vc ^ vd ^ a);
+        }
+        acc = x;
+    } else if (mode == 2) {
+        for (int i = 0; i < iters; ++i) { x = mix(x + 1); acc ^= atomicCAS(&table[x & mask], 0ull, x | 1); }
+    } else {
+        for (int i = 0; i < iters; ++i) {
+            x = mix(x + 1);
+            u64 v = table[x & mask];
+            if (v == 0) v = atomicCAS(&table[x & mask], 0ull, x | 1);
+            acc ^= v;
+        }
+    }
+    if (acc == 0x1234) sink[0] = acc;
+}
+int main(int argc, char** argv) {
+    const u64 slots = 1ull << 30;  // 8 GiB
+    u64 *table, *sink;
+    hipMalloc(&table, slots * 8); hipMalloc(&sink, 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 4; ++mode)
+        for (int bpc : {4, 8}) {
+            hipMemset(table, 0, slots * 8);
+            const int blocks = 256 * bpc, iters = mode == 0 ? 400 : 800;
+            k<<<blocks, 256>>>(table, slots - 1, 8, mode, sink);  // warm-up
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            k<<<blocks, 256>>>(table, slots - 1, iters, mode, sink);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            double n = (double)blocks * 256 * iters;
+            printf("mode %d blocks/CU %d: %.1f M accesses in %.2f ms = %.1f G/s (%.2f TB/s of 64-B sectors)\n", mode, bpc,
+                   n / 1e6, ms, n / ms / 1e6, n * 64 / ms / 1e9);
+        }
+    return 0;
+}
