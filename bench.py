@@ -37,6 +37,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_BPS = 8.0e12  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+# Random-access roofline of the seen-set's pattern, measured with tools/membench/randbench on an
+# MI355X (profiles/r01_randbench.txt): uniformly random 8-byte accesses over an 8 GiB table.
+RANDOM_LOADS_PER_S = 49.8e9
+RANDOM_CAS_PER_S = 17.3e9
 
 
 def headline_config():
@@ -145,6 +149,9 @@ def main():
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # memory floor of this run under the measured random-access rates: one probe load per generated
+    # successor, one CAS per claim (about 1.11 per distinct state: ties between racing lanes)
+    mem_floor_s = generated / RANDOM_LOADS_PER_S + 1.115 * distinct / RANDOM_CAS_PER_S
     out = {
         "metric": "distinct states/sec + time-to-exhaustive, KafkaReplication 3-broker",
         "value": value, "unit": "distinct states/s", "n_gpus": max(a.gpus, world), "steps": a.steps,
@@ -159,6 +166,10 @@ def main():
                      "kernel": "kmc_expand_*", "kernel_seconds_per_step": kernel_s, "launches_per_step": launches,
                      "algorithmic_bytes_per_launch": alg_bytes_per_state * distinct / max(launches, 1),
                      "algorithmic_bytes_per_distinct_state": alg_bytes_per_state,
+                     "random_access_floor_s": mem_floor_s,
+                     "frac_of_random_access_floor": mem_floor_s / max(kernel_s, 1e-12),
+                     "random_access_rates": {"loads_per_s": RANDOM_LOADS_PER_S, "cas_per_s": RANDOM_CAS_PER_S,
+                                             "source": "profiles/r01_randbench.txt"},
                      "note": "aggregate over the step's per-level launches (HIP events on the engine stream); "
                              "random 8-B probes move >= one 64-B sector each, so 12.5 % useful bytes is the ceiling "
                              "for the probe part"},
