@@ -78,3 +78,24 @@ def test_cli_error_paths(capsys):
     if not torch.cuda.is_available():
         rc = tlc.main([os.path.join(ROOT, "models", "IdSequence.tla"), "-deadlock"])
         assert rc == 3 and "no CPU fallback" in capsys.readouterr().err         # fails loudly without a GPU
+
+
+def test_native_cli_error_paths(tmp_path):
+    import subprocess
+    exe = os.path.join(ROOT, "kafka_specification_amd", "tlc")
+    assert os.path.exists(exe), "native CLI not built (python __graft_entry__.py)"
+    r = subprocess.run([exe, os.path.join(ROOT, "models", "Nope.tla")], capture_output=True, text=True)
+    assert r.returncode == 2 and "not found" in r.stderr
+    bad = tmp_path / "x.cfg"
+    bad.write_text("CONSTANT MaxId = 3\nSYMMETRY Perms\n")
+    r = subprocess.run([exe, "-config", str(bad), os.path.join(ROOT, "models", "IdSequence.tla")],
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "SYMMETRY is not supported" in r.stderr
+    r = subprocess.run([exe, os.path.join(ROOT, "models", "AsyncIsr.tla"), "-config",
+                        os.path.join(ROOT, "models", "IdSequence.cfg")], capture_output=True, text=True)
+    assert r.returncode == 2 and "no lowered model" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, os.path.join(ROOT, "models", "IdSequence.tla"), "-deadlock"],
+                           capture_output=True, text=True)
+        assert r.returncode == 3 and "no CPU fallback" in r.stderr  # fails loudly without a GPU

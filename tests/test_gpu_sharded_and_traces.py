@@ -166,3 +166,25 @@ def test_rccl_single_rank_process_group_matches_oracle():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_native_cli_matches_python_cli(capsys):
+    """The C++ front end (kafka_specification_amd/tlc) over the same C ABI prints the same verdict,
+    counts and trace states as the Python one."""
+    import subprocess
+    from kafka_specification_amd import tlc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "kafka_specification_amd", "tlc")
+    args = [os.path.join(root, "models", "Kip101.tla"), "-table", "4194304", "-frontier", "1048576"]
+    rc_py = tlc.main(args)
+    out_py = capsys.readouterr().out
+    r = subprocess.run([exe] + args, capture_output=True, text=True)
+    assert r.returncode == rc_py == 12
+
+    def keep(text):
+        return [l for l in text.splitlines() if l.startswith(("Error:", "State ", "/\\ ")) or "states generated," in l
+                or l.startswith("The depth")]
+    assert keep(r.stdout) == keep(out_py)
+    r = subprocess.run([exe, os.path.join(root, "models", "FiniteReplicatedLog.tla"), "-table", "1048576",
+                        "-frontier", "262144"], capture_output=True, text=True)
+    assert r.returncode == 0 and "1190091 states generated, 116281 distinct states found, 0 states left on queue." in r.stdout
