@@ -7,19 +7,20 @@
 // hiprtc), so every bit offset, loop bound and action-instance index below is a compile-time
 // constant and a packed state lives in W 64-bit registers per lane.
 //
-// Kernel shape (k_expand): one wavefront lane per frontier state.
-//   * coalesced loads of the SoA frontier planes (plane k, state i at fin[k*stride+i]);
-//   * the action instances of `Next` (every binding of the specs' \E over replicas /
-//     requests) are walked in a wave-uniform loop; a scalar binary dispatch jumps to the
-//     statically specialised guard+effect of instance i, so lanes never diverge on *which*
-//     action they evaluate, only on whether it is enabled;
-//   * enabled successors are compacted with __ballot + mbcnt prefix ranks into a per-wave
-//     LDS ring (SoA, conflict-free), which write-combines them until 64 are queued;
+// Kernel shape (k_expand): one wavefront lane per frontier state (DESIGN.md §4).
+//   * coalesced loads of the SoA frontier planes (plane k, state i at fin[k*stride+i]); every
+//     field is extracted once; the invariants of the state being expanded are checked here;
+//   * pass 1: the guards of all action instances of `Next` (every binding of the specs' \E over
+//     replicas / requests) in one straight-line VALU-domain block -> per-lane "enabled" bitset;
+//   * pass 2: a wave-uniform walk over the instances; a scalar binary dispatch jumps to the
+//     statically specialised effect of each instance some lane enabled, so lanes never diverge
+//     on *which* action they apply; enabled successors are compacted with __ballot + mbcnt
+//     prefix ranks into a per-wave LDS ring (SoA, conflict-free): the write-combining stage;
 //   * a flush drains exactly 64 successors, one per lane, so the random HBM probes of the
 //     fingerprint table always run with a full wave of independent requests in flight:
 //     64-bit mix hash -> open-addressed linear probe -> atomicCAS(0 -> fp) claim;
-//   * winners check the invariants and append the state to the next frontier through one
-//     wave-aggregated atomicAdd, written as coalesced SoA planes.
+//   * winners wait in a second LDS ring and are appended to the next frontier 64 at a time:
+//     one atomicAdd on a per-segment counter and W fully coalesced 512-byte plane stores.
 // The seen-set replaces tlc2.tool.fp.FPSet, the frontier arrays replace
 // tlc2.tool.queue.StateQueue and this loop replaces tlc2.tool.Worker.run [TLC-recall; TLC is
 // not part of /root/reference].
