@@ -112,15 +112,15 @@ struct KmcArgs {
     u64* pred;         // optional: predecessor fingerprint per table slot (trace reconstruction)
     KmcLevelCtl* ctl;
     u64 seed;
-    u64* send;         // SHARDED: [shard][KMC_SEGS][send_cap] AoS records of W+1 words (state, parent fp);
+    u64* send;         // SHARDED: [shard][KMC_SEGS][send_cap] AoS records of rec_words words (state[, parent fp]);
     u64 send_cap;      //   block b fills sub-buffer b % KMC_SEGS.  ENUM: one list of W+2-word records (state, fp, kind)
-    const u64* recv;   // k_insert input: AoS records of W+1 words
+    const u64* recv;   // k_insert input: AoS records of rec_words words
     u32 inv_mask;
     u32 mode;
     u32 flags;
     u32 nshards;
     u32 shard;         // this handle's shard id (SHARDED mode keeps its own successors local)
-    u32 pad_;
+    u32 rec_words;     // exchange record size in words: W, or W+1 when predecessor fingerprints travel (trace)
 };
 
 // ----------------------------------------------------------------------------------------
@@ -931,10 +931,10 @@ template <class M> struct KmcSink {
                 if (mine) {
                     const u64 pos = base + kmc_rank_in(m);
                     if (pos < a.send_cap) {
-                        u64* rec = a.send + (((u64)d * KMC_SEGS + sub) * a.send_cap + pos) * (u64)(W + 1);
+                        u64* rec = a.send + (((u64)d * KMC_SEGS + sub) * a.send_cap + pos) * (u64)a.rec_words;
 #pragma unroll
                         for (int k = 0; k < W; ++k) rec[k] = t[k];
-                        rec[W] = meta;
+                        if (a.rec_words > (u32)W) rec[W] = meta;
                     } else {
                         atomicOr(&a.ctl->err, KMC_ERR_SEND_FULL);
                     }
@@ -1162,8 +1162,8 @@ template <class M> KMC_DEV void kmc_insert_body(const KmcArgs& a) {
         const bool valid = idx < n;
         u64 t[W];
 #pragma unroll
-        for (int k = 0; k < W; ++k) t[k] = valid ? a.recv[idx * (u64)(W + 1) + k] : 0ull;
-        const u64 meta = valid ? a.recv[idx * (u64)(W + 1) + W] : 0ull;
+        for (int k = 0; k < W; ++k) t[k] = valid ? a.recv[idx * (u64)a.rec_words + k] : 0ull;
+        const u64 meta = (valid && a.rec_words > (u32)W) ? a.recv[idx * (u64)a.rec_words + W] : 0ull;
         KmcArgs b = a;
         b.mode = KMC_MODE_LOCAL;
         KmcSink<M>::process(b, out, valid, t, meta);

@@ -252,6 +252,7 @@ struct kmc_handle {
     hipFunction_t f_expand = nullptr, f_insert = nullptr, f_init = nullptr, f_find = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int rec_words = 0;  // exchange / insert record size: W, +1 when predecessor fingerprints are kept
     int n_cus = 256;
     int blocks_per_cu = 4;  // k_expand residency, from the occupancy query at open
     u64 *table = nullptr, *pred = nullptr, *table2 = nullptr;
@@ -310,6 +311,7 @@ KmcArgs base_args(kmc_handle* h, int ctl_slot) {
     a.flags = h->cfg.keep_trace ? KMC_FLAG_TRACE : 0u;
     a.nshards = (uint32_t)h->cfg.n_shards;
     a.shard = (uint32_t)h->cfg.shard_id;
+    a.rec_words = (uint32_t)h->rec_words;
     a.fin_stride = a.fout_stride = h->fcap;
     a.seg_cap = h->seg_cap;
     for (int sg = 0; sg < KMC_SEGS; ++sg) a.seg_count[sg] = h->seg_n[sg];
@@ -549,6 +551,7 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
         return get_code_object(h->cfg, "gfx950", &dummy, &name);  // produces the KMC_E_ARG message
     }
     h->W = h->lay.W;
+    h->rec_words = h->W + (cfg->keep_trace ? 1 : 0);
     if (cfg->device == -1) return KMC_OK;  // host-only handle: pack/unpack/fingerprint, no device work
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -614,10 +617,10 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     HIP_TRY(hipMalloc(&h->enum_out, h->enum_cap * (h->W + 2) * 8ull));
     if (h->cfg.n_shards > 1) {
         uint64_t scap = cfg->send_capacity;
-        if (!scap) scap = (uint64_t)(budget * 0.16) / (8ull * (h->W + 1) * h->cfg.n_shards * KMC_SEGS);
+        if (!scap) scap = (uint64_t)(budget * 0.16) / (8ull * h->rec_words * h->cfg.n_shards * KMC_SEGS);
         if (scap < 64) scap = 64;
         h->send_cap = scap;  // records per (destination, sub-buffer)
-        if (hipMalloc(&h->send, scap * (h->W + 1) * 8ull * h->cfg.n_shards * KMC_SEGS) != hipSuccess)
+        if (hipMalloc(&h->send, scap * h->rec_words * 8ull * h->cfg.n_shards * KMC_SEGS) != hipSuccess)
             return fail(KMC_E_NOMEM, "cannot allocate send buffers");
     }
     return KMC_OK;
@@ -1084,8 +1087,8 @@ int kmc_step_set_send_buffer(kmc_handle* h, void* dev_ptr, uint64_t records_per_
 int kmc_step_send_buffer(kmc_handle* h, int32_t dst, int32_t sub, void** dev_ptr, uint64_t* record_words) {
     if (!h || !h->send || dst < 0 || dst >= h->cfg.n_shards || sub < 0 || sub >= KMC_SEGS)
         return fail(KMC_E_ARG, "bad destination / sub-buffer");
-    *dev_ptr = h->send + ((uint64_t)dst * KMC_SEGS + sub) * h->send_cap * (h->W + 1);
-    *record_words = h->W + 1;
+    *dev_ptr = h->send + ((uint64_t)dst * KMC_SEGS + sub) * h->send_cap * h->rec_words;
+    *record_words = h->rec_words;
     return KMC_OK;
 }
 

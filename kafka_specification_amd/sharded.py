@@ -4,8 +4,8 @@ one process per GPU) and every BFS level exchanges successor states with one all
     owner(state) = (fingerprint >> 40) % P            (csrc/kmc_device.h: kmc_owner)
 
 Per level, on every shard:  expand the local frontier, bucketing each successor into the send
-area of its owner (k_expand, mode SHARDED)  ->  all-to-all-v of packed states (W+1 words: the
-state and its predecessor fingerprint; the owner recomputes the fingerprint because it must
+area of its owner (k_expand, mode SHARDED)  ->  all-to-all-v of packed states (W words, plus the
+predecessor fingerprint when traces are kept; the owner recomputes the fingerprint because it must
 later expand the state)  ->  the owner probes/inserts what it received, checks invariants on
 the winners and appends them to its next frontier (k_insert)  ->  all-reduce of a small
 statistics vector (new states, generated, violations, deadlocks, error flags) decides
@@ -47,7 +47,7 @@ class HipShardEngine:
         self.mc = ModelChecker(self.cfg)
         self.lib = nat.lib()
         self.W = self.mc.state_words
-        self.record_words = self.W + 1
+        self.record_words = self.W + (1 if cfg.keep_trace else 0)  # the predecessor fingerprint travels only for traces
         # the send area belongs to torch so that slices of it can be handed to the collective:
         # [destination][sub-buffer][record]; block b of k_expand fills sub-buffer b % KMC_SEND_SUBS
         subs = nat.KMC_SEND_SUBS
