@@ -81,15 +81,24 @@ typedef unsigned int u32;
 #define KMC_FLAG_DRY_RAND 256u  // tuning: DRY mode does one load from an uncorrelated random table slot
 #define KMC_FLAG_META 2u  // the ring carries a meta plane (predecessor fp for traces / kind for ENUM)
 
+// A counter alone on its 128-byte line.  Device-scope atomics serialise per cache line at the
+// memory side (~90 M/s): eight "separate" 8-byte append counters packed into one 64-byte line were
+// still ONE hot spot — adjacent BFS levels of equal size ran 0.24 vs 0.18 ns/state depending only
+// on how the two control-block slots happened to straddle a line boundary.
+struct alignas(128) KmcCounterLine {
+    u64 v;
+    u64 pad_[15];
+};
+
 // One per BFS level; the host zeroes it before the level runs and reads it back after.
-struct KmcLevelCtl {
-    u64 next_count[KMC_SEGS];        // states appended to each segment of the next frontier
+struct alignas(128) KmcLevelCtl {
+    KmcCounterLine next_count[KMC_SEGS];  // states appended to each segment of the next frontier
+    KmcCounterLine send_count[KMC_MAX_SHARDS][KMC_SEGS];  // SHARDED: records bucketed per (destination, sub-buffer)
     u64 generated[KMC_MAX_KINDS];    // successors generated per action kind (Next disjunct)
     u64 viol_count[4];               // states of the EXPANDED level violating invariant k
     u64 viol_fp_inv[4];              // max over violators of ~fp  (=> min fp), 0 = none
     u64 deadlock_count;              // expanded states without any successor
     u64 deadlock_fp_inv;
-    u64 send_count[KMC_MAX_SHARDS][KMC_SEGS];  // SHARDED: records bucketed per (destination, sub-buffer)
     u64 enum_count;                  // ENUM: records written
     u64 inserted;                    // table claims (== next_count unless the frontier overflowed)
     u64 prof[8];                     // KMC_PROFILE: summed per-wave s_memtime ticks per phase (tuning aid)
@@ -326,11 +335,24 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
     static constexpr u32 MEr = (1u << Y.BEr) - 1;    // record.epoch
     static constexpr u32 FULL = (1u << N) - 1;
 
+    // A lazy view over the packed state: fields are re-extracted on demand (one or two VALU ops
+    // with compile-time offsets) instead of living in ~35 registers across the whole instance
+    // loop — the kernel is bound by waves per SIMD, not by VALU work.
     struct Pre {
-        u32 end[N], hw[N], ep1[N], ldr1[N], isr[N];
-        LogT logv[N];
-        u32 nextRec, nextEp, qep1, qldr1, qisr;
-        u32 rldr1[E + 1], risr[E + 1];
+        const u64* w;  // the packed state words (the caller's registers)
+        KMC_DEV u32 end(int r) const { return (u32)kmc_getbits(w, Y.end_off[r], Y.BO); }
+        KMC_DEV u32 hw(int r) const { return (u32)kmc_getbits(w, Y.hw_off[r], Y.BO); }
+        KMC_DEV u32 ep1(int r) const { return (u32)kmc_getbits(w, Y.ep_off[r], Y.BE); }
+        KMC_DEV u32 ldr1(int r) const { return (u32)kmc_getbits(w, Y.ldr_off[r], Y.BL); }
+        KMC_DEV u32 isr(int r) const { return (u32)kmc_getbits(w, Y.isr_off[r], Y.BI); }
+        KMC_DEV LogT logv(int r) const { return (LogT)kmc_getbits(w, Y.log_off[r], Y.BR * L); }
+        KMC_DEV u32 nextRec() const { return (u32)kmc_getbits(w, Y.nextrec_off, Y.BNR); }
+        KMC_DEV u32 nextEp() const { return (u32)kmc_getbits(w, Y.nextep_off, Y.BE); }
+        KMC_DEV u32 qep1() const { return (u32)kmc_getbits(w, Y.qep_off, Y.BE); }
+        KMC_DEV u32 qldr1() const { return (u32)kmc_getbits(w, Y.qldr_off, Y.BL); }
+        KMC_DEV u32 qisr() const { return (u32)kmc_getbits(w, Y.qisr_off, Y.BI); }
+        KMC_DEV u32 rldr1(int e) const { return (u32)kmc_getbits(w, Y.reqldr_off[e], Y.BL); }
+        KMC_DEV u32 risr(int e) const { return (u32)kmc_getbits(w, Y.reqisr_off[e], Y.BI); }
         // shared sub-predicates of the guards, as opaque integers (see kmc_and)
         u32 one;    // 1
         u32 epok;   // nextLeaderEpoch <= MaxLeaderEpoch            (LeaderEpochSeq!NextId, IdSequence.tla:31)
@@ -347,27 +369,9 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
 
     static KMC_DEV Pre extract(const u64* s) {
         Pre p;
-        kmc_static_for<0, N>([&](auto RR) {
-            constexpr int r = decltype(RR)::value;
-            p.logv[r] = (LogT)kmc_getbits(s, Y.log_off[r], Y.BR * L);
-            p.end[r] = (u32)kmc_getbits(s, Y.end_off[r], Y.BO);
-            p.hw[r] = (u32)kmc_getbits(s, Y.hw_off[r], Y.BO);
-            p.ep1[r] = (u32)kmc_getbits(s, Y.ep_off[r], Y.BE);
-            p.ldr1[r] = (u32)kmc_getbits(s, Y.ldr_off[r], Y.BL);
-            p.isr[r] = (u32)kmc_getbits(s, Y.isr_off[r], Y.BI);
-        });
-        p.nextRec = (u32)kmc_getbits(s, Y.nextrec_off, Y.BNR);
-        p.nextEp = (u32)kmc_getbits(s, Y.nextep_off, Y.BE);
-        p.qep1 = (u32)kmc_getbits(s, Y.qep_off, Y.BE);
-        p.qldr1 = (u32)kmc_getbits(s, Y.qldr_off, Y.BL);
-        p.qisr = (u32)kmc_getbits(s, Y.qisr_off, Y.BI);
-        kmc_static_for<0, E + 1>([&](auto EE) {
-            constexpr int e = decltype(EE)::value;
-            p.rldr1[e] = (u32)kmc_getbits(s, Y.reqldr_off[e], Y.BL);
-            p.risr[e] = (u32)kmc_getbits(s, Y.reqisr_off[e], Y.BI);
-        });
+        p.w = s;
         p.one = 1u;
-        p.epok = p.nextEp <= (u32)E ? 1u : 0u;
+        p.epok = p.nextEp() <= (u32)E ? 1u : 0u;
         p.pm = 0; p.tm = 0; p.hm = 0; p.fm = 0;
         kmc_static_for<0, N>([&](auto LL) {
             constexpr int l = decltype(LL)::value;
@@ -386,15 +390,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
         return p;
     }
 
-    static KMC_DEV void launder(Pre& p) {
-#pragma unroll
-        for (int r = 0; r < N; ++r) {
-            kmc_launder(p.end[r]); kmc_launder(p.hw[r]); kmc_launder(p.ep1[r]); kmc_launder(p.ldr1[r]);
-            kmc_launder(p.isr[r]); kmc_launder(p.logv[r]);
-        }
-        kmc_launder(p.nextRec); kmc_launder(p.nextEp); kmc_launder(p.qep1); kmc_launder(p.qldr1); kmc_launder(p.qisr);
-#pragma unroll
-        for (int e = 0; e <= E; ++e) { kmc_launder(p.rldr1[e]); kmc_launder(p.risr[e]); }
+    static KMC_DEV void launder(Pre& p) {  // (the state words themselves are laundered by the caller)
         kmc_launder(p.one); kmc_launder(p.epok); kmc_launder(p.pm); kmc_launder(p.tm); kmc_launder(p.hm);
         kmc_launder(p.fm);
     }
@@ -408,29 +404,29 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
     }
     // TruncateTo(replica, off) for off <= end (FiniteReplicatedLog.tla:105-109)
     template <int r> static KMC_DEV void truncate(u64* t, const Pre& p, u32 off) {
-        kmc_setbits(t, Y.log_off[r], Y.BR * L, p.logv[r] & keep_below(off));
+        kmc_setbits(t, Y.log_off[r], Y.BR * L, p.logv(r) & keep_below(off));
         kmc_setbits(t, Y.end_off[r], Y.BO, off);
     }
 
     // ---- predicates (KafkaReplication.tla:126-131) ----
-    template <int r> static KMC_DEV bool presumes(const Pre& p) { return p.ldr1[r] == (u32)(r + 1); }
+    template <int r> static KMC_DEV bool presumes(const Pre& p) { return p.ldr1(r) == (u32)(r + 1); }
     template <int l> static KMC_DEV bool is_true_leader(const Pre& p) {
-        return p.qldr1 == (u32)(l + 1) && presumes<l>(p) && p.ep1[l] == p.qep1;
+        return p.qldr1() == (u32)(l + 1) && presumes<l>(p) && p.ep1(l) == p.qep1();
     }
 
     // ControllerUpdateIsr(newLeader, newIsr) (:138-145); the guard nextLeaderEpoch <= E is the caller's
     static KMC_DEV void controller_update(u64* t, const Pre& p, u32 newLdr1, u32 newIsr) {
-        kmc_setbits(t, Y.qep_off, Y.BE, p.nextEp + 1);
+        kmc_setbits(t, Y.qep_off, Y.BE, p.nextEp() + 1);
         kmc_setbits(t, Y.qldr_off, Y.BL, newLdr1);
         kmc_setbits(t, Y.qisr_off, Y.BI, newIsr);
         kmc_static_for<0, E + 1>([&](auto EE) {
             constexpr int e = decltype(EE)::value;
-            if (p.nextEp == (u32)e) {
+            if (p.nextEp() == (u32)e) {
                 kmc_setbits(t, Y.reqldr_off[e], Y.BL, newLdr1);
                 kmc_setbits(t, Y.reqisr_off[e], Y.BI, newIsr);
             }
         });
-        kmc_setbits(t, Y.nextep_off, Y.BE, p.nextEp + 1);
+        kmc_setbits(t, Y.nextep_off, Y.BE, p.nextEp() + 1);
     }
     // QuorumUpdateLeaderAndIsr(leader, newIsr) effect (:213-217)
     template <int l> static KMC_DEV void quorum_update(u64* t, u32 newIsr) {
@@ -440,36 +436,36 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
     // IsFollowerCaughtUp(leader, follower, endOffset) (:219-225): the \E record is satisfied by
     // the leader's own record at endOffset-1 whenever that offset is below its end.
     template <int l, int f> static KMC_DEV bool caught_up(const Pre& p, u32 endOffset) {
-        return p.ldr1[f] == (u32)(l + 1) && endOffset <= p.end[l] && endOffset <= p.end[f];
+        return p.ldr1(f) == (u32)(l + 1) && endOffset <= p.end(l) && endOffset <= p.end(f);
     }
     // Kip320.tla:39-42
     template <int l, int f> static KMC_DEV bool following_epoch(const Pre& p) {
-        return presumes<l>(p) && p.ldr1[f] == (u32)(l + 1) && p.ep1[f] == p.ep1[l];
+        return presumes<l>(p) && p.ldr1(f) == (u32)(l + 1) && p.ep1(f) == p.ep1(l);
     }
     // HasHighWatermarkReachedCurrentEpoch (Kip320.tla:87-92, Kip320FirstTry.tla:122-127)
     template <int l> static KMC_DEV bool hw_reached_epoch(const Pre& p) {
-        return p.hw[l] == p.end[l] ||
-               (p.hw[l] < p.end[l] && rec_epoch(rec_at(p.logv[l], p.hw[l])) + 1 == p.ep1[l]);
+        return p.hw(l) == p.end(l) ||
+               (p.hw(l) < p.end(l) && rec_epoch(rec_at(p.logv(l), p.hw(l))) + 1 == p.ep1(l));
     }
     // IsFollowerCaughtUpToLeaderEpoch (Kip320FirstTry.tla:49-57)
     template <int l, int f> static KMC_DEV bool caught_up_epoch(const Pre& p, u32 endOffset) {
-        if (!(presumes<l>(p) && p.ldr1[f] == (u32)(l + 1))) return false;
+        if (!(presumes<l>(p) && p.ldr1(f) == (u32)(l + 1))) return false;
         if (endOffset == 0) return true;
         const u32 o = endOffset - 1;
-        return o < p.end[l] && o < p.end[f] &&
-               rec_epoch(rec_at(p.logv[f], o)) == rec_epoch(rec_at(p.logv[l], o));
+        return o < p.end(l) && o < p.end(f) &&
+               rec_epoch(rec_at(p.logv(f), o)) == rec_epoch(rec_at(p.logv(l), o));
     }
     // FollowerNeedsTruncation (Kip320FirstTry.tla:64-69)
     template <int f, int l> static KMC_DEV bool needs_truncation(const Pre& p) {
-        if (p.end[f] > p.end[l]) return true;
-        if (p.end[f] == 0) return false;
-        const u32 o = p.end[f] - 1;
-        return o < p.end[l] && rec_epoch(rec_at(p.logv[l], o)) != rec_epoch(rec_at(p.logv[f], o));
+        if (p.end(f) > p.end(l)) return true;
+        if (p.end(f) == 0) return false;
+        const u32 o = p.end(f) - 1;
+        return o < p.end(l) && rec_epoch(rec_at(p.logv(l), o)) != rec_epoch(rec_at(p.logv(f), o));
     }
     // FirstNonMatchingOffsetFromTail(leader, follower) (Kip279.tla:27-45)
     template <int l, int f> static KMC_DEV u32 first_non_matching(const Pre& p) {
-        const LogT x = p.logv[l] ^ p.logv[f];
-        const u32 lim = kmc_min(p.end[l], p.end[f]);  // leader empty => no match => 0
+        const LogT x = p.logv(l) ^ p.logv(f);
+        const u32 lim = kmc_min(p.end(l), p.end(f));  // leader empty => no match => 0
         u32 best = 0;
         kmc_static_for<0, L>([&](auto O) {
             constexpr int o = decltype(O)::value;
@@ -479,15 +475,15 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
     }
     // LookupOffsetForEpoch(leader, follower, epoch) (Kip101.tla:27-39)
     template <int l, int f> static KMC_DEV u32 lookup_offset_for_epoch(const Pre& p, u32 epoch) {
-        const u32 el = p.end[l];
-        u32 first_larger = p.hw[f];  // offsetWithLargerEpochs = {} -> follower hw
+        const u32 el = p.end(l);
+        u32 first_larger = p.hw(f);  // offsetWithLargerEpochs = {} -> follower hw
         bool found = false;
         kmc_static_for<0, L>([&](auto O) {
             constexpr int o = decltype(O)::value;
-            if (!found && (u32)o < el && rec_epoch(rec_at(p.logv[l], o)) > epoch) { first_larger = o; found = true; }
+            if (!found && (u32)o < el && rec_epoch(rec_at(p.logv(l), o)) > epoch) { first_larger = o; found = true; }
         });
-        if (el == 0) return p.hw[f];
-        if (rec_epoch(rec_at(p.logv[l], el - 1)) == epoch) return el;
+        if (el == 0) return p.hw(f);
+        if (rec_epoch(rec_at(p.logv(l), el - 1)) == epoch) return el;
         return first_larger;
     }
 
@@ -502,104 +498,104 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             // ControllerElectLeader (KafkaReplication.tla:176-179)
             constexpr int r = I - B0;
             kind = 0;
-            controller_update(t, p, r + 1, p.qisr);
-            u32 g = p.epok & kmc_bit(p.qisr, r);
-            g = kmc_and(g, p.qldr1 != (u32)(r + 1));
+            controller_update(t, p, r + 1, p.qisr());
+            u32 g = p.epok & kmc_bit(p.qisr(), r);
+            g = kmc_and(g, p.qldr1() != (u32)(r + 1));
             return g;
         } else if constexpr (I < B2) {
             // ControllerShrinkIsr (:158-168), three mutually exclusive cases per replica
             constexpr int r = I - B1;
             kind = 1;
-            const bool is_ldr = p.qldr1 == (u32)(r + 1);
-            const bool only = p.qisr == (1u << r);
-            const u32 newLdr1 = is_ldr ? 0u : p.qldr1;
-            const u32 newIsr = (is_ldr && only) ? p.qisr : (p.qisr & ~(1u << r));
+            const bool is_ldr = p.qldr1() == (u32)(r + 1);
+            const bool only = p.qisr() == (1u << r);
+            const u32 newLdr1 = is_ldr ? 0u : p.qldr1();
+            const u32 newIsr = (is_ldr && only) ? p.qisr() : (p.qisr() & ~(1u << r));
             controller_update(t, p, newLdr1, newIsr);
-            return kmc_and(p.epok, is_ldr || (p.qisr >> r & 1u));
+            return kmc_and(p.epok, is_ldr || (p.qisr() >> r & 1u));
         } else if constexpr (I < B3) {
             // BecomeLeader (:186-195): request e names leader l
             constexpr int J = I - B2, e = J / N, l = J % N;
             kind = 2;
             kmc_setbits(t, Y.ep_off[l], Y.BE, e + 1);
             kmc_setbits(t, Y.ldr_off[l], Y.BL, l + 1);
-            kmc_setbits(t, Y.isr_off[l], Y.BI, p.risr[e]);
-            u32 g = kmc_and(p.one, p.rldr1[e] == (u32)(l + 1));
-            g = kmc_and(g, (u32)e < p.nextEp);
-            g = kmc_and(g, (u32)(e + 1) > p.ep1[l]);
+            kmc_setbits(t, Y.isr_off[l], Y.BI, p.risr(e));
+            u32 g = kmc_and(p.one, p.rldr1(e) == (u32)(l + 1));
+            g = kmc_and(g, (u32)e < p.nextEp());
+            g = kmc_and(g, (u32)(e + 1) > p.ep1(l));
             return g;
         } else if constexpr (I < B4) {
             constexpr int J = I - B3, l = J / N, r = J % N;
             kind = 3;
-            const u32 isr = p.isr[l];
+            const u32 isr = p.isr(l);
             quorum_update<l>(t, isr | (1u << r));
             u32 g = kmc_bit(p.tm, l) & kmc_bit(~isr, r);
             if constexpr (K320) {  // FencedLeaderExpandIsr (Kip320.tla:110-117)
                 g &= kmc_bit64(p.fm, l * N + r) & kmc_bit(p.hm, l);
-                g = kmc_and(g, p.hw[l] <= p.end[r]);  // HasFollowerReachedHighWatermark :94-98
+                g = kmc_and(g, p.hw(l) <= p.end(r));  // HasFollowerReachedHighWatermark :94-98
             } else if constexpr (FIRST) {  // LeaderExpandIsrBetterFencing (Kip320FirstTry.tla:134-141)
                 g &= kmc_bit(p.hm, l);
-                g = kmc_and(g, caught_up_epoch<l, r>(p, p.hw[l]));
+                g = kmc_and(g, caught_up_epoch<l, r>(p, p.hw(l)));
             } else {  // LeaderExpandIsr (KafkaReplication.tla:248-254); IsFollowerCaughtUp :219-225
-                g = kmc_and(g, p.ldr1[r] == (u32)(l + 1));
-                g = kmc_and(g, p.hw[l] <= p.end[l]);
-                g = kmc_and(g, p.hw[l] <= p.end[r]);
+                g = kmc_and(g, p.ldr1(r) == (u32)(l + 1));
+                g = kmc_and(g, p.hw(l) <= p.end(l));
+                g = kmc_and(g, p.hw(l) <= p.end(r));
             }
             return g;
         } else if constexpr (I < B5) {
             constexpr int J = I - B4, l = J / (N - 1), q = J % (N - 1), r = q + (q >= l);
             kind = 4;
-            const u32 isr = p.isr[l];
+            const u32 isr = p.isr(l);
             quorum_update<l>(t, isr & ~(1u << r));
             u32 g = kmc_bit(p.tm, l) & kmc_bit(isr, r);
             if constexpr (K320) {  // FencedLeaderShrinkIsr (Kip320.tla:78-85)
-                g = kmc_and(g, kmc_bit64(p.fm, l * N + r) == 0u || p.end[r] < p.end[l]);
+                g = kmc_and(g, kmc_bit64(p.fm, l * N + r) == 0u || p.end(r) < p.end(l));
             } else if constexpr (FIRST) {  // LeaderShrinkIsrBetterFencing (Kip320FirstTry.tla:114-120)
-                g = kmc_and(g, !caught_up_epoch<l, r>(p, p.end[l]));
+                g = kmc_and(g, !caught_up_epoch<l, r>(p, p.end(l)));
             } else {  // LeaderShrinkIsr (KafkaReplication.tla:233-239)
-                g = kmc_and(g, !caught_up<l, r>(p, p.end[l]));
+                g = kmc_and(g, !caught_up<l, r>(p, p.end(l)));
             }
             return g;
         } else if constexpr (I < B6) {
             // LeaderWrite (KafkaReplication.tla:202-207)
             constexpr int r = I - B5;
             kind = 5;
-            const u32 end = p.end[r];
-            const LogT rec = (LogT)(((p.nextRec + 1) << Y.BEr) | (p.ep1[r] - 1));
-            kmc_setbits(t, Y.log_off[r], Y.BR * L, (LogT)(p.logv[r] | (LogT)(rec << (end * Y.BR))));
+            const u32 end = p.end(r);
+            const LogT rec = (LogT)(((p.nextRec() + 1) << Y.BEr) | (p.ep1(r) - 1));
+            kmc_setbits(t, Y.log_off[r], Y.BR * L, (LogT)(p.logv(r) | (LogT)(rec << (end * Y.BR))));
             kmc_setbits(t, Y.end_off[r], Y.BO, end + 1);
-            kmc_setbits(t, Y.nextrec_off, Y.BNR, p.nextRec + 1);
+            kmc_setbits(t, Y.nextrec_off, Y.BNR, p.nextRec() + 1);
             u32 g = kmc_bit(p.pm, r);
-            g = kmc_and(g, p.nextRec <= (u32)(R - 1));
+            g = kmc_and(g, p.nextRec() <= (u32)(R - 1));
             g = kmc_and(g, end < (u32)L);
             return g;
         } else if constexpr (I < B7) {
             constexpr int l = I - B6;
             kind = 6;
-            const u32 hw = p.hw[l];
+            const u32 hw = p.hw(l);
             kmc_setbits(t, Y.hw_off[l], Y.BO, hw + 1);
             u32 g;
             if constexpr (K320) {  // FencedLeaderIncHighWatermark (Kip320.tla:63-70)
-                g = kmc_and(p.one, hw < p.end[l]);
+                g = kmc_and(p.one, hw < p.end(l));
                 kmc_static_for<0, N>([&](auto F) {
                     constexpr int f = decltype(F)::value;
                     // f \in isr  =>  IsFollowingLeaderEpoch(l, f) /\ HasOffset(f, hw)
-                    const u32 in = kmc_bit(p.isr[l], f);
+                    const u32 in = kmc_bit(p.isr(l), f);
                     g &= (in ^ 1u) | kmc_bit64(p.fm, l * N + f);
-                    g = kmc_and(g, in == 0u || hw < p.end[f]);
+                    g = kmc_and(g, in == 0u || hw < p.end(f));
                 });
             } else if constexpr (FIRST) {  // ImprovedLeaderIncHighWatermark (Kip320FirstTry.tla:90-97)
                 g = kmc_bit(p.pm, l);
-                g = kmc_and(g, hw < p.end[l]);
+                g = kmc_and(g, hw < p.end(l));
                 kmc_static_for<0, N>([&](auto F) {
                     constexpr int f = decltype(F)::value;
-                    g = kmc_and(g, !(p.isr[l] >> f & 1u) || caught_up_epoch<l, f>(p, hw + 1));
+                    g = kmc_and(g, !(p.isr(l) >> f & 1u) || caught_up_epoch<l, f>(p, hw + 1));
                 });
             } else {  // LeaderIncHighWatermark (KafkaReplication.tla:264-271)
                 g = kmc_bit(p.pm, l);
                 g = kmc_and(g, hw <= (u32)(L - 1));
                 kmc_static_for<0, N>([&](auto F) {
                     constexpr int f = decltype(F)::value;
-                    g = kmc_and(g, !(p.isr[l] >> f & 1u) || (p.ldr1[f] == (u32)(l + 1) && hw < p.end[f]));
+                    g = kmc_and(g, !(p.isr(l) >> f & 1u) || (p.ldr1(f) == (u32)(l + 1) && hw < p.end(f)));
                 });
             }
             return g;
@@ -609,35 +605,35 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             constexpr int J = I - B7, pr = J / (E + 1), e = J % (E + 1);
             constexpr int l = pr / (N - 1), q = pr % (N - 1), r = q + (q >= l);
             kind = 7;
-            u32 g = kmc_and(p.one, p.rldr1[e] == (u32)(l + 1));
-            g = kmc_and(g, (u32)e < p.nextEp);
-            g = kmc_and(g, (u32)(e + 1) > p.ep1[r]);
+            u32 g = kmc_and(p.one, p.rldr1(e) == (u32)(l + 1));
+            g = kmc_and(g, (u32)e < p.nextEp());
+            g = kmc_and(g, (u32)(e + 1) > p.ep1(r));
             kmc_setbits(t, Y.ep_off[r], Y.BE, e + 1);
             kmc_setbits(t, Y.ldr_off[r], Y.BL, l + 1);
-            kmc_setbits(t, Y.isr_off[r], Y.BI, p.risr[e]);
+            kmc_setbits(t, Y.isr_off[r], Y.BI, p.risr(e));
             if constexpr (FIRST) {
                 // BecomeFollower (Kip320FirstTry.tla:148-157): no truncation, hw unchanged
             } else {
                 u32 off;
                 if constexpr (MODEL == KMC_MODEL_TRUNCATE_TO_HW) {
-                    off = p.hw[r];  // KafkaTruncateToHighWatermark.tla:29-31
+                    off = p.hw(r);  // KafkaTruncateToHighWatermark.tla:29-31
                 } else if constexpr (MODEL == KMC_MODEL_KIP101) {
                     // BecomeFollowerTruncateKip101 (Kip101.tla:41-47)
-                    const u32 er = p.end[r];
-                    const u32 last_epoch = rec_epoch(rec_at(p.logv[r], er == 0 ? 0 : er - 1));
+                    const u32 er = p.end(r);
+                    const u32 last_epoch = rec_epoch(rec_at(p.logv(r), er == 0 ? 0 : er - 1));
                     off = er == 0 ? 0u : lookup_offset_for_epoch<l, r>(p, last_epoch);
                 } else {
                     // BecomeFollowerTruncateKip279 (Kip279.tla:47-51) / FencedBecomeFollowerAndTruncate (Kip320.tla:134-148)
                     off = first_non_matching<l, r>(p);
-                    if constexpr (MODEL == KMC_MODEL_KIP279) extra = p.end[r] == 0 ? 1u : 0u;  // both disjuncts fire
+                    if constexpr (MODEL == KMC_MODEL_KIP279) extra = p.end(r) == 0 ? 1u : 0u;  // both disjuncts fire
                     if constexpr (K320) {
                         g &= kmc_bit(p.pm, l);
-                        g = kmc_and(g, p.ep1[l] == (u32)(e + 1));
+                        g = kmc_and(g, p.ep1(l) == (u32)(e + 1));
                     }
                 }
-                g = kmc_and(g, off <= p.end[r]);  // TruncateTo is disabled, not clamped (FiniteReplicatedLog.tla:106)
+                g = kmc_and(g, off <= p.end(r));  // TruncateTo is disabled, not clamped (FiniteReplicatedLog.tla:106)
                 truncate<r>(t, p, off);
-                kmc_setbits(t, Y.hw_off[r], Y.BO, kmc_min(off, p.hw[r]));  // BecomeFollowerAndTruncateTo (:281-294)
+                kmc_setbits(t, Y.hw_off[r], Y.BO, kmc_min(off, p.hw(r)));  // BecomeFollowerAndTruncateTo (:281-294)
             }
             return g;
         } else if constexpr (I < B9) {
@@ -645,18 +641,18 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             // Kip320.tla:49-56, Kip320FirstTry.tla:103-111)
             constexpr int J = I - B8, l = J / (N - 1), q = J % (N - 1), f = q + (q >= l);
             kind = 8;
-            const u32 ef = p.end[f];
-            const LogT rec = (LogT)rec_at(p.logv[l], ef);
-            kmc_setbits(t, Y.log_off[f], Y.BR * L, (LogT)(p.logv[f] | (LogT)(rec << (ef * Y.BR))));
+            const u32 ef = p.end(f);
+            const LogT rec = (LogT)rec_at(p.logv(l), ef);
+            kmc_setbits(t, Y.log_off[f], Y.BR * L, (LogT)(p.logv(f) | (LogT)(rec << (ef * Y.BR))));
             kmc_setbits(t, Y.end_off[f], Y.BO, ef + 1);
-            kmc_setbits(t, Y.hw_off[f], Y.BO, kmc_min(p.hw[l], ef + 1));
-            u32 g = kmc_and(p.one, ef < p.end[l]);
+            kmc_setbits(t, Y.hw_off[f], Y.BO, kmc_min(p.hw(l), ef + 1));
+            u32 g = kmc_and(p.one, ef < p.end(l));
             g = kmc_and(g, ef < (u32)L);
             if constexpr (K320) g &= kmc_bit64(p.fm, l * N + f);
             else if constexpr (FIRST) g = kmc_and(g, caught_up_epoch<l, f>(p, ef));
             else {
                 g &= kmc_bit(p.pm, l);
-                g = kmc_and(g, p.ldr1[f] == (u32)(l + 1));
+                g = kmc_and(g, p.ldr1(f) == (u32)(l + 1));
             }
             return g;
         } else {
@@ -665,11 +661,11 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             kind = 9;
             const u32 off = first_non_matching<l, f>(p);
             truncate<f>(t, p, off);
-            kmc_setbits(t, Y.hw_off[f], Y.BO, kmc_min(off, p.hw[f]));
+            kmc_setbits(t, Y.hw_off[f], Y.BO, kmc_min(off, p.hw(f)));
             u32 g = kmc_bit(p.pm, l);
-            g = kmc_and(g, p.ldr1[f] == (u32)(l + 1));
+            g = kmc_and(g, p.ldr1(f) == (u32)(l + 1));
             g = kmc_and(g, needs_truncation<f, l>(p));
-            g = kmc_and(g, off <= p.end[f]);
+            g = kmc_and(g, off <= p.end(f));
             return g;
         }
     }
@@ -681,21 +677,21 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
         if (inv_mask == 0) return 0;
         u32 bad = 0;
         if (inv_mask & 1u) {
-            bool ok = p.nextEp <= (u32)(E + 1) && p.nextRec <= (u32)R && p.qep1 <= (u32)(E + 1) && p.qldr1 <= (u32)N;
+            bool ok = p.nextEp() <= (u32)(E + 1) && p.nextRec() <= (u32)R && p.qep1() <= (u32)(E + 1) && p.qldr1() <= (u32)N;
             kmc_static_for<0, N>([&](auto RR) {
                 constexpr int r = decltype(RR)::value;
-                ok = ok && p.end[r] <= (u32)L && p.hw[r] <= (u32)L && p.ep1[r] <= (u32)(E + 1) && p.ldr1[r] <= (u32)N;
+                ok = ok && p.end(r) <= (u32)L && p.hw(r) <= (u32)L && p.ep1(r) <= (u32)(E + 1) && p.ldr1(r) <= (u32)N;
                 kmc_static_for<0, L>([&](auto O) {
                     constexpr int o = decltype(O)::value;
-                    const u32 c = rec_at(p.logv[r], o);
+                    const u32 c = rec_at(p.logv(r), o);
                     const u32 id1 = c >> Y.BEr;
                     const bool in_records = id1 >= 1 && id1 <= (u32)R && rec_epoch(c) <= (u32)E;
-                    ok = ok && ((u32)o < p.end[r] ? in_records : c == 0);
+                    ok = ok && ((u32)o < p.end(r) ? in_records : c == 0);
                 });
             });
             kmc_static_for<0, E + 1>([&](auto EE) {
                 constexpr int e = decltype(EE)::value;
-                if ((u32)e < p.nextEp) ok = ok && p.rldr1[e] <= (u32)N;
+                if ((u32)e < p.nextEp()) ok = ok && p.rldr1(e) <= (u32)N;
             });
             if (!ok) bad |= 1u;
         }
@@ -703,15 +699,15 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             bool weak = true, strong = true;
             kmc_static_for<0, N>([&](auto R1) {
                 constexpr int r1 = decltype(R1)::value;
-                const u32 hw = p.hw[r1];
+                const u32 hw = p.hw(r1);
                 if (presumes<r1>(p) && hw > 0) {
                     kmc_static_for<0, N>([&](auto R2) {
                         constexpr int r2 = decltype(R2)::value;
                         // \A offset < hw : \E record : HasEntry(r1,..) /\ HasEntry(r2,..)
-                        const bool same = hw <= p.end[r1] && hw <= p.end[r2] &&
-                                          ((p.logv[r1] ^ p.logv[r2]) & keep_below(hw)) == 0;
-                        if (p.isr[r1] >> r2 & 1u) weak = weak && same;
-                        if (p.qisr >> r2 & 1u) strong = strong && same;
+                        const bool same = hw <= p.end(r1) && hw <= p.end(r2) &&
+                                          ((p.logv(r1) ^ p.logv(r2)) & keep_below(hw)) == 0;
+                        if (p.isr(r1) >> r2 & 1u) weak = weak && same;
+                        if (p.qisr() >> r2 & 1u) strong = strong && same;
                     });
                 }
             });
@@ -719,7 +715,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             if ((inv_mask & 4u) && !strong) bad |= 4u;
         }
         if (inv_mask & 8u) {
-            const bool ok = p.qldr1 != 0 && (p.qisr >> (p.qldr1 - 1) & 1u);
+            const bool ok = p.qldr1() != 0 && (p.qisr() >> (p.qldr1() - 1) & 1u);
             if (!ok) bad |= 8u;
         }
         return bad;
@@ -746,7 +742,7 @@ template <int W> struct KmcStager {
         const u32 lane = kmc_lane();
         const u32 seg = blockIdx.x % KMC_SEGS;
         u64 base = 0;
-        if (lane == 0) base = atomicAdd(&a.ctl->next_count[seg], (u64)n);
+        if (lane == 0) base = atomicAdd(&a.ctl->next_count[seg].v, (u64)n);
         base = kmc_bcast64(base, 0);
         if (lane < n) {
             const u32 pos = (head + lane) & (KMC_QCAP - 1);
@@ -898,7 +894,7 @@ template <class M> struct KmcSink {
                 const u32 n = __popcll(m);
                 const u32 seg = blockIdx.x % KMC_SEGS;
                 u64 base = 0;
-                if ((int)kmc_lane() == leader) base = atomicAdd(&a.ctl->next_count[seg], (u64)n);
+                if ((int)kmc_lane() == leader) base = atomicAdd(&a.ctl->next_count[seg].v, (u64)n);
                 base = kmc_bcast64(base, leader) + kmc_rank_in(m);
                 const u64 idx = (u64)seg * a.seg_cap + base;
                 if (isnew) {
@@ -926,7 +922,7 @@ template <class M> struct KmcSink {
                 if (m == 0) continue;
                 const int leader = __builtin_ctzll(m);
                 u64 base = 0;
-                if ((int)kmc_lane() == leader) base = atomicAdd(&a.ctl->send_count[d][sub], (u64)__popcll(m));
+                if ((int)kmc_lane() == leader) base = atomicAdd(&a.ctl->send_count[d][sub].v, (u64)__popcll(m));
                 base = kmc_bcast64(base, leader);
                 if (mine) {
                     const u64 pos = base + kmc_rank_in(m);
@@ -1200,7 +1196,7 @@ template <class M> KMC_DEV void kmc_find_body(const KmcArgs& a) {
 }
 
 #ifndef KMC_MIN_WAVES
-#define KMC_MIN_WAVES 5   // __launch_bounds__ second argument for k_expand: minimum waves per SIMD
+#define KMC_MIN_WAVES 6   // __launch_bounds__ second argument for k_expand: minimum waves per SIMD (LDS admits 6 blocks/CU)
 #endif
 #define KMC_INSTANTIATE(NAME, ...)                                                                       \
     extern "C" __global__ __launch_bounds__(KMC_BLOCK, KMC_MIN_WAVES) void kmc_expand_##NAME(KmcArgs a) { \

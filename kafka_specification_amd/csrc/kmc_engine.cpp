@@ -346,7 +346,7 @@ int zero_ctl(kmc_handle* h, int slot) {
 uint64_t produced_segments(kmc_handle* h, const KmcLevelCtl& c, uint64_t seg[KMC_SEGS]) {
     uint64_t total = 0;
     for (int sg = 0; sg < KMC_SEGS; ++sg) {
-        seg[sg] = c.next_count[sg] < h->seg_cap ? c.next_count[sg] : h->seg_cap;
+        seg[sg] = c.next_count[sg].v < h->seg_cap ? c.next_count[sg].v : h->seg_cap;
         total += seg[sg];
     }
     return total;
@@ -1067,7 +1067,7 @@ int kmc_step_expand(kmc_handle* h, uint64_t* send_counts /* [KMC_MAX_SHARDS][KMC
     h->res.expand_launches++;
     for (int d = 0; d < KMC_MAX_SHARDS; ++d)
         for (int sb = 0; sb < KMC_SEGS; ++sb) {
-            uint64_t c = h->ctl_host->send_count[d][sb];
+            uint64_t c = h->ctl_host->send_count[d][sb].v;
             send_counts[d * KMC_SEGS + sb] = c < h->send_cap ? c : h->send_cap;
         }
     h->step_expanded = true;
