@@ -66,12 +66,12 @@ typedef unsigned int u32;
 #define KMC_T(var)
 #define KMC_TADD(slot, t0, t1)
 #endif
-#ifndef KMC_FLUSH2
-#define KMC_FLUSH2 0      // 1: drain 128 successors per flush, two independent probe chains per lane
-#endif                    //    (measured: no gain — the extra registers cost a wave per SIMD)
+#ifndef KMC_PREFETCH
+#define KMC_PREFETCH 0    // 1: request the next tile's state words while the current tile is processed (measured: no gain)
+#endif
 // per-wave successor ring capacity: < KMC_FLUSH_N queued before a push, <= 64 pushed at once
-#define KMC_FLUSH_N (KMC_FLUSH2 ? 128 : 64)
-#define KMC_RING (KMC_FLUSH2 ? 256 : 128)
+#define KMC_FLUSH_N 64
+#define KMC_RING 128
 #define KMC_FLAG_DRY_PROBE 4u  // tuning: DRY mode also walks the (read-only) probe sequence
 #define KMC_FLAG_DRY_INV 8u    // tuning: ... and evaluates the invariants on every successor
 #define KMC_FLAG_DRY_ATOM 16u  // tuning: ... and a no-op atomicCAS on ~35 % of the probed slots
@@ -822,41 +822,6 @@ template <class M> struct KmcSink {
             }
     }
 
-    // Two successors per lane.  In LOCAL mode the first probe round of both is issued
-    // back-to-back (two loads, then two CASes in flight) before either result is consumed:
-    // the kernel is bound by HBM latency, not bandwidth, so this doubles what one wave keeps
-    // in flight.
-    static KMC_DEV void process2(const KmcArgs& a, KmcStager<W>& out, bool valid0, const u64* t0, u64 meta0,
-                                 bool valid1, const u64* t1, u64 meta1) {
-        if (a.mode != KMC_MODE_LOCAL) {
-            process(a, out, valid0, t0, meta0);
-            process(a, out, valid1, t1, meta1);
-            return;
-        }
-        const u64 fp0 = kmc_fingerprint<W>(t0, a.seed), fp1 = kmc_fingerprint<W>(t1, a.seed);
-        u64 i0 = fp0 & a.table_mask, i1 = fp1 & a.table_mask;
-        bool done0 = !valid0, done1 = !valid1, new0 = false, new1 = false;
-        const u64 v0 = done0 ? ~0ull : a.table[i0];
-        const u64 v1 = done1 ? ~0ull : a.table[i1];
-        u64 w0 = v0, w1 = v1;
-        if (v0 == 0) w0 = atomicCAS(&a.table[i0], 0ull, fp0);
-        if (v1 == 0) w1 = atomicCAS(&a.table[i1], 0ull, fp1);
-        if (!done0) {
-            if (v0 == 0 && w0 == 0) { new0 = true; done0 = true; if (a.pred) a.pred[i0] = meta0; }
-            else if (w0 == fp0) done0 = true;
-            else i0 = (i0 + 1) & a.table_mask;
-        }
-        if (!done1) {
-            if (v1 == 0 && w1 == 0) { new1 = true; done1 = true; if (a.pred) a.pred[i1] = meta1; }
-            else if (w1 == fp1) done1 = true;
-            else i1 = (i1 + 1) & a.table_mask;
-        }
-        if (!done0) new0 = claim_from(a, fp0, i0, meta0);  // collision chain: the rare slow path
-        if (!done1) new1 = claim_from(a, fp1, i1, meta1);
-        out.push(a, new0, t0);
-        out.push(a, new1, t1);
-    }
-
     // Executed by the whole wave; lanes with valid=false only take part in the ballots.
     static KMC_DEV void process(const KmcArgs& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta) {
         const u64 fp = kmc_fingerprint<W>(t, a.seed);
@@ -988,16 +953,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #pragma unroll
         for (int k = 0; k < W; ++k) t0[k] = q[k * KMC_RING + pos0];
         const u64 meta0 = has_meta ? q[W * KMC_RING + pos0] : 0ull;
-#if KMC_FLUSH2
-        u64 t1[W];
-        const u32 pos1 = (head + 64 + lane) & (KMC_RING - 1);
-#pragma unroll
-        for (int k = 0; k < W; ++k) t1[k] = q[k * KMC_RING + pos1];
-        const u64 meta1 = has_meta ? q[W * KMC_RING + pos1] : 0ull;
-        KmcSink<M>::process2(a, out, lane < nv, t0, meta0, lane + 64 < nv, t1, meta1);
-#else
         KmcSink<M>::process(a, out, lane < nv, t0, meta0);
-#endif
         head = (head + nv) & (KMC_RING - 1);
         count -= nv;
     };
@@ -1014,17 +970,38 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     const u64 seg_tiles = (seg_n + 63) >> 6;
     // rotate the starting wave per segment so that short segments do not always land on the same waves
     const u32 first = (wave0 + nwaves - (u32)((sg * 977u) % nwaves)) % nwaves;
+#if KMC_PREFETCH
+    // software prefetch: the next tile's state words are requested before this tile is processed,
+    // so their HBM latency (a quarter of the compute-only time when exposed) hides under it
+    u64 s_next[W];
+    {
+        const u64 j0 = ((u64)first << 6) + lane;
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+            s_next[k] = (first < seg_tiles && j0 < seg_n) ? a.fin[(u64)k * a.fin_stride + seg_base + j0] : 0ull;
+    }
+#endif
 #pragma clang loop unroll(disable)
     for (u64 tile = first; tile < seg_tiles; tile += nwaves) {
         const u64 j = (tile << 6) + lane;
         const bool valid = j < seg_n;
-        const u64 idx = seg_base + j;
         KMC_T(tp0);
-        // (prefetching the next tile's words here was measured: no gain — the extra live registers
-        // spill under the 96-VGPR budget that 5 waves/SIMD need)
         u64 s[W];
+#if KMC_PREFETCH
+#pragma unroll
+        for (int k = 0; k < W; ++k) s[k] = s_next[k];
+        {
+            const u64 tn = tile + nwaves;
+            const u64 jn = (tn << 6) + lane;
+            const bool vn = tn < seg_tiles && jn < seg_n;
+#pragma unroll
+            for (int k = 0; k < W; ++k) s_next[k] = vn ? a.fin[(u64)k * a.fin_stride + seg_base + jn] : 0ull;
+        }
+#else
+        const u64 idx = seg_base + j;
 #pragma unroll
         for (int k = 0; k < W; ++k) s[k] = valid ? a.fin[(u64)k * a.fin_stride + idx] : 0ull;
+#endif
         const u64 parent = (a.flags & KMC_FLAG_TRACE) ? kmc_fingerprint<W>(s, a.seed) : 0ull;
         typename M::Pre pre = M::extract(s);
 
