@@ -101,3 +101,19 @@ def test_seed_independence():
     a, _ = gpu_run("Kip320", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1, hash_seed=1)
     b, _ = gpu_run("Kip320", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1, hash_seed=0xDEADBEEF)
     assert (a.distinct, a.generated, a.levels) == (b.distinct, b.generated, b.levels)
+
+
+@pytest.mark.parametrize("model,N,L,R,E", [("Kip320", 4, 2, 2, 1), ("Kip279", 5, 1, 1, 1), ("Kip101", 4, 2, 1, 2),
+                                           ("KafkaTruncateToHighWatermark", 6, 1, 1, 1),
+                                           ("Kip320FirstTry", 8, 1, 1, 0)])
+def test_wider_replica_sets(model, N, L, R, E):
+    """4 to 8 replicas: other state widths, up to 328 action instances (six words of instance bits)."""
+    inv = ("TypeOk", "WeakIsr", "StrongIsr")
+    o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv, threads=8))
+    res, _ = gpu_run(model, invariants=inv, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E,
+                     table_capacity=1 << 25, frontier_capacity=1 << 23)
+    assert res.verdict == o.verdict and res.violated_invariant == o.viol_inv
+    assert res.levels == o.levels and res.distinct == o.distinct and res.generated == o.generated
+    assert list(res.action_generated.values()) == o.action_generated[:len(res.action_generated)]
+    if o.viol_inv:
+        assert res.violation_depth == o.viol_depth and res.violation_count == o.viol_count
