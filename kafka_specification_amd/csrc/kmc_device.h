@@ -66,6 +66,9 @@ typedef unsigned int u32;
 #define KMC_T(var)
 #define KMC_TADD(slot, t0, t1)
 #endif
+#ifndef KMC_SC1_PROBE
+#define KMC_SC1_PROBE 0   // 1: probe with agent-scope (L2-bypassing) loads: fewer stale "empty" reads -> fewer lost CASes
+#endif
 #ifndef KMC_PREFETCH
 #define KMC_PREFETCH 0    // 1: request the next tile's state words while the current tile is processed (measured: no gain)
 #endif
@@ -781,7 +784,11 @@ template <class M> struct KmcSink {
     static KMC_DEV bool claim_from(const KmcArgs& a, u64 fp, u64 i, u64 meta) {
         // open addressing, linear probing.  Slots only ever change 0 -> fp, so a plain
         // (possibly stale) load can only mis-report "empty", which the CAS then corrects.
-        for (u64 probes = 0; probes <= a.table_mask; ++probes) {
+        // The probe chain is bounded: a table filled beyond ~95 % makes linear probing walk millions
+        // of slots per insert (a run that looked hung), so a chain this long is reported as
+        // "table full" instead.  At load <= 0.9 the chance of a 1 K chain is nil.
+        const u64 max_probes = a.table_mask < (1ull << 10) ? a.table_mask : (1ull << 10);
+        for (u64 probes = 0; probes <= max_probes; ++probes) {
 #if KMC_CAS_FIRST
             u64 v = atomicCAS(&a.table[i], 0ull, fp);
             if (v == 0) {
@@ -789,7 +796,11 @@ template <class M> struct KmcSink {
                 return true;
             }
 #else
+#if KMC_SC1_PROBE
+            u64 v = __hip_atomic_load(&a.table[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
             u64 v = a.table[i];
+#endif
             if (v == 0) {
                 if (a.flags & KMC_FLAG_X_PLAINSTORE) {
                     a.table[i] = fp;
@@ -846,6 +857,11 @@ template <class M> struct KmcSink {
             return;
         }
         if (a.mode == KMC_MODE_LOCAL) {
+            // once any wave has found the table full the level is lost anyway: stop probing (one
+            // fresh 4-byte read per flush) so the launch ends promptly instead of walking full chains
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) &
+                KMC_ERR_TABLE_FULL)
+                return;
             // (A per-wave LDS filter of recently resolved fingerprints was tried here to skip
             // duplicate probes: only 4.9 % of the successors hit it — duplicates are not local to
             // a wave — so it was dropped.)

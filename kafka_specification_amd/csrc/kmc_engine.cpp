@@ -869,6 +869,12 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
         r.distinct += produced;
         h->levels.push_back(produced);
         report();
+        // stop before linear probing degenerates (sized for load <= 0.5, still fine at 0.9)
+        if ((double)r.distinct > 0.92 * (double)h->table_cap && r.verdict == KMC_V_OK) {
+            r.verdict = KMC_V_TABLE_FULL;
+            r.queue_left = h->n_cur;
+            break;
+        }
     }
     r.n_levels = h->levels.size();
     r.seconds_total = now_s() - h->t_start;

@@ -194,3 +194,13 @@ def test_native_cli_matches_python_cli(capsys):
     r = subprocess.run([exe, os.path.join(root, "models", "FiniteReplicatedLog.tla"), "-table", "1048576",
                         "-frontier", "262144"], capture_output=True, text=True)
     assert r.returncode == 0 and "1190091 states generated, 116281 distinct states found, 0 states left on queue." in r.stdout
+
+
+def test_overfull_table_stops_quickly():
+    """A table far too small must end in `table_full` fast (bounded probe chains), not crawl."""
+    import time
+    t0 = time.time()
+    with ModelChecker(CheckerConfig(model="Kip320", n_replicas=3, log_size=4, max_records=4, max_leader_epoch=2,
+                                    table_capacity=1 << 20, frontier_capacity=1 << 23)) as mc:
+        r = mc.run()
+    assert r.verdict == "table_full" and time.time() - t0 < 20

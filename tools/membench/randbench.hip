@@ -4,6 +4,9 @@
 //   mode 1: 4 independent random loads / lane (memory-level parallelism x4)
 //   mode 2: random atomicCAS(0 -> x) on a zeroed table, one per lane-iteration
 //   mode 3: load, then atomicCAS when the slot was empty (the claim sequence)
+//   mode 4: random plain 8-byte stores
+//   mode 5: random atomicMax without using the result (no-return atomic)
+//   mode 6: random agent-scope (sc1, L2-bypassing) loads
 // Prints G accesses/s.  Build: hipcc --offload-arch=gfx950 -O3 randbench.hip -o randbench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -25,13 +28,20 @@ __global__ __launch_bounds__(256) void k(u64* table, u64 mask, int iters, int mo
         acc = x;
     } else if (mode == 2) {
         for (int i = 0; i < iters; ++i) { x = mix(x + 1); acc ^= atomicCAS(&table[x & mask], 0ull, x | 1); }
-    } else {
+    } else if (mode == 3) {
         for (int i = 0; i < iters; ++i) {
             x = mix(x + 1);
             u64 v = table[x & mask];
             if (v == 0) v = atomicCAS(&table[x & mask], 0ull, x | 1);
             acc ^= v;
         }
+    } else if (mode == 4) {
+        for (int i = 0; i < iters; ++i) { x = mix(x + 1); table[x & mask] = x | 1; }
+    } else if (mode == 5) {
+        for (int i = 0; i < iters; ++i) { x = mix(x + 1); atomicMax(&table[x & mask], x | 1); }
+    } else {
+        for (int i = 0; i < iters; ++i) { x = mix(x + __hip_atomic_load(&table[x & mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+        acc = x;
     }
     if (acc == 0x1234) sink[0] = acc;
 }
@@ -40,10 +50,10 @@ int main(int argc, char** argv) {
     u64 *table, *sink;
     hipMalloc(&table, slots * 8); hipMalloc(&sink, 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 4; ++mode)
-        for (int bpc : {4, 8}) {
+    for (int mode = (argc > 1 ? atoi(argv[1]) : 0); mode < 7; ++mode)
+        for (int bpc : {8}) {
             hipMemset(table, 0, slots * 8);
-            const int blocks = 256 * bpc, iters = mode == 0 ? 400 : 800;
+            const int blocks = 256 * bpc, iters = (mode == 0 || mode == 6) ? 400 : 800;
             k<<<blocks, 256>>>(table, slots - 1, 8, mode, sink);  // warm-up
             hipDeviceSynchronize();
             hipEventRecord(e0);

@@ -19,6 +19,8 @@ RUNS = {
                                            invariants=("TypeOk",), max_levels=16),
     "config4_kip320_7brokers_log8_levels": dict(model="Kip320", n_replicas=7, log_size=8, max_records=8,
                                                 max_leader_epoch=3, invariants=("TypeOk",), max_levels=13),
+    "stretch_kip279_5brokers_exhaustive": dict(model="Kip279", n_replicas=5, log_size=2, max_records=2,
+                                               max_leader_epoch=2, invariants=("TypeOk",)),
     "stretch_kip320_3_6_6_3": dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3,
                                    invariants=("TypeOk", "WeakIsr", "StrongIsr")),
     "stretch_kip320_3_6_6_3_seed2": dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3,
