@@ -142,6 +142,13 @@ int kmc_precompile(const kmc_config* cfg, const char* arch);
 /* Whole breadth-first search on the device; cb (may be NULL) is called once per level. */
 int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user);
 int kmc_result_get(kmc_handle* h, kmc_result* out);
+/* TLC -checkpoint / -recover analogues [TLC-recall].  Save after a run stopped early (max_levels):
+ * the fingerprint table, the current frontier and all counters go to `path`.  Load into a handle
+ * opened with the same constants, hash seed and capacities, then kmc_resume continues the
+ * search as if it had never stopped (max_levels of the new handle applies). */
+int kmc_checkpoint_save(kmc_handle* h, const char* path);
+int kmc_checkpoint_load(kmc_handle* h, const char* path);
+int kmc_resume(kmc_handle* h, kmc_progress_cb cb, void* user);
 /* Per-level sizes of the last run: fills up to cap entries, returns the number of levels. */
 uint64_t kmc_level_sizes(kmc_handle* h, uint64_t* out, uint64_t cap);
 void kmc_close(kmc_handle* h);
@@ -164,6 +171,9 @@ int kmc_successors(kmc_handle* h, const uint64_t* words, uint64_t* out, uint64_t
 /* Counterexample of the last run (needs keep_trace): canonical-byte states from the initial
  * state to the witness, with the action kind that produced each (-1 for the initial state). */
 int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap, uint64_t* n_out);
+/* tlc2.tool.fp.FPSet.contains analogue [TLC-recall]: was this packed state reached by the last run
+ * (on this shard)?  A host-side probe of the device table (a few 8-byte reads). */
+int kmc_contains(kmc_handle* h, const uint64_t* words, int32_t* present);
 /* The witness of the reported violation / deadlock as a packed state. */
 int kmc_witness(kmc_handle* h, uint64_t* words);
 

@@ -67,6 +67,9 @@ SYMBOLS = [
     ("kmc_precompile", C.c_int, [C.POINTER(KmcConfig), C.c_char_p]),
     ("kmc_run", C.c_int, [_H, PROGRESS_CB, C.c_void_p]),
     ("kmc_result_get", C.c_int, [_H, C.POINTER(KmcResult)]),
+    ("kmc_checkpoint_save", C.c_int, [_H, C.c_char_p]),
+    ("kmc_checkpoint_load", C.c_int, [_H, C.c_char_p]),
+    ("kmc_resume", C.c_int, [_H, PROGRESS_CB, C.c_void_p]),
     ("kmc_level_sizes", C.c_uint64, [_H, C.POINTER(C.c_uint64), C.c_uint64]),
     ("kmc_close", None, [_H]),
     ("kmc_last_error", C.c_char_p, []),
@@ -78,6 +81,7 @@ SYMBOLS = [
     ("kmc_frontier_states", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]),
     ("kmc_successors", C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]),
     ("kmc_trace", C.c_int, [_H, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("kmc_contains", C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     ("kmc_witness", C.c_int, [_H, C.POINTER(C.c_uint64)]),
     ("kmc_model_name", C.c_char_p, [C.c_int32]),
     ("kmc_action_name", C.c_char_p, [C.c_int32, C.c_int32]),

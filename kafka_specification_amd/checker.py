@@ -139,6 +139,17 @@ class ModelChecker:
         nat.check(self._lib.kmc_run(self._h, cb, None))
         return self.result()
 
+    # -- checkpoint / recover (TLC -checkpoint / -recover) ----------------------------------------
+    def save_checkpoint(self, path: str) -> None:
+        nat.check(self._lib.kmc_checkpoint_save(self._h, path.encode()))
+
+    def load_checkpoint(self, path: str) -> None:
+        nat.check(self._lib.kmc_checkpoint_load(self._h, path.encode()))
+
+    def resume(self, progress: Optional[Callable[[dict], None]] = None) -> CheckResult:
+        nat.check(self._lib.kmc_resume(self._h, nat.PROGRESS_CB(), None))
+        return self.result()
+
     def result(self) -> CheckResult:
         r = nat.KmcResult()
         nat.check(self._lib.kmc_result_get(self._h, C.byref(r)))
@@ -195,6 +206,13 @@ class ModelChecker:
         n = C.c_uint64()
         nat.check(self._lib.kmc_successors(self._h, w, out.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n)))
         return [(tuple(int(x) for x in out[i, :W]), int(out[i, W]), int(out[i, W + 1])) for i in range(min(n.value, cap))]
+
+    def contains(self, words) -> bool:
+        """Was this packed state reached by the last run?  (FPSet.contains analogue)"""
+        w = (C.c_uint64 * self.state_words)(*[int(x) for x in words])
+        present = C.c_int32()
+        nat.check(self._lib.kmc_contains(self._h, w, C.byref(present)))
+        return bool(present.value)
 
     def witness(self):
         w = (C.c_uint64 * self.state_words)()

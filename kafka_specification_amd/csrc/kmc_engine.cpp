@@ -274,7 +274,7 @@ struct kmc_handle {
     uint64_t seg_n[KMC_SEGS] = {0};  // ... per segment
     uint64_t seg_cap = 0;        // slots per segment
     uint64_t level = 0;          // number of completed levels
-    bool stepping = false, step_expanded = false;
+    bool stepping = false, step_expanded = false, restored = false;
     std::vector<uint64_t> levels;
     std::vector<uint64_t> init_words, witness;
     bool have_witness = false, have_deadlock = false;
@@ -753,6 +753,8 @@ int kmc_pack_state(kmc_handle* h, const uint8_t* c, uint64_t* words) {
     return KMC_OK;
 }
 
+static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh);
+
 int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
     if (!h) return fail(KMC_E_ARG, "null handle");
     if (!h->table) return fail(KMC_E_STATE, "host-only handle (device = -1) cannot run");
@@ -761,6 +763,24 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
     h->stepping = false;
     int rc = do_begin(h);
     if (rc) return rc;
+    return run_levels(h, cb, user, true);
+}
+
+// TLC -recover analogue: continue the search of a handle restored by kmc_checkpoint_load.
+int kmc_resume(kmc_handle* h, kmc_progress_cb cb, void* user) {
+    if (!h) return fail(KMC_E_ARG, "null handle");
+    if (!h->table || !h->restored) return fail(KMC_E_STATE, "kmc_resume needs a handle restored by kmc_checkpoint_load");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    h->stepping = false;
+    h->restored = false;
+    h->t_start = now_s() - h->res.seconds_total;
+    if (h->res.verdict == KMC_V_LEVEL_LIMIT) h->res.verdict = KMC_V_OK;  // the limit that stopped the saved run is lifted
+    h->res.queue_left = 0;
+    return run_levels(h, cb, user, false);
+}
+
+static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh) {
+    int rc = KMC_OK;
     kmc_result& r = h->res;
     auto report = [&]() {
         if (!cb) return;
@@ -772,7 +792,7 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
         info.seconds = now_s() - h->t_start;
         cb(&info, user);
     };
-    report();
+    if (fresh) report();
     bool stop = false;
     const uint64_t max_levels = h->cfg.max_levels ? h->cfg.max_levels : ~0ull;
     while (!stop && h->n_cur > 0) {
@@ -986,6 +1006,19 @@ static int table_lookup(kmc_handle* h, uint64_t fp, uint64_t* slot) {
     return fail(KMC_E_STATE, "fingerprint %016llx not in table", (unsigned long long)fp);
 }
 
+// FPSet.contains analogue: is this packed state's fingerprint in the seen-set of the last run?
+int kmc_contains(kmc_handle* h, const uint64_t* words, int32_t* present) {
+    if (!h || !words || !present) return fail(KMC_E_ARG, "null argument");
+    if (!h->table) return fail(KMC_E_STATE, "host-only handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    uint64_t slot = 0;
+    const int rc = table_lookup(h, kmc_fingerprint_of(h, words), &slot);
+    *present = rc == KMC_OK;
+    g_err.clear();
+    return KMC_OK;
+}
+
 int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap, uint64_t* n_out) {
     if (!h || !n_out) return fail(KMC_E_ARG, "null argument");
     if (!h->pred) return fail(KMC_E_STATE, "kmc_trace needs keep_trace=1");
@@ -1034,6 +1067,112 @@ int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap
         if (!found) return fail(KMC_E_STATE, "trace replay lost the path at step %llu", (unsigned long long)step);
     }
     if (kinds && cap) kinds[0] = -1;
+    return KMC_OK;
+}
+
+// ---- checkpoint / recover (TLC -checkpoint / -recover [TLC-recall]) --------------------------
+// File: header, kmc_result, level sizes, segment sizes, then the fingerprint table (and the
+// predecessor table when traces are kept) and the current frontier's planes, segment by segment.
+namespace {
+struct CkptHeader {
+    char magic[8];          // "KMCCKPT1"
+    kmc_config cfg;         // pointers inside are not meaningful in the file
+    uint64_t table_cap, fcap, seg_cap, level, n_cur, n_levels, w, has_pred;
+};
+bool wr(FILE* f, const void* p, size_t n) { return fwrite(p, 1, n, f) == n; }
+bool rd(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n; }
+// device <-> file through a bounded pinned staging buffer
+int dev_to_file(FILE* f, const u64* dev, uint64_t words) {
+    const uint64_t chunk = 1ull << 24;  // 128 MiB
+    std::vector<uint64_t> buf(words < chunk ? words : chunk);
+    for (uint64_t at = 0; at < words; at += chunk) {
+        const uint64_t n = words - at < chunk ? words - at : chunk;
+        HIP_TRY(hipMemcpy(buf.data(), dev + at, n * 8, hipMemcpyDeviceToHost));
+        if (!wr(f, buf.data(), n * 8)) return fail(KMC_E_STATE, "checkpoint: short write");
+    }
+    return KMC_OK;
+}
+int file_to_dev(FILE* f, u64* dev, uint64_t words) {
+    const uint64_t chunk = 1ull << 24;
+    std::vector<uint64_t> buf(words < chunk ? words : chunk);
+    for (uint64_t at = 0; at < words; at += chunk) {
+        const uint64_t n = words - at < chunk ? words - at : chunk;
+        if (!rd(f, buf.data(), n * 8)) return fail(KMC_E_STATE, "checkpoint: short read");
+        HIP_TRY(hipMemcpy(dev + at, buf.data(), n * 8, hipMemcpyHostToDevice));
+    }
+    return KMC_OK;
+}
+}  // namespace
+
+int kmc_checkpoint_save(kmc_handle* h, const char* path) {
+    if (!h || !path) return fail(KMC_E_ARG, "null argument");
+    if (!h->table || h->cfg.n_shards != 1) return fail(KMC_E_STATE, "checkpoints are for single-GPU device handles");
+    if (h->levels.empty()) return fail(KMC_E_STATE, "nothing to checkpoint: run first");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(KMC_E_ARG, "cannot open %s for writing", path);
+    CkptHeader hd{};
+    memcpy(hd.magic, "KMCCKPT1", 8);
+    hd.cfg = h->cfg;
+    hd.cfg.cache_dir = nullptr;
+    hd.table_cap = h->table_cap; hd.fcap = h->fcap; hd.seg_cap = h->seg_cap; hd.level = h->level;
+    hd.n_cur = h->n_cur; hd.n_levels = h->levels.size(); hd.w = h->W; hd.has_pred = h->pred != nullptr;
+    int rc = KMC_OK;
+    bool ok = wr(f, &hd, sizeof hd) && wr(f, &h->res, sizeof h->res) && wr(f, h->levels.data(), h->levels.size() * 8) &&
+              wr(f, h->seg_n, sizeof h->seg_n) && wr(f, h->init_words.data(), h->W * 8);
+    if (!ok) rc = fail(KMC_E_STATE, "checkpoint: short write");
+    if (!rc) rc = dev_to_file(f, h->table, h->table_cap);
+    if (!rc && h->pred) rc = dev_to_file(f, h->pred, h->table_cap);
+    for (int sg = 0; sg < KMC_SEGS && !rc; ++sg)
+        for (int k = 0; k < h->W && !rc; ++k)
+            if (h->seg_n[sg])
+                rc = dev_to_file(f, h->frontier[h->cur] + (uint64_t)k * h->fcap + (uint64_t)sg * h->seg_cap, h->seg_n[sg]);
+    fclose(f);
+    return rc;
+}
+
+int kmc_checkpoint_load(kmc_handle* h, const char* path) {
+    if (!h || !path) return fail(KMC_E_ARG, "null argument");
+    if (!h->table || h->cfg.n_shards != 1) return fail(KMC_E_STATE, "checkpoints are for single-GPU device handles");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(KMC_E_ARG, "cannot open %s", path);
+    CkptHeader hd{};
+    int rc = KMC_OK;
+    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT1", 8) != 0) rc = fail(KMC_E_ARG, "%s is not a checkpoint", path);
+    const kmc_config& a = hd.cfg;
+    const kmc_config& b = h->cfg;
+    if (!rc && (a.model != b.model || a.n_replicas != b.n_replicas || a.log_size != b.log_size ||
+                a.max_records != b.max_records || a.max_leader_epoch != b.max_leader_epoch ||
+                a.n_log_records != b.n_log_records || a.max_id != b.max_id || a.hash_seed != b.hash_seed ||
+                hd.w != (uint64_t)h->W))
+        rc = fail(KMC_E_ARG, "checkpoint was taken for a different model / constants / hash seed");
+    if (!rc && (hd.table_cap != h->table_cap || hd.fcap != h->fcap || hd.seg_cap != h->seg_cap ||
+                hd.has_pred != (uint64_t)(h->pred != nullptr)))
+        rc = fail(KMC_E_ARG, "checkpoint capacities differ: open the handle with table_capacity=%llu frontier_capacity=%llu keep_trace=%d",
+                  (unsigned long long)hd.table_cap, (unsigned long long)hd.fcap, (int)hd.has_pred);
+    if (!rc) rc = reset_run(h);
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(KMC_E_DEVICE, "stream sync failed");
+    if (!rc) {
+        h->levels.resize(hd.n_levels);
+        h->init_words.resize(h->W);
+        bool ok = rd(f, &h->res, sizeof h->res) && rd(f, h->levels.data(), hd.n_levels * 8) && rd(f, h->seg_n, sizeof h->seg_n) &&
+                  rd(f, h->init_words.data(), h->W * 8);
+        if (!ok) rc = fail(KMC_E_STATE, "checkpoint: short read");
+    }
+    if (!rc) rc = file_to_dev(f, h->table, h->table_cap);
+    if (!rc && h->pred) rc = file_to_dev(f, h->pred, h->table_cap);
+    h->cur = 0;
+    for (int sg = 0; sg < KMC_SEGS && !rc; ++sg)
+        for (int k = 0; k < h->W && !rc; ++k)
+            if (h->seg_n[sg])
+                rc = file_to_dev(f, h->frontier[0] + (uint64_t)k * h->fcap + (uint64_t)sg * h->seg_cap, h->seg_n[sg]);
+    fclose(f);
+    if (rc) return rc;
+    h->level = hd.level;
+    h->n_cur = hd.n_cur;
+    h->restored = true;
     return KMC_OK;
 }
 

@@ -204,3 +204,51 @@ def test_overfull_table_stops_quickly():
                                     table_capacity=1 << 20, frontier_capacity=1 << 23)) as mc:
         r = mc.run()
     assert r.verdict == "table_full" and time.time() - t0 < 20
+
+
+def test_checkpoint_and_recover(tmp_path):
+    """TLC -checkpoint / -recover analogue: stop at a level limit, save, load into a fresh handle,
+    resume: every number equals the uninterrupted run's."""
+    base = dict(model="Kip320", n_replicas=3, log_size=3, max_records=3, max_leader_epoch=1,
+                invariants=("TypeOk", "WeakIsr", "StrongIsr"), table_capacity=1 << 20, frontier_capacity=1 << 17)
+    with ModelChecker(CheckerConfig(**base)) as mc:
+        full = mc.run()
+    path = str(tmp_path / "kip320.ckpt")
+    with ModelChecker(CheckerConfig(**base, max_levels=11)) as mc:
+        part = mc.run()
+        assert part.verdict == "level_limit" and part.depth == 11 and part.queue_left == full.levels[10]
+        assert part.levels == full.levels[:11]
+        mc.save_checkpoint(path)
+    with ModelChecker(CheckerConfig(**base)) as mc:
+        mc.load_checkpoint(path)
+        rest = mc.resume()
+        init = mc.pack(kmo.Run(kmo.make_config("Kip320", N=3, L=3, R=3, E=1, max_states=1)).state(0))
+        assert mc.contains(init)                         # FPSet.contains analogue
+        assert not mc.contains([x ^ 0x5555 for x in init])
+    assert (rest.verdict, rest.distinct, rest.generated, rest.depth, rest.levels, rest.queue_left) == \
+        (full.verdict, full.distinct, full.generated, full.depth, full.levels, 0)
+    assert rest.action_generated == full.action_generated and rest.deadlock_states == full.deadlock_states
+    # a checkpoint only fits a handle with the same constants and capacities
+    from kafka_specification_amd import KmcError
+    with ModelChecker(CheckerConfig(**{**base, "log_size": 2})) as mc:
+        with pytest.raises(KmcError):
+            mc.load_checkpoint(path)
+    with ModelChecker(CheckerConfig(**{**base, "table_capacity": 1 << 21})) as mc:
+        with pytest.raises(KmcError):
+            mc.load_checkpoint(path)
+
+
+def test_level_limit_still_checks_the_last_frontier():
+    """With max_levels the last frontier is not expanded; its states still get their invariant check."""
+    inv = ("TypeOk", "StrongIsr")
+    o = kmo.Run(kmo.make_config("Kip279", N=3, L=2, R=2, E=2, invariants=inv))
+    assert o.verdict == "invariant"
+    cfg = dict(model="Kip279", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=2, invariants=inv,
+               table_capacity=1 << 22, frontier_capacity=1 << 20)
+    with ModelChecker(CheckerConfig(**cfg, max_levels=o.viol_depth)) as mc:   # stop exactly at the violating level
+        r = mc.run()
+    assert (r.verdict, r.violated_invariant, r.violation_depth) == ("invariant", o.viol_inv, o.viol_depth)
+    assert r.violation_count == o.viol_count and r.levels == o.levels
+    with ModelChecker(CheckerConfig(**cfg, max_levels=o.viol_depth - 1)) as mc:  # one level earlier: nothing found yet
+        r = mc.run()
+    assert r.verdict == "level_limit" and r.violated_invariant is None and r.depth == o.viol_depth - 1
