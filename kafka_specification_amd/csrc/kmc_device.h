@@ -50,9 +50,6 @@ typedef unsigned int u32;
 #define KMC_SEGS 8    // frontier segments, each with its own append counter (block b appends to b % KMC_SEGS)
 
 // tuning knobs (the host may override them per code object through KMC_JIT_DEFINES)
-#ifndef KMC_OUT_STAGE
-#define KMC_OUT_STAGE 1   // stage winners in LDS and append 64 at a time (1 atomic per 64 states)
-#endif
 #ifndef KMC_CAS_FIRST
 #define KMC_CAS_FIRST 0   // probe with atomicCAS directly instead of load-then-CAS
 #endif
@@ -103,7 +100,6 @@ struct alignas(128) KmcLevelCtl {
     u64 deadlock_count;              // expanded states without any successor
     u64 deadlock_fp_inv;
     u64 enum_count;                  // ENUM: records written
-    u64 inserted;                    // table claims (== next_count unless the frontier overflowed)
     u64 prof[8];                     // KMC_PROFILE: summed per-wave s_memtime ticks per phase (tuning aid)
     u32 err;
     u32 pad;
@@ -866,28 +862,7 @@ template <class M> struct KmcSink {
             // duplicate probes: only 4.9 % of the successors hit it — duplicates are not local to
             // a wave — so it was dropped.)
             const bool isnew = valid && claim(a, fp, meta);
-#if KMC_OUT_STAGE
             if (!(a.flags & KMC_FLAG_X_NOSTAGE)) out.push(a, isnew, t);
-#else
-            const u64 m = __ballot(isnew);
-            if (m) {
-                const int leader = __builtin_ctzll(m);
-                const u32 n = __popcll(m);
-                const u32 seg = blockIdx.x % KMC_SEGS;
-                u64 base = 0;
-                if ((int)kmc_lane() == leader) base = atomicAdd(&a.ctl->next_count[seg].v, (u64)n);
-                base = kmc_bcast64(base, leader) + kmc_rank_in(m);
-                const u64 idx = (u64)seg * a.seg_cap + base;
-                if (isnew) {
-                    if (base < a.seg_cap) {
-#pragma unroll
-                        for (int k = 0; k < W; ++k) a.fout[(u64)k * a.fout_stride + idx] = t[k];
-                    } else {
-                        atomicOr(&a.ctl->err, KMC_ERR_FRONTIER_FULL);
-                    }
-                }
-            }
-#endif
         } else if (a.mode == KMC_MODE_SHARDED) {
             // successors this shard owns take the local path at once (probe, claim, stage): only
             // the (P-1)/P that belong elsewhere travel

@@ -164,7 +164,7 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
                                "L*bits(record)<=64, E<=7", cfg.model, cfg.n_replicas, cfg.log_size,
                     cfg.max_records, cfg.max_leader_epoch, cfg.n_log_records);
     *kname = name;
-    // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_CAS_FIRST=1 -DKMC_OUT_STAGE=0"
+    // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_MIN_WAVES=5 -DKMC_PROFILE=1"
     std::vector<std::string> defines;
     std::string defines_key;
     if (const char* d = getenv("KMC_JIT_DEFINES")) {
