@@ -103,6 +103,7 @@ typedef struct kmc_level_info {
     uint64_t violation_count[4]; /* states of the EXPANDED level (depth-1) violating each invariant */
     uint64_t violation_fp[4];    /* smallest violating fingerprint per invariant, 0 = none */
     uint64_t deadlocks_level;    /* states of the expanded level without successors */
+    uint64_t send_filtered;      /* n_shards>1: remote successors the sender-side duplicate filter did not ship */
     uint32_t error_flags;        /* 1 frontier full, 2 table full, 4 send area full */
     uint32_t pad_;
 } kmc_level_info;

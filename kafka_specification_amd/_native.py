@@ -42,7 +42,7 @@ class KmcLevelInfo(C.Structure):
     _fields_ = [("depth", C.c_uint64), ("new_states", C.c_uint64), ("generated_total", C.c_uint64),
                 ("distinct_total", C.c_uint64), ("seconds", C.c_double),
                 ("generated_level", C.c_uint64 * KMC_MAX_KINDS), ("violation_count", C.c_uint64 * 4),
-                ("violation_fp", C.c_uint64 * 4), ("deadlocks_level", C.c_uint64),
+                ("violation_fp", C.c_uint64 * 4), ("deadlocks_level", C.c_uint64), ("send_filtered", C.c_uint64),
                 ("error_flags", C.c_uint32), ("pad_", C.c_uint32)]
 
 

@@ -100,6 +100,7 @@ struct alignas(128) KmcLevelCtl {
     u64 deadlock_count;              // expanded states without any successor
     u64 deadlock_fp_inv;
     u64 enum_count;                  // ENUM: records written
+    u64 send_filtered;               // SHARDED: remote successors dropped by the sender-side filter
     u64 prof[8];                     // KMC_PROFILE: summed per-wave s_memtime ticks per phase (tuning aid)
     u32 err;
     u32 pad;
@@ -118,6 +119,8 @@ struct KmcArgs {
     u64* table;        // open-addressed fingerprint table, 0 = empty
     u64 table_mask;    // capacity-1 (capacity is a power of two)
     u64* pred;         // optional: predecessor fingerprint per table slot (trace reconstruction)
+    u64* sent;         // SHARDED, optional: fingerprints already shipped to their (remote) owner
+    u64 sent_mask;
     KmcLevelCtl* ctl;
     u64 seed;
     u64* send;         // SHARDED: [shard][KMC_SEGS][send_cap] AoS records of rec_words words (state[, parent fp]);
@@ -816,6 +819,23 @@ template <class M> struct KmcSink {
         return false;
     }
 
+    // Sender-side duplicate filter of the sharded path: true when fp was not yet in `set` (and is now).
+    // BFS generates every state ~g times; without the filter all g copies cross xGMI.  A full or
+    // over-long chain just answers "fresh" (the copy travels, the owner dedups): never wrong.
+    static KMC_DEV bool first_time(u64* set, u64 mask, u64 fp) {
+        u64 i = (fp >> 17) & mask;  // other bits than the owner's table index
+        for (u32 probes = 0; probes < 64; ++probes) {
+            u64 v = set[i];
+            if (v == 0) {
+                v = atomicCAS(&set[i], 0ull, fp);
+                if (v == 0) return true;
+            }
+            if (v == fp) return false;
+            i = (i + 1) & mask;
+        }
+        return true;
+    }
+
     // Invariants are evaluated when a state is EXPANDED (kmc_expand_body), not when it is first
     // claimed: every distinct state is expanded exactly once, its fields are already extracted
     // there, and all 64 lanes hold a state to check.  (Checking winners inside the flush ran the
@@ -871,9 +891,15 @@ template <class M> struct KmcSink {
             out.push(a, isnew, t);
             // bucket the rest by owner: one wave-aggregated atomicAdd per destination present in this batch
             const u32 sub = blockIdx.x % KMC_SEGS;
+            const bool remote = valid && dst != a.shard;
+            const bool ship = remote && (a.sent == nullptr || first_time(a.sent, a.sent_mask, fp));
+            {
+                const u64 dropped = __ballot(remote && !ship);
+                if (dropped && kmc_lane() == 0) atomicAdd(&a.ctl->send_filtered, (u64)__popcll(dropped));
+            }
             for (u32 d = 0; d < a.nshards; ++d) {  // wave-uniform
                 if (d == a.shard) continue;
-                const bool mine = dst == d;
+                const bool mine = ship && dst == d;
                 const u64 m = __ballot(mine);
                 if (m == 0) continue;
                 const int leader = __builtin_ctzll(m);

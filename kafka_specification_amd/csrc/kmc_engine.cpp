@@ -256,6 +256,8 @@ struct kmc_handle {
     int n_cus = 256;
     int blocks_per_cu = 4;  // k_expand residency, from the occupancy query at open
     u64 *table = nullptr, *pred = nullptr, *table2 = nullptr;
+    u64* sent = nullptr;      // n_shards > 1: sender-side filter of fingerprints already shipped
+    uint64_t sent_cap = 0;
     uint64_t table_cap = 0;
     u64* frontier[2] = {nullptr, nullptr};
     uint64_t fcap = 0;
@@ -305,6 +307,8 @@ KmcArgs base_args(kmc_handle* h, int ctl_slot) {
     a.table = h->table;
     a.table_mask = h->table_cap - 1;
     a.pred = h->pred;
+    a.sent = h->sent;
+    a.sent_mask = h->sent_cap ? h->sent_cap - 1 : 0;
     a.ctl = h->ctl + ctl_slot;
     a.seed = h->cfg.hash_seed;
     a.inv_mask = h->cfg.invariant_mask;
@@ -373,6 +377,7 @@ int find_state(kmc_handle* h, const u64* frontier, const uint64_t seg[KMC_SEGS],
 int reset_run(kmc_handle* h) {
     HIP_TRY(hipMemsetAsync(h->table, 0, h->table_cap * 8, h->stream));
     if (h->pred) HIP_TRY(hipMemsetAsync(h->pred, 0, h->table_cap * 8, h->stream));
+    if (h->sent) HIP_TRY(hipMemsetAsync(h->sent, 0, h->sent_cap * 8, h->stream));
     HIP_TRY(hipMemsetAsync(h->ctl, 0, 3 * sizeof(KmcLevelCtl), h->stream));
     h->levels.clear();
     h->witness.clear();
@@ -525,6 +530,7 @@ void kmc_close(kmc_handle* h) {
     if (h->table) hipFree(h->table);
     if (h->pred) hipFree(h->pred);
     if (h->table2) hipFree(h->table2);
+    if (h->sent) hipFree(h->sent);
     if (h->frontier[0]) hipFree(h->frontier[0]);
     if (h->frontier[1]) hipFree(h->frontier[1]);
     if (h->ctl) hipFree(h->ctl);
@@ -592,7 +598,10 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double budget = 0.85 * (double)free_b;
     const uint64_t slot_bytes = cfg->keep_trace ? 16 : 8;
-    uint64_t tcap = cfg->table_capacity ? pow2_ceil(cfg->table_capacity) : pow2_floor((uint64_t)(budget * 0.5) / slot_bytes);
+    // auto-sizing: half of the budget for the table; a shard also keeps a sender-side filter of twice the table
+    const double table_share = h->cfg.n_shards > 1 ? 0.18 : 0.5;
+    uint64_t tcap = cfg->table_capacity ? pow2_ceil(cfg->table_capacity)
+                                        : pow2_floor((uint64_t)(budget * table_share) / slot_bytes);
     if (tcap < 1024) tcap = 1024;
     uint64_t fcap = cfg->frontier_capacity;
     if (!fcap) {
@@ -615,6 +624,12 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     HIP_TRY(hipMalloc(&h->scratch, 64 * 8));
     HIP_TRY(hipHostMalloc(&h->scratch_host, 64 * 8));
     HIP_TRY(hipMalloc(&h->enum_out, h->enum_cap * (h->W + 2) * 8ull));
+    if (h->cfg.n_shards > 1 && !(getenv("KMC_NO_SEND_FILTER") && atoi(getenv("KMC_NO_SEND_FILTER")))) {
+        // sender-side duplicate filter: a shard generates (and would ship) a remote state several
+        // times; it may meet up to ~2x as many distinct remote fingerprints as it owns
+        h->sent_cap = tcap * 2;
+        if (hipMalloc(&h->sent, h->sent_cap * 8) != hipSuccess) { h->sent = nullptr; h->sent_cap = 0; }  // optional
+    }
     if (h->cfg.n_shards > 1) {
         uint64_t scap = cfg->send_capacity;
         if (!scap) scap = (uint64_t)(budget * 0.16) / (8ull * h->rec_words * h->cfg.n_shards * KMC_SEGS);
@@ -1291,6 +1306,7 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
             info->violation_fp[k] = c.viol_count[k] ? ~c.viol_fp_inv[k] : 0;
         }
         info->deadlocks_level = c.deadlock_count;
+        info->send_filtered = c.send_filtered;
         info->error_flags = c.err;
     }
     return rc;

@@ -96,6 +96,7 @@ class HipShardEngine:
         for k in range(4):
             st[17 + k] = info.violation_count[k]
         st[21] = info.deadlocks_level
+        st[24] = info.send_filtered
         st[22] = 1 if info.error_flags & 2 else 0
         st[23] = 1 if info.error_flags & (1 | 4) else 0
         return st
@@ -197,12 +198,14 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
     t0 = time.perf_counter()
     inv_names = nat.INVARIANT_NAMES
     levels, generated, deadlocks = [], 0, 0
+    filtered = 0  # remote successors dropped by the sender-side filters (all shards)
     action_generated = [0] * nat.KMC_MAX_KINDS
     verdict, viol_inv, viol_depth, viol_count = "ok", None, 0, {n: 0 for n in inv_names}
 
     def absorb(st, parent_depth):
         """st describes the expansion of the level at `parent_depth`.  Returns (stop, new)."""
-        nonlocal generated, deadlocks, verdict, viol_inv, viol_depth, viol_count
+        nonlocal generated, deadlocks, verdict, viol_inv, viol_depth, viol_count, filtered
+        filtered += int(st[24])
         if viol_inv is None:
             counts = {n: int(st[17 + k]) for k, n in enumerate(inv_names)}
             hit = [n for n in inv_names if n in cfg.invariants and counts[n]]
@@ -255,6 +258,7 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
     if depth >= max_levels and new > 0 and verdict == "ok":
         verdict = "level_limit"  # (the unexpanded last frontier is not invariant-checked in sharded mode)
     local = [e.result() for e in engines]
+    run_sharded.last_send_filtered = filtered  # observability for tests / bench
     return CheckResult(
         generated=generated, distinct=sum(levels), depth=len(levels),
         queue_left=(levels[-1] if verdict != "ok" else 0), verdict=verdict, violated_invariant=viol_inv,

@@ -252,3 +252,24 @@ def test_level_limit_still_checks_the_last_frontier():
     with ModelChecker(CheckerConfig(**cfg, max_levels=o.viol_depth - 1)) as mc:  # one level earlier: nothing found yet
         r = mc.run()
     assert r.verdict == "level_limit" and r.violated_invariant is None and r.depth == o.viol_depth - 1
+
+
+def test_sender_side_filter_drops_duplicates_but_not_states():
+    """The sharded path ships each remote state once per shard that generates it, not once per
+    generation: same results with and without the filter, and the filter really drops copies."""
+    from kafka_specification_amd import sharded
+    cfg = CheckerConfig(model="Kip320", n_replicas=3, log_size=3, max_records=3, max_leader_epoch=1,
+                        invariants=("TypeOk",), table_capacity=1 << 20, frontier_capacity=1 << 18,
+                        send_capacity=1 << 17)
+    o = kmo.Run(kmo.make_config("Kip320", N=3, L=3, R=3, E=1))
+    r = check_loopback(cfg, 3)
+    dropped = sharded.run_sharded.last_send_filtered
+    assert (r.distinct, r.generated, r.levels) == (o.distinct, o.generated, o.levels)
+    assert dropped > o.generated // 10        # g = 2.8 here: most remote copies are duplicates
+    os.environ["KMC_NO_SEND_FILTER"] = "1"
+    try:
+        r2 = check_loopback(cfg, 3)
+        assert sharded.run_sharded.last_send_filtered == 0
+    finally:
+        del os.environ["KMC_NO_SEND_FILTER"]
+    assert (r2.distinct, r2.generated, r2.levels) == (r.distinct, r.generated, r.levels)
