@@ -157,8 +157,15 @@ const char* kmc_last_error(void);
 
 /* --- states as data ---------------------------------------------------------------------
  * Packed states are state_words little-endian uint64 (layout: csrc/kmc_layout.h).  The
- * "canonical bytes" form is one byte per field (documented in oracle/kmc_oracle.c and
- * DESIGN.md) and is what traces are returned in. */
+ * "canonical bytes" form — what traces are returned in — is one byte per field:
+ *   Kafka family: per replica r a block of 5+LogSize bytes at r*(5+LogSize):
+ *       [0] endOffset  [1] hw  [2] leaderEpoch+1 (Nil -> 0)  [3] leader+1 ("NONE" -> 0)
+ *       [4] isr bitmask  [5+o] record at offset o: 0 = Nil, else 1 + id*(MaxLeaderEpoch+1) + epoch
+ *     then globals: [0] nextRecordId [1] nextLeaderEpoch [2] quorum.leaderEpoch+1 [3] quorum.leader+1
+ *       [4] quorum.isr, then for e in 0..MaxLeaderEpoch: leader+1, isr of the request with that epoch
+ *       (zeros while e >= nextLeaderEpoch);
+ *   FiniteReplicatedLog: per replica [endOffset, record(0 = Nil | 1..K) x LogSize];
+ *   IdSequence: nextId as 8 little-endian bytes. */
 uint64_t kmc_state_words(kmc_handle* h);
 uint64_t kmc_canon_bytes(kmc_handle* h);
 int kmc_unpack_state(kmc_handle* h, const uint64_t* words, uint8_t* canon);

@@ -105,7 +105,8 @@ def test_seed_independence():
 
 @pytest.mark.parametrize("model,N,L,R,E", [("Kip320", 4, 2, 2, 1), ("Kip279", 5, 1, 1, 1), ("Kip101", 4, 2, 1, 2),
                                            ("KafkaTruncateToHighWatermark", 6, 1, 1, 1),
-                                           ("Kip320FirstTry", 8, 1, 1, 0)])
+                                           ("Kip320FirstTry", 8, 1, 1, 0), ("Kip320", 7, 1, 1, 0),
+                                           ("Kip279", 7, 1, 1, 0)])
 def test_wider_replica_sets(model, N, L, R, E):
     """4 to 8 replicas: other state widths, up to 328 action instances (six words of instance bits)."""
     inv = ("TypeOk", "WeakIsr", "StrongIsr")
