@@ -127,15 +127,19 @@ class ModelChecker:
         return [self._lib.kmc_action_name(self.model_id, k).decode() for k in range(n)]
 
     # -- the search ---------------------------------------------------------------------
+    @staticmethod
+    def _callback(progress):
+        if progress is None:
+            return nat.PROGRESS_CB()
+
+        def _cb(info, _user):
+            i = info.contents
+            progress(dict(depth=i.depth, new_states=i.new_states, generated=i.generated_total,
+                          distinct=i.distinct_total, seconds=i.seconds))
+        return nat.PROGRESS_CB(_cb)
+
     def run(self, progress: Optional[Callable[[dict], None]] = None) -> CheckResult:
-        if progress is not None:
-            def _cb(info, _user):
-                i = info.contents
-                progress(dict(depth=i.depth, new_states=i.new_states, generated=i.generated_total,
-                              distinct=i.distinct_total, seconds=i.seconds))
-            cb = nat.PROGRESS_CB(_cb)
-        else:
-            cb = nat.PROGRESS_CB()
+        cb = self._callback(progress)
         nat.check(self._lib.kmc_run(self._h, cb, None))
         return self.result()
 
@@ -147,7 +151,8 @@ class ModelChecker:
         nat.check(self._lib.kmc_checkpoint_load(self._h, path.encode()))
 
     def resume(self, progress: Optional[Callable[[dict], None]] = None) -> CheckResult:
-        nat.check(self._lib.kmc_resume(self._h, nat.PROGRESS_CB(), None))
+        cb = self._callback(progress)
+        nat.check(self._lib.kmc_resume(self._h, cb, None))
         return self.result()
 
     def result(self) -> CheckResult:
