@@ -42,6 +42,10 @@ def precompile_list():
             dict(model="Kip320FirstTry", n_replicas=8, log_size=1, max_records=1, max_leader_epoch=0),
             dict(model="Kip320", n_replicas=7, log_size=1, max_records=1, max_leader_epoch=0),
             dict(model="Kip279", n_replicas=7, log_size=1, max_records=1, max_leader_epoch=0)]
+    out += [dict(model="KafkaTruncateToHighWatermark", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=2),
+            dict(model="Kip279", n_replicas=3, log_size=2, max_records=3, max_leader_epoch=1),
+            dict(model="Kip320", n_replicas=3, log_size=3, max_records=3, max_leader_epoch=1),
+            dict(model="Kip320", n_replicas=4, log_size=2, max_records=1, max_leader_epoch=1)]
     for M in (0, 1, 10, 1000):
         out.append(dict(model="IdSequence", max_id=M))
     for K in (1, 2, 3, 4):

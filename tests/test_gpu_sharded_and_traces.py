@@ -76,12 +76,16 @@ def test_frontier_and_table_overflow_are_reported():
         assert mc.run().verdict == "table_full"
 
 
-def test_device_successors_match_oracle_on_sampled_states():
-    model, N, L, R, E = "Kip101", 3, 3, 2, 2
+@pytest.mark.parametrize("model,N,L,R,E", [("KafkaTruncateToHighWatermark", 3, 2, 2, 2), ("Kip101", 3, 3, 2, 2),
+                                           ("Kip279", 3, 2, 3, 1), ("Kip320", 3, 3, 3, 1),
+                                           ("Kip320FirstTry", 3, 2, 2, 2), ("Kip320", 4, 2, 1, 1)])
+def test_device_successors_match_oracle_on_sampled_states(model, N, L, R, E):
+    """Per-state differential test: the device's Next (guards + effects of every action instance)
+    against the C oracle's, on a sample of reachable states."""
     o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=(), max_states=20000))
     with ModelChecker(CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E,
                                     table_capacity=1 << 16, frontier_capacity=1 << 12)) as mc:
-        for idx in range(0, min(o.distinct, 20000), 97):
+        for idx in range(0, min(o.distinct, 20000), 131):
             s = o.state(idx)
             got = sorted((k, mc.unpack(w)) for (w, _fp, k) in mc.successors(mc.pack(s)))
             want = sorted(set(kmo.successors(o.cfg, s, o.sb)))  # the device lists each binding's successor once
