@@ -143,3 +143,55 @@ def test_fingerprints_are_distinct_on_a_reachable_set():
             for idx in range(0, o.distinct, 3):
                 fps.add(mc.fingerprint(mc.pack(o.state(idx))))
             assert len(fps) == len(range(0, o.distinct, 3))
+
+
+def test_pack_unpack_property_random_fields():
+    """hypothesis: for random constants and random in-range field values, unpack(pack(x)) == x and
+    distinct canonical states get distinct packed words (the layout shared by host and device)."""
+    from hypothesis import given, settings, strategies as st
+
+    @st.composite
+    def case(draw):
+        N = draw(st.integers(2, 8)); E = draw(st.integers(0, 7)); R = draw(st.integers(1, 12))
+        bits_rec = max(1, (E).bit_length() if E else 0) + (R + 1 - 1).bit_length()
+        L = draw(st.integers(1, max(1, min(10, 64 // max(1, (R).bit_length() + (E).bit_length() or 1)))))
+        return N, L, R, E, draw(st.randoms(use_true_random=False))
+
+    handles = {}
+
+    @settings(max_examples=120, deadline=None)
+    @given(case())
+    def run(c):
+        N, L, R, E, rnd = c
+        key = (N, L, R, E)
+        if key not in handles:
+            try:
+                handles[key] = ModelChecker(CheckerConfig(model="Kip320", n_replicas=N, log_size=L, max_records=R,
+                                                          max_leader_epoch=E, device=-1))
+            except KmcError:
+                handles[key] = None     # constants that cannot be packed are rejected, not mis-packed
+        mc = handles[key]
+        if mc is None:
+            return
+        b = bytearray()
+        for _ in range(N):
+            end = rnd.randint(0, L)
+            b += bytes([end, rnd.randint(0, L), rnd.randint(0, E + 1), rnd.randint(0, N), rnd.randint(0, (1 << N) - 1)])
+            b += bytes((1 + rnd.randint(0, R - 1) * (E + 1) + rnd.randint(0, E)) if o < end else 0 for o in range(L))
+        nep = rnd.randint(0, E + 1)
+        b += bytes([rnd.randint(0, R), nep, rnd.randint(0, E + 1), rnd.randint(0, N), rnd.randint(0, (1 << N) - 1)])
+        for e in range(E + 1):
+            b += bytes([rnd.randint(0, N), rnd.randint(0, (1 << N) - 1)]) if e < nep else bytes([0, 0])
+        b = bytes(b)
+        assert len(b) == mc.canon_bytes
+        w = mc.pack(b)
+        assert mc.unpack(w) == b
+        assert len(w) == mc.state_words and all(0 <= x < 1 << 64 for x in w)
+        b2 = bytearray(b); b2[1] = (b2[1] + 1) % (L + 1)      # change one field (hw of replica 0)
+        if bytes(b2) != b:
+            assert mc.pack(bytes(b2)) != w
+
+    run()
+    for mc in handles.values():
+        if mc is not None:
+            mc.close()
