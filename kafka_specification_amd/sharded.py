@@ -7,9 +7,10 @@ Per level, on every shard:  expand the local frontier, bucketing each successor 
 area of its owner (k_expand, mode SHARDED)  ->  all-to-all-v of packed states (W words, plus the
 predecessor fingerprint when traces are kept; the owner recomputes the fingerprint because it must
 later expand the state)  ->  the owner probes/inserts what it received, checks invariants on
-the winners and appends them to its next frontier (k_insert)  ->  all-reduce of a small
-statistics vector (new states, generated, violations, deadlocks, error flags) decides
-termination and the verdict identically on every rank.
+the winners and appends them to its next frontier (k_insert).  A small statistics vector per
+shard (new states, generated, violations, deadlocks, error flags) rides on the send-count
+all-gather of the NEXT level, whose sum decides termination and the verdict identically on every
+rank: one collective and one device sync fewer per BFS level than a separate all-reduce.
 
 The level logic is written against two small interfaces so that it can be exercised without
 GPUs:
@@ -111,6 +112,10 @@ class LoopbackExchange:
     def __init__(self, n):
         self.n = n
 
+    def exchange(self, sends, stats):
+        """-> (global statistics of the PREVIOUS expansion, deliver) ; deliver() routes the payload."""
+        return np.sum(np.stack(stats), axis=0), lambda: self.all_to_all(sends)
+
     def all_to_all(self, sends):  # sends[i][d] = chunks from shard i for shard d  ->  recvs[d] = all chunks for d
         return [[c for i in range(self.n) for c in _chunks(sends[i][d])] for d in range(self.n)]
 
@@ -141,17 +146,35 @@ class DistExchange:
     # cut into rounds of at most ROUND_BYTES per rank.
     ROUND_BYTES = 1 << 30
 
-    def all_to_all(self, sends):
+    def exchange(self, sends, stats):
+        """One all-gather carries this level's send counts AND the statistics of the previous
+        expansion (a collective and a device sync fewer per BFS level).  Returns the summed
+        statistics and a `deliver` closure that performs the payload all-to-all."""
         torch, dist = self.torch, self.dist
         (mine,) = sends  # one engine per process: mine[d] = chunks for destination d
-        P, me = self.world, self.rank
+        (st,) = stats
+        P = self.world
         chunks = [_chunks(x) for x in mine]
+        counts = [sum(int(c.shape[0]) for c in cs) for cs in chunks]
+        row = torch.tensor(counts + [int(x) for x in st], dtype=torch.int64, device=self.device)
+        rows = [torch.empty_like(row) for _ in range(P)]
+        dist.all_gather(rows, row)                       # (gloo has no all_gather_into_tensor)
+        m = torch.stack(rows).cpu()
+        allc = m[:, :P]                                  # allc[s][d]: records s sends to d
+        global_stats = m[:, P:].sum(dim=0).numpy()
+        return global_stats, lambda: self._deliver(chunks, allc)
+
+    def all_to_all(self, sends):  # counts exchange + payload, without piggy-backed statistics
+        _, deliver = self.exchange(sends, [np.zeros(N_STATS, dtype=np.int64)])
+        return deliver()
+
+    def _deliver(self, chunks, allc):
+        torch, dist = self.torch, self.dist
+        P, me = self.world, self.rank
         words = next((int(c.shape[1]) for cs in chunks for c in cs), 1)
         dtype = next((c.dtype for cs in chunks for c in cs), torch.int64)
-        cnt = torch.tensor([sum(int(c.shape[0]) for c in cs) for cs in chunks], dtype=torch.int64, device=self.device)
-        rows = [torch.empty_like(cnt) for _ in range(P)]
-        dist.all_gather(rows, cnt)                       # (gloo has no all_gather_into_tensor)
-        allc = torch.stack(rows).cpu()                   # allc[s][d]: records s sends to d
+        if int(allc.max().item()) == 0:
+            return [[]]                                  # nothing moves this level (every successor was local)
         per_dst = [torch.cat(cs, dim=0) if len(cs) > 1 else (cs[0] if cs else torch.empty((0, words), dtype=dtype,
                    device=self.device)) for cs in chunks]
         budget = max(1, self.ROUND_BYTES // (words * 8 * P))  # records per (source, destination) per round
@@ -230,22 +253,24 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
             return True, 0
         return False, int(st[0])
 
-    st = exchange.all_reduce_sum([e.begin() for e in engines])
-    _, new = absorb(st, 0)
-    levels.append(new)
-    depth = 1
-    if progress:
-        progress(dict(depth=depth, new_states=new, generated=generated, distinct=sum(levels)))
+    # The statistics of expansion k travel with the send counts of expansion k+1 (one all-gather),
+    # so expansion k+1 has already run locally when its predecessor's verdict becomes known: after
+    # a stop, or once the global frontier is empty, that speculative expansion is simply not
+    # counted (on an empty frontier it did nothing at all).
+    pending = [e.begin() for e in engines]   # per-engine statistics not yet reduced ...
+    pending_depth = 0                        # ... of the expansion of this level (0: Init's insertion)
+    depth = 0                                # levels recorded so far
     max_levels = cfg.max_levels or (1 << 62)
-    stopped = False
-    while new > 0 and depth < max_levels:
-        sends = [e.expand() for e in engines]
-        recvs = exchange.all_to_all(sends)
-        for e, rs in zip(engines, recvs):
-            for r in rs:
-                e.insert(r)
-        st = exchange.all_reduce_sum([e.finish() for e in engines])
-        stopped, produced = absorb(st, depth)
+    new = 0
+    while True:
+        # the engines hold level depth+1 (complete); like kmc_run, level l is expanded iff l < max_levels
+        can_expand = depth + 1 < max_levels
+        if can_expand:
+            sends = [e.expand() for e in engines]
+            st, deliver = exchange.exchange(sends, pending)
+        else:
+            st, deliver = exchange.all_reduce_sum(pending), None
+        stopped, produced = absorb(st, pending_depth)
         if stopped:
             break
         new = produced
@@ -255,6 +280,14 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
         levels.append(new)
         if progress:
             progress(dict(depth=depth, new_states=new, generated=generated, distinct=sum(levels)))
+        if not can_expand:
+            break
+        recvs = deliver()
+        for e, rs in zip(engines, recvs):
+            for r in rs:
+                e.insert(r)
+        pending = [e.finish() for e in engines]
+        pending_depth = depth
     if depth >= max_levels and new > 0 and verdict == "ok":
         verdict = "level_limit"  # (the unexpanded last frontier is not invariant-checked in sharded mode)
     local = [e.result() for e in engines]

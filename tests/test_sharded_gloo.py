@@ -171,3 +171,20 @@ def test_exchange_in_many_small_rounds():
     out = _run_world(kw, world=2, round_bytes=16 * 8 * 2 * 8)  # 8 records per pair per round
     o = kmo.Run(kmo.make_config("Kip320", N=2, L=2, R=2, E=2))
     assert out[0]["levels"] == o.levels and out[0]["generated"] == o.generated and out[0]["verdict"] == "ok"
+
+
+def test_level_limit_and_deadlock_in_sharded_mode():
+    # max_levels: levels 1..M recorded, level M not expanded; deadlock checking stops at the first
+    # level that holds a state without successors — both decided identically on every rank
+    kw = dict(model="Kip320", n_replicas=2, log_size=2, max_records=2, max_leader_epoch=2, invariants=("TypeOk",),
+              max_levels=7)
+    out = _run_world(kw, world=2)
+    o = kmo.Run(kmo.make_config("Kip320", N=2, L=2, R=2, E=2))
+    assert out[0]["verdict"] == out[1]["verdict"] == "level_limit"
+    assert out[0]["levels"] == o.levels[:7] and out[0]["depth"] == 7
+    kw = dict(model="Kip320", n_replicas=2, log_size=1, max_records=1, max_leader_epoch=1, invariants=("TypeOk",),
+              check_deadlock=True)
+    out = _run_world(kw, world=2)
+    od = kmo.Run(kmo.make_config("Kip320", N=2, L=1, R=1, E=1, check_deadlock=True))
+    assert out[0]["verdict"] == out[1]["verdict"] == "deadlock" == od.verdict
+    assert out[0]["levels"] == od.levels
