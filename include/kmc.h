@@ -41,12 +41,19 @@ extern "C" {
 #define KMC_KIP279 4                  /* Kip279.tla                                            */
 #define KMC_KIP320 5                  /* Kip320.tla                                            */
 #define KMC_KIP320_FIRST_TRY 6        /* Kip320FirstTry.tla                                    */
+#define KMC_ASYNC_ISR 7               /* AsyncIsr.tla under the state constraint of models/MCAsyncIsr.tla (the spec is
+                                         unbounded, AsyncIsr.tla:40-56,117): n_replicas (<= 6; replica 0 is `Leader`,
+                                         :24), log_size = MaxOffset (:25), max_leader_epoch = MaxVersion (<= 7) */
 
 /* invariant bits (invariant_mask) */
 #define KMC_INV_TYPEOK 1u        /* TypeOk      KafkaReplication.tla:101 / FiniteReplicatedLog.tla:95 / IdSequence.tla:43 */
 #define KMC_INV_WEAKISR 2u       /* WeakIsr     KafkaReplication.tla:320 */
 #define KMC_INV_STRONGISR 4u     /* StrongIsr   KafkaReplication.tla:334 */
 #define KMC_INV_LEADERINISR 8u   /* LeaderInIsr KafkaReplication.tla:345 */
+/* KMC_ASYNC_ISR reuses the bit positions: 1 TypeOk (AsyncIsr.tla:62), 2 ValidHighWatermark (:161),
+ * 4 LeaderOffsetInRange (models/MCAsyncIsr.tla; not in the reference) */
+#define KMC_INV_VALIDHIGHWATERMARK 2u
+#define KMC_INV_LEADEROFFSETINRANGE 4u
 
 #define KMC_MAX_KINDS 16
 #define KMC_MAX_SHARDS 8
@@ -102,6 +109,10 @@ typedef struct kmc_level_info {
     uint64_t generated_level[KMC_MAX_KINDS]; /* successors generated per action kind */
     uint64_t violation_count[4]; /* states of the EXPANDED level (depth-1) violating each invariant */
     uint64_t violation_fp[4];    /* smallest violating fingerprint per invariant, 0 = none */
+    uint64_t outside_violation_count[4]; /* KMC_ASYNC_ISR: successors (depth) OUTSIDE the state constraint violating
+                                            each invariant, counted per generation: TLC checks invariants on them
+                                            although it neither fingerprints nor explores them [TLC-recall] */
+    uint64_t outside_violation_fp[4];
     uint64_t deadlocks_level;    /* states of the expanded level without successors */
     uint64_t send_filtered;      /* n_shards>1: remote successors the sender-side duplicate filter did not ship */
     uint32_t error_flags;        /* 1 frontier full, 2 table full, 4 send area full */
@@ -164,6 +175,10 @@ const char* kmc_last_error(void);
  *     then globals: [0] nextRecordId [1] nextLeaderEpoch [2] quorum.leaderEpoch+1 [3] quorum.leader+1
  *       [4] quorum.isr, then for e in 0..MaxLeaderEpoch: leader+1, isr of the request with that epoch
  *       (zeros while e >= nextLeaderEpoch);
+ *   AsyncIsr: [0] controllerState.isr [1] .version [2] leaderState.isr [3] .version [4] .pendingIsr
+ *       [5] .pendingVersion+1 (Nil -> 0) [6+r] .offsets[r]; then requests: per version 0..MaxVersion a
+ *       bitset over isr masks (ceil(2^N/8) bytes); then updates: per version 1..MaxVersion+1 the isr
+ *       written at that version (0 while version > controllerState.version);
  *   FiniteReplicatedLog: per replica [endOffset, record(0 = Nil | 1..K) x LogSize];
  *   IdSequence: nextId as 8 little-endian bytes. */
 uint64_t kmc_state_words(kmc_handle* h);
@@ -188,7 +203,8 @@ int kmc_witness(kmc_handle* h, uint64_t* words);
 const char* kmc_model_name(int32_t model);
 const char* kmc_action_name(int32_t model, int32_t kind);
 int32_t kmc_action_count(int32_t model);
-const char* kmc_invariant_name(int32_t index);
+const char* kmc_invariant_name(int32_t index);                      /* Kafka-family names */
+const char* kmc_model_invariant_name(int32_t model, int32_t index); /* per model (KMC_ASYNC_ISR has its own) */
 
 /* --- level-step interface for the multi-GPU driver (n_shards > 1) ---------------------------
  * One BFS level = kmc_step_expand (bucket successors by owner into per-destination send

@@ -20,9 +20,21 @@ MODELS = {
     "Kip279": 4,
     "Kip320": 5,
     "Kip320FirstTry": 6,
+    "AsyncIsr": 7,      # under the state constraint of models/MCAsyncIsr.tla
 }
 INVARIANTS = {"TypeOk": 1, "WeakIsr": 2, "StrongIsr": 4, "LeaderInIsr": 8}
 INVARIANT_NAMES = ("TypeOk", "WeakIsr", "StrongIsr", "LeaderInIsr")
+# AsyncIsr reuses the bit positions (include/kmc.h): TypeOk, ValidHighWatermark, LeaderOffsetInRange
+ASYNC_INVARIANTS = {"TypeOk": 1, "ValidHighWatermark": 2, "LeaderOffsetInRange": 4}
+ASYNC_INVARIANT_NAMES = ("TypeOk", "ValidHighWatermark", "LeaderOffsetInRange", "?")
+
+
+def invariant_bits(model: str) -> dict:
+    return ASYNC_INVARIANTS if model == "AsyncIsr" else INVARIANTS
+
+
+def invariant_names(model: str) -> tuple:
+    return ASYNC_INVARIANT_NAMES if model == "AsyncIsr" else INVARIANT_NAMES
 VERDICTS = ("ok", "invariant", "deadlock", "table_full", "frontier_full", "level_limit", "error")
 
 
@@ -42,7 +54,8 @@ class KmcLevelInfo(C.Structure):
     _fields_ = [("depth", C.c_uint64), ("new_states", C.c_uint64), ("generated_total", C.c_uint64),
                 ("distinct_total", C.c_uint64), ("seconds", C.c_double),
                 ("generated_level", C.c_uint64 * KMC_MAX_KINDS), ("violation_count", C.c_uint64 * 4),
-                ("violation_fp", C.c_uint64 * 4), ("deadlocks_level", C.c_uint64), ("send_filtered", C.c_uint64),
+                ("violation_fp", C.c_uint64 * 4), ("outside_violation_count", C.c_uint64 * 4),
+                ("outside_violation_fp", C.c_uint64 * 4), ("deadlocks_level", C.c_uint64), ("send_filtered", C.c_uint64),
                 ("error_flags", C.c_uint32), ("pad_", C.c_uint32)]
 
 
@@ -87,6 +100,7 @@ SYMBOLS = [
     ("kmc_action_name", C.c_char_p, [C.c_int32, C.c_int32]),
     ("kmc_action_count", C.c_int32, [C.c_int32]),
     ("kmc_invariant_name", C.c_char_p, [C.c_int32]),
+    ("kmc_model_invariant_name", C.c_char_p, [C.c_int32, C.c_int32]),
     ("kmc_step_begin", C.c_int, [_H]),
     ("kmc_step_expand", C.c_int, [_H, C.POINTER(C.c_uint64)]),
     ("kmc_step_send_buffer", C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),

@@ -1,7 +1,9 @@
 """A reader for the subset of TLC's model-configuration (.cfg) syntax these specs need
 [TLC-recall]: CONSTANT(S), INIT, NEXT, SPECIFICATION, INVARIANT(S), CHECK_DEADLOCK, and
-`\\*` / `(* *)` comments.  SYMMETRY / CONSTRAINT / VIEW / PROPERTY are rejected: each one
-changes the set of distinct states (or asks for liveness), which this checker does not do.
+`\\*` / `(* *)` comments.  SYMMETRY / VIEW / PROPERTY are rejected: each one changes the set of
+distinct states (or asks for liveness), which this checker does not do.  CONSTRAINT is accepted in
+exactly one form — `CONSTRAINT StateConstraint` with root module MCAsyncIsr (models/MCAsyncIsr.tla),
+whose constraint is lowered into the AsyncIsr kernels (AsyncIsr.tla is unbounded without it).
 
 The reference repository ships no .cfg files (its .gitignore excludes *.toolbox), so the
 `models/*.cfg` twins in this repo are authored here; names bind to
@@ -18,8 +20,9 @@ from .checker import CheckerConfig
 KEYWORDS = {"CONSTANT", "CONSTANTS", "INIT", "NEXT", "SPECIFICATION", "INVARIANT", "INVARIANTS",
             "CHECK_DEADLOCK", "SYMMETRY", "CONSTRAINT", "CONSTRAINTS", "ACTION_CONSTRAINT", "VIEW",
             "PROPERTY", "PROPERTIES", "ALIAS", "POSTCONDITION"}
-UNSUPPORTED = {"SYMMETRY", "CONSTRAINT", "CONSTRAINTS", "ACTION_CONSTRAINT", "VIEW", "PROPERTY", "PROPERTIES",
-               "ALIAS", "POSTCONDITION"}
+UNSUPPORTED = {"SYMMETRY", "ACTION_CONSTRAINT", "VIEW", "PROPERTY", "PROPERTIES", "ALIAS", "POSTCONDITION"}
+# root modules whose lowered model carries another name: the MC module adds the state constraint
+MODULE_TO_MODEL = {"MCAsyncIsr": "AsyncIsr"}
 
 
 class CfgError(ValueError):
@@ -33,6 +36,7 @@ class ModelCfg:
     next: Optional[str] = None
     specification: Optional[str] = None
     invariants: List[str] = field(default_factory=list)
+    constraints: List[str] = field(default_factory=list)
     check_deadlock: Optional[bool] = None
 
 
@@ -83,6 +87,8 @@ def parse_cfg(text: str) -> ModelCfg:
             cfg.specification = t
         elif section in ("INVARIANT", "INVARIANTS"):
             cfg.invariants.append(t)
+        elif section in ("CONSTRAINT", "CONSTRAINTS"):
+            cfg.constraints.append(t)
         elif section == "CHECK_DEADLOCK":
             if t not in ("TRUE", "FALSE"):
                 raise CfgError("CHECK_DEADLOCK takes TRUE or FALSE")
@@ -95,11 +101,18 @@ def parse_cfg(text: str) -> ModelCfg:
 
 def to_checker_config(module: str, cfg: ModelCfg, **overrides) -> CheckerConfig:
     """Bind a parsed .cfg to the lowered model of `module` (the root module's name)."""
-    from ._native import MODELS, INVARIANTS
-    if module not in MODELS:
-        raise CfgError(f"module {module!r} has no lowered model; known: {sorted(MODELS)}")
+    from ._native import MODELS, INVARIANTS, ASYNC_INVARIANTS
+    if module == "AsyncIsr":
+        raise CfgError("AsyncIsr.tla is unbounded (version: Nat, offsets: [Replicas -> Nat]); check it through "
+                       "the root module models/MCAsyncIsr.tla, which adds CONSTRAINT StateConstraint")
+    model = MODULE_TO_MODEL.get(module, module)
+    if model not in MODELS:
+        raise CfgError(f"module {module!r} has no lowered model; known: "
+                       f"{sorted((set(MODELS) - {'AsyncIsr'}) | set(MODULE_TO_MODEL))}")
     c = cfg.constants
-    kw: Dict[str, object] = dict(model=module)
+    kw: Dict[str, object] = dict(model=model)
+    if cfg.constraints and model != "AsyncIsr":
+        raise CfgError("CONSTRAINT is not supported for this module (it changes the distinct-state count)")
 
     def need(name):
         if name not in c:
@@ -109,6 +122,20 @@ def to_checker_config(module: str, cfg: ModelCfg, **overrides) -> CheckerConfig:
     if module == "IdSequence":
         kw["max_id"] = int(need("MaxId"))
         allowed_inv = {"TypeOk"}
+    elif model == "AsyncIsr":
+        # AsyncIsr.tla:22-29 + MaxVersion / StateConstraint of models/MCAsyncIsr.tla
+        reps = need("Replicas")
+        if not isinstance(reps, list) or len(set(map(str, reps))) != len(reps):
+            raise CfgError("Replicas must be a set of distinct model values")
+        if str(need("Leader")) not in map(str, reps):
+            raise CfgError("Leader must be an element of Replicas (ASSUME Leader \\in Replicas, AsyncIsr.tla:29)")
+        if int(need("MaxOffset")) <= 0:
+            raise CfgError("MaxOffset must be positive (ASSUME MaxOffset > 0, AsyncIsr.tla:28)")
+        if cfg.constraints != ["StateConstraint"]:
+            raise CfgError("MCAsyncIsr needs exactly `CONSTRAINT StateConstraint`: AsyncIsr is unbounded without it")
+        # the engine numbers the replicas with Leader first; the others keep their order
+        kw.update(n_replicas=len(reps), log_size=int(need("MaxOffset")), max_leader_epoch=int(need("MaxVersion")))
+        allowed_inv = set(ASYNC_INVARIANTS)
     elif module == "FiniteReplicatedLog":
         reps, recs = need("Replicas"), need("LogRecords")
         if not isinstance(reps, list) or not isinstance(recs, list):

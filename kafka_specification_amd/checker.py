@@ -20,9 +20,9 @@ from . import _native as nat
 class CheckerConfig:
     model: str                              # root module, e.g. "Kip320"
     n_replicas: int = 3                     # |Replicas|          KafkaReplication.tla:33
-    log_size: int = 2                       # LogSize             :34
+    log_size: int = 2                       # LogSize             :34   (AsyncIsr: MaxOffset, AsyncIsr.tla:25)
     max_records: int = 2                    # MaxRecords          :35
-    max_leader_epoch: int = 1               # MaxLeaderEpoch      :36
+    max_leader_epoch: int = 1               # MaxLeaderEpoch      :36   (AsyncIsr: MaxVersion of the state constraint)
     n_log_records: int = 2                  # |LogRecords|        FiniteReplicatedLog.tla:24 (standalone)
     max_id: int = 10                        # MaxId               IdSequence.tla:22 (standalone)
     invariants: Sequence[str] = ("TypeOk",)
@@ -43,10 +43,11 @@ class CheckerConfig:
         if self.model not in nat.MODELS:
             raise ValueError(f"unknown module {self.model!r}; known: {sorted(nat.MODELS)}")
         mask = 0
+        bits = nat.invariant_bits(self.model)
         for name in self.invariants:
-            if name not in nat.INVARIANTS:
-                raise ValueError(f"unknown invariant {name!r}")
-            mask |= nat.INVARIANTS[name]
+            if name not in bits:
+                raise ValueError(f"unknown invariant {name!r} for {self.model}; known: {sorted(bits)}")
+            mask |= bits[name]
         return nat.KmcConfig(
             model=nat.MODELS[self.model], n_replicas=self.n_replicas, log_size=self.log_size,
             max_records=self.max_records, max_leader_epoch=self.max_leader_epoch,
@@ -162,12 +163,13 @@ class ModelChecker:
         buf = (C.c_uint64 * max(nlev, 1))()
         self._lib.kmc_level_sizes(self._h, buf, nlev)
         names = self.action_names()
+        inv_names = nat.invariant_names(self.cfg.model)
         return CheckResult(
             generated=int(r.generated), distinct=int(r.distinct), depth=int(r.depth),
             queue_left=int(r.queue_left), verdict=nat.VERDICTS[r.verdict],
-            violated_invariant=(nat.INVARIANT_NAMES[r.violated_invariant] if r.violated_invariant >= 0 else None),
+            violated_invariant=(inv_names[r.violated_invariant] if r.violated_invariant >= 0 else None),
             violation_depth=int(r.violation_depth),
-            violation_count={nat.INVARIANT_NAMES[k]: int(r.violation_count[k]) for k in range(4)},
+            violation_count={inv_names[k]: int(r.violation_count[k]) for k in range(4) if inv_names[k] != "?"},
             violation_fp=int(r.violation_fp), deadlock_states=int(r.deadlock_states),
             action_generated={names[k]: int(r.action_generated[k]) for k in range(len(names))},
             levels=[int(buf[i]) for i in range(nlev)],

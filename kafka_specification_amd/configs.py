@@ -50,6 +50,10 @@ def precompile_list():
         out.append(dict(model="IdSequence", max_id=M))
     for K in (1, 2, 3, 4):
         out.append(dict(model="FiniteReplicatedLog", n_replicas=2, log_size=4, n_log_records=K))
+    # AsyncIsr under the state constraint of models/MCAsyncIsr.tla: (N, MaxOffset, MaxVersion)
+    for (N, M, V) in [(1, 1, 3), (1, 5, 3), (1, 9, 3), (1, 3, 2), (2, 1, 1), (2, 2, 2), (3, 1, 2), (3, 2, 2), (3, 2, 3),
+                      (4, 1, 2), (3, 3, 4), (4, 2, 3), (5, 1, 2), (2, 6, 7), (2, 3, 1), (4, 2, 2), (2, 3, 7), (4, 3, 4)]:
+        out.append(dict(model="AsyncIsr", n_replicas=N, log_size=M, max_leader_epoch=V))
     for c in BASELINE_CONFIGS.values():
         out.append({k: v for k, v in c.items() if k != "invariants"})
     seen, uniq = set(), []

@@ -5,7 +5,7 @@
 //       [-frontier STATES] [-device D] [-notrace] Spec.tla
 //
 // [TLC-recall] flag names and output lines follow tlc2.TLC; TLC itself is not part of the
-// reference repository.  The module name selects one of the seven lowered models; constants
+// reference repository.  The module name selects one of the lowered models; constants
 // and invariants come from the .cfg (CONSTANT(S), INIT, NEXT, SPECIFICATION, INVARIANT(S),
 // CHECK_DEADLOCK).  No TLA+ is parsed.
 #include <cstdio>
@@ -22,7 +22,7 @@ namespace {
 
 struct Cfg {
     std::map<std::string, std::string> constants;  // raw value text ("{b1, b2}" or "6")
-    std::vector<std::string> invariants;
+    std::vector<std::string> invariants, constraints;
     int check_deadlock = 1;  // TLC's default
     std::string error;
 };
@@ -84,7 +84,7 @@ Cfg parse_cfg(const std::string& text) {
     for (size_t i = 0; i < t.size(); ++i) {
         const std::string& w = t[i];
         if (is_keyword(w)) {
-            if (w == "SYMMETRY" || w == "VIEW" || w.rfind("CONSTRAINT", 0) == 0 || w == "ACTION_CONSTRAINT" ||
+            if (w == "SYMMETRY" || w == "VIEW" || w == "ACTION_CONSTRAINT" ||
                 w.rfind("PROPERT", 0) == 0 || w == "ALIAS" || w == "POSTCONDITION") {
                 c.error = w + " is not supported (it changes the distinct-state count or asks for liveness)";
                 return c;
@@ -108,6 +108,8 @@ Cfg parse_cfg(const std::string& text) {
             if (w != "Spec") c.error = "only SPECIFICATION Spec is known";
         } else if (section == "INVARIANT" || section == "INVARIANTS") {
             c.invariants.push_back(w);
+        } else if (section == "CONSTRAINT" || section == "CONSTRAINTS") {
+            c.constraints.push_back(w);  // only MCAsyncIsr's StateConstraint is lowered (checked by main)
         } else if (section == "CHECK_DEADLOCK") {
             c.check_deadlock = w == "TRUE";
         } else {
@@ -157,6 +159,28 @@ void print_state(const kmc_config& c, const uint8_t* b) {
         return;
     }
     const int N = c.n_replicas, L = c.log_size, E = c.max_leader_epoch;
+    if (c.model == KMC_ASYNC_ISR) {  // AsyncIsr.tla:31-35; replica 1 is `Leader`
+        const int rb = ((1 << N) + 7) / 8;
+        const uint8_t* q = b + 6 + N;
+        const uint8_t* u = q + (E + 1) * rb;
+        printf("/\\ controllerState = [isr |-> %s, version |-> %d]\n", bitset_names(b[0], N, "r").c_str(), b[1]);
+        printf("/\\ leaderState = [isr |-> %s, version |-> %d, pendingIsr |-> %s, pendingVersion |-> %d, offsets |-> (",
+               bitset_names(b[2], N, "r").c_str(), b[3], bitset_names(b[4], N, "r").c_str(), b[5] - 1);
+        for (int r = 0; r < N; ++r) printf("%sr%d :> %d", r ? " @@ " : "", r + 1, b[6 + r]);
+        printf(")]\n/\\ requests = {");
+        bool first = true;
+        for (int v = 0; v <= E; ++v)
+            for (int m = 0; m < (1 << N); ++m)
+                if (q[v * rb + (m >> 3)] >> (m & 7) & 1) {
+                    printf("%s[isr |-> %s, version |-> %d]", first ? "" : ", ", bitset_names(m, N, "r").c_str(), v);
+                    first = false;
+                }
+        printf("}\n/\\ updates = {");
+        for (int v = 1; v <= b[1] && v <= E + 1; ++v)
+            printf("%s[isr |-> %s, version |-> %d]", v > 1 ? ", " : "", bitset_names(u[v - 1], N, "r").c_str(), v);
+        printf("}\n");
+        return;
+    }
     if (c.model == KMC_FINITE_REPLICATED_LOG) {
         printf("logs = (");
         for (int r = 0; r < N; ++r) {
@@ -252,6 +276,15 @@ int main(int argc, char** argv) {
     c.model = -1;
     for (int m = 0; m <= 6; ++m)
         if (module == kmc_model_name(m)) c.model = m;
+    if (module == "MCAsyncIsr") c.model = KMC_ASYNC_ISR;  // models/MCAsyncIsr.tla = AsyncIsr + the state constraint
+    if (module == "AsyncIsr") {
+        fprintf(stderr, "Error: AsyncIsr.tla is unbounded; check it through models/MCAsyncIsr.tla (CONSTRAINT StateConstraint)\n");
+        return 2;
+    }
+    if (!cfg.constraints.empty() && c.model != KMC_ASYNC_ISR) {
+        fprintf(stderr, "Error: CONSTRAINT is not supported for this module (it changes the distinct-state count)\n");
+        return 2;
+    }
     if (c.model < 0) { fprintf(stderr, "Error: module %s has no lowered model\n", module.c_str()); return 2; }
     auto need = [&](const char* name) -> std::string {
         auto it = cfg.constants.find(name);
@@ -260,6 +293,19 @@ int main(int argc, char** argv) {
     };
     if (c.model == KMC_IDSEQUENCE) {
         c.max_id = atoll(need("MaxId").c_str());
+    } else if (c.model == KMC_ASYNC_ISR) {
+        const std::string reps = need("Replicas"), leader = need("Leader");
+        if (reps.find(leader) == std::string::npos) {
+            fprintf(stderr, "Error: Leader must be an element of Replicas (AsyncIsr.tla:29)\n");
+            return 2;
+        }
+        if (cfg.constraints.size() != 1 || cfg.constraints[0] != "StateConstraint") {
+            fprintf(stderr, "Error: MCAsyncIsr needs exactly `CONSTRAINT StateConstraint`: AsyncIsr is unbounded without it\n");
+            return 2;
+        }
+        c.n_replicas = set_size(reps);
+        c.log_size = atoi(need("MaxOffset").c_str());
+        c.max_leader_epoch = atoi(need("MaxVersion").c_str());
     } else if (c.model == KMC_FINITE_REPLICATED_LOG) {
         c.n_replicas = set_size(need("Replicas"));
         c.n_log_records = set_size(need("LogRecords"));
@@ -279,7 +325,7 @@ int main(int argc, char** argv) {
     for (const std::string& inv : cfg.invariants) {
         int bit = -1;
         for (int k = 0; k < 4; ++k)
-            if (inv == kmc_invariant_name(k)) bit = k;
+            if (inv == kmc_model_invariant_name(c.model, k)) bit = k;
         if (bit < 0 || (c.model <= KMC_FINITE_REPLICATED_LOG && bit != 0)) {
             fprintf(stderr, "Error: unknown invariant %s for module %s\n", inv.c_str(), module.c_str());
             return 2;
@@ -300,7 +346,7 @@ int main(int argc, char** argv) {
     if (r.verdict == KMC_V_OK) {
         printf("Model checking completed. No error has been found.\n");
     } else if (r.verdict == KMC_V_INVARIANT) {
-        printf("Error: Invariant %s is violated%s.\n", kmc_invariant_name(r.violated_invariant),
+        printf("Error: Invariant %s is violated%s.\n", kmc_model_invariant_name(c.model, r.violated_invariant),
                r.violation_depth == 1 ? " by the initial state" : "");
         rc = 12;
     } else if (r.verdict == KMC_V_DEADLOCK) {

@@ -79,6 +79,7 @@ typedef unsigned int u32;
 #define KMC_FLAG_X_NOINV 64u      // tuning: skip invariants
 #define KMC_FLAG_X_PLAINSTORE 128u  // tuning: claim with a plain store instead of atomicCAS (racy, timing only)
 #define KMC_FLAG_DRY_RAND 256u  // tuning: DRY mode does one load from an uncorrelated random table slot
+#define KMC_FLAG_ENUM_MATCH 512u  // ENUM lists only the successors whose fingerprint is KmcArgs::match_fp, with their parent's fp
 #define KMC_FLAG_META 2u  // the ring carries a meta plane (predecessor fp for traces / kind for ENUM)
 
 // A counter alone on its 128-byte line.  Device-scope atomics serialise per cache line at the
@@ -101,6 +102,8 @@ struct alignas(128) KmcLevelCtl {
     u64 deadlock_fp_inv;
     u64 enum_count;                  // ENUM: records written
     u64 send_filtered;               // SHARDED: remote successors dropped by the sender-side filter
+    u64 oviol_count[4];              // successors OUTSIDE the state constraint violating invariant k (per generation)
+    u64 oviol_fp_inv[4];             // max over those of ~fp
     u64 prof[8];                     // KMC_PROFILE: summed per-wave s_memtime ticks per phase (tuning aid)
     u32 err;
     u32 pad;
@@ -132,6 +135,7 @@ struct KmcArgs {
     u32 nshards;
     u32 shard;         // this handle's shard id (SHARDED mode keeps its own successors local)
     u32 rec_words;     // exchange record size in words: W, or W+1 when predecessor fingerprints travel (trace)
+    u64 match_fp;      // ENUM with KMC_FLAG_ENUM_MATCH: list only successors with this fingerprint (meta = parent fp)
 };
 
 // ----------------------------------------------------------------------------------------
@@ -213,7 +217,7 @@ KMC_HD inline u32 kmc_owner(u64 fp, u32 nshards) { return (u32)((fp >> 40) % nsh
 // ========================================================================================
 template <long long MAXID> struct KmcIdSequence {
     static constexpr int W = 1, NKINDS = 1, NINST = 1;
-    static constexpr bool HAS_EXTRA = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false;
     struct Pre { u64 nextId; };
     static KMC_DEV void init(u64* w) { w[0] = 0; }  // IdSequence.tla:37
     static KMC_DEV Pre extract(const u64* s) { return Pre{s[0]}; }
@@ -237,7 +241,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
     static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_FINITE_REPLICATED_LOG, N, L, 0, 0, K);
     static_assert(Y.valid, "FiniteReplicatedLog parameters cannot be packed");
     static constexpr int W = Y.W, NKINDS = 3;
-    static constexpr bool HAS_EXTRA = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false;
     static constexpr int C_APPEND = N * K, C_TRUNC = N * L, C_REPL = N * (N - 1);
     static constexpr int NINST = C_APPEND + C_TRUNC + C_REPL;
     static constexpr u64 MR = (1ull << Y.BR) - 1;
@@ -306,6 +310,140 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
 };
 
 // ========================================================================================
+// AsyncIsr.tla standalone, under the state constraint of models/MCAsyncIsr.tla (layout: kmc_layout.h)
+// ========================================================================================
+template <int N, int MO, int V> struct KmcAsyncIsr {
+    static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_ASYNC_ISR, N, MO, 0, V, 0);
+    static_assert(Y.valid, "AsyncIsr parameters cannot be packed (need N <= 6, MaxVersion <= 7)");
+    static constexpr int W = Y.W, NKINDS = 7;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = true;
+    static constexpr int NS = 1 << N;  // isr masks = request bits per version
+    // Next (AsyncIsr.tla:152-159) flattened into instances, one per binding of each disjunct's \E
+    static constexpr int B0 = 0;             // ControllerShrinkIsr        (replica # Leader)
+    static constexpr int B1 = B0 + (N - 1);  // ControllerHandleRequest    (message.isr; message.version = controller's)
+    static constexpr int B2 = B1 + NS;       // LeaderRequestShrinkIsr     (replica # Leader)
+    static constexpr int B3 = B2 + (N - 1);  // LeaderRequestExpandIsr     (replica)
+    static constexpr int B4 = B3 + N;        // LeaderWrite
+    static constexpr int B5 = B4 + 1;        // LeaderHandleUpdate         (update.version 1..MaxVersion)
+    static constexpr int B6 = B5 + V;        // FollowerReplicate          (replica # Leader)
+    static constexpr int NINST = B6 + (N - 1);
+    static constexpr u32 FULL = (1u << N) - 1;
+
+    struct Pre {
+        u32 cisr, cver, lisr, lver, pisr, pver1, hw;
+        u32 off[N];
+        u64 reqcur;  // the requests whose version is controllerState.version, as a bitset over isr masks
+    };
+
+    static KMC_DEV void init(u64* w) {  // Init, :137-150
+        for (int k = 0; k < W; ++k) w[k] = 0;
+        kmc_setbits(w, Y.a_cisr, N, FULL);
+        kmc_setbits(w, Y.a_lisr, N, FULL);  // version 0, pendingIsr {}, pendingVersion Nil (-> 0), offsets 0, no messages
+    }
+    static KMC_DEV Pre extract(const u64* s) {
+        Pre p;
+        p.cisr = (u32)kmc_getbits(s, Y.a_cisr, N);
+        p.cver = (u32)kmc_getbits(s, Y.a_cver, Y.BV);
+        p.lisr = (u32)kmc_getbits(s, Y.a_lisr, N);
+        p.lver = (u32)kmc_getbits(s, Y.a_lver, Y.BV);
+        p.pisr = (u32)kmc_getbits(s, Y.a_pisr, N);
+        p.pver1 = (u32)kmc_getbits(s, Y.a_pver, Y.BV);
+        // HighWatermark, :58-60 (Leader never leaves leaderState.isr, so the set is never empty)
+        const u32 potential = p.lisr | p.pisr;
+        p.hw = ~0u;
+        kmc_static_for<0, N>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            p.off[r] = (u32)kmc_getbits(s, Y.a_off[r], Y.BF);
+            if (potential >> r & 1u) p.hw = kmc_min(p.hw, p.off[r]);
+        });
+        p.reqcur = p.cver <= (u32)V ? kmc_getbits(s, Y.a_req + (int)p.cver * NS, NS) : 0ull;
+        return p;
+    }
+    static KMC_DEV void launder(Pre& p) {
+        kmc_launder(p.cisr); kmc_launder(p.cver); kmc_launder(p.lisr); kmc_launder(p.lver);
+        kmc_launder(p.pisr); kmc_launder(p.pver1); kmc_launder(p.hw); kmc_launder(p.reqcur);
+        for (int r = 0; r < N; ++r) kmc_launder(p.off[r]);
+    }
+    // the state constraint (NOT in the reference): offsets[Leader] <= MaxOffset /\ controllerState.version <= MaxVersion
+    static KMC_DEV bool in_model(const u64* t) {
+        return (u32)kmc_getbits(t, Y.a_off[0], Y.BF) <= (u32)MO && (u32)kmc_getbits(t, Y.a_cver, Y.BV) <= (u32)V;
+    }
+    static KMC_DEV void controller_write(u64* t, const Pre& p, u32 isr) {  // ControllerWriteIsr :68-70 + updates' (:78, :85)
+        kmc_setbits(t, Y.a_cisr, N, isr);
+        kmc_setbits(t, Y.a_cver, Y.BV, p.cver + 1);
+        kmc_setbits(t, Y.a_upd + (int)kmc_min(p.cver, (u32)V) * N, N, isr);  // the update of version cver+1
+    }
+    static KMC_DEV void leader_request(u64* t, const Pre& p, u32 isr) {  // :92-99 / :107-114
+        kmc_setbits(t, Y.a_req + (int)kmc_min(p.lver, (u32)V) * NS + (int)isr, 1, 1);
+        kmc_setbits(t, Y.a_pisr, N, p.pisr | isr);
+        kmc_setbits(t, Y.a_pver, Y.BV, p.lver + 1);
+    }
+    // Guards carry `version <= MaxVersion` / `offset <= MaxOffset`: states beyond the constraint are
+    // never expanded by the search, and this keeps a caller-supplied one from writing outside its fields.
+    template <int I> static KMC_DEV u32 inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
+        extra = 0;
+        for (int k = 0; k < W; ++k) t[k] = s[k];
+        if constexpr (I < B1) {  // ControllerShrinkIsr :72-79
+            constexpr int r = I - B0 + 1;
+            kind = 0;
+            controller_write(t, p, p.cisr & ~(1u << r));
+            return (kmc_bit(p.cisr, r) && p.cver <= (u32)V) ? 1u : 0u;
+        } else if constexpr (I < B2) {  // ControllerHandleRequest :81-86
+            constexpr int m = I - B1;
+            kind = 1;
+            controller_write(t, p, (u32)m);
+            return kmc_bit64(p.reqcur, m);
+        } else if constexpr (I < B3) {  // LeaderRequestShrinkIsr :88-100
+            constexpr int r = I - B2 + 1;
+            kind = 2;
+            leader_request(t, p, p.lisr & ~(1u << r));
+            return (kmc_bit(p.lisr, r) && p.lver <= (u32)V) ? 1u : 0u;
+        } else if constexpr (I < B4) {  // LeaderRequestExpandIsr :102-115
+            constexpr int r = I - B3;
+            kind = 3;
+            leader_request(t, p, p.lisr | (1u << r));
+            return (!kmc_bit(p.lisr, r) && p.off[r] >= p.hw && p.lver <= (u32)V) ? 1u : 0u;
+        } else if constexpr (I < B5) {  // LeaderWrite :117-119
+            kind = 4;
+            kmc_setbits(t, Y.a_off[0], Y.BF, p.off[0] + 1);
+            return p.off[0] <= (u32)MO ? 1u : 0u;
+        } else if constexpr (I < B6) {  // LeaderHandleUpdate :121-129
+            constexpr int v = I - B5 + 1;
+            kind = 5;
+            kmc_setbits(t, Y.a_lisr, N, kmc_getbits(s, Y.a_upd + (v - 1) * N, N));
+            kmc_setbits(t, Y.a_lver, Y.BV, v);
+            kmc_setbits(t, Y.a_pisr, N, 0);
+            kmc_setbits(t, Y.a_pver, Y.BV, 0);
+            return ((u32)v > p.lver && (u32)v <= p.cver) ? 1u : 0u;
+        } else {  // FollowerReplicate :131-135
+            constexpr int r = I - B6 + 1;
+            kind = 6;
+            kmc_setbits(t, Y.a_off[r], Y.BF, p.off[r] + 1);
+            return p.off[r] < p.off[0] ? 1u : 0u;
+        }
+    }
+    // bit 0 TypeOk :62-66 — every conjunct is a tautology of the representation except
+    //   pendingVersion \in Nat (:44), false while pendingVersion = Nil (:38), e.g. in Init (:146);
+    // bit 1 ValidHighWatermark :161-162;
+    // bit 2 LeaderOffsetInRange (models/MCAsyncIsr.tla, not in the reference): offsets[Leader] \in Offsets (:37)
+    static KMC_DEV u32 violated_pre(const Pre& p, u32 inv_mask) {
+        u32 bad = 0;
+        if ((inv_mask & 1u) && p.pver1 == 0) bad |= 1u;
+        if (inv_mask & 2u) {
+            bool ok = true;
+            kmc_static_for<0, N>([&](auto R) {
+                constexpr int r = decltype(R)::value;
+                ok = ok && (!(p.cisr >> r & 1u) || p.off[r] >= p.hw);
+            });
+            if (!ok) bad |= 2u;
+        }
+        if ((inv_mask & 4u) && p.off[0] > (u32)MO) bad |= 4u;
+        return bad;
+    }
+    static KMC_DEV u32 violated(const u64* t, u32 inv_mask) { return violated_pre(extract(t), inv_mask); }
+};
+
+// ========================================================================================
 // KafkaReplication.tla and the five modules that give it a Next
 // ========================================================================================
 template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
@@ -316,6 +454,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
     static constexpr bool K320 = MODEL == KMC_MODEL_KIP320;
     static constexpr int NKINDS = FIRST ? 10 : 9;
     static constexpr bool HAS_EXTRA = MODEL == KMC_MODEL_KIP279;  // Kip279.tla:47-51: two disjuncts can coincide
+    static constexpr bool HAS_CONSTRAINT = false;
     static constexpr int NP = N * (N - 1);  // ordered pairs of distinct replicas
     // action instances, in the order of the Next disjuncts (the index of the disjunct is
     // the "kind"): KafkaTruncateToHighWatermark.tla:33-42, Kip101.tla:49-58, Kip279.tla:53-62,
@@ -849,6 +988,18 @@ template <class M> struct KmcSink {
             }
     }
 
+    // A violating successor outside the state constraint (models with HAS_CONSTRAINT): it enters no
+    // table and no frontier, so it is counted per generation and identified by its fingerprint; the
+    // host fetches the state (and a parent) with an ENUM_MATCH pass over the expanded level.
+    static KMC_DEV void report_outside_violation(const KmcArgs& a, u32 bad, u64 fp) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (bad >> k & 1u) {
+                atomicAdd(&a.ctl->oviol_count[k], 1ull);
+                atomicMax(&a.ctl->oviol_fp_inv[k], ~fp);
+            }
+    }
+
     // Executed by the whole wave; lanes with valid=false only take part in the ballots.
     static KMC_DEV void process(const KmcArgs& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta) {
         const u64 fp = kmc_fingerprint<W>(t, a.seed);
@@ -919,7 +1070,7 @@ template <class M> struct KmcSink {
                 }
             }
         } else {  // KMC_MODE_ENUM
-            if (valid) {
+            if (valid && (!(a.flags & KMC_FLAG_ENUM_MATCH) || fp == a.match_fp)) {
                 const u64 pos = atomicAdd(&a.ctl->enum_count, 1ull);
                 if (pos < a.send_cap) {
                     u64* rec = a.send + pos * (u64)(W + 2);
@@ -1019,7 +1170,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #pragma unroll
         for (int k = 0; k < W; ++k) s[k] = valid ? a.fin[(u64)k * a.fin_stride + idx] : 0ull;
 #endif
-        const u64 parent = (a.flags & KMC_FLAG_TRACE) ? kmc_fingerprint<W>(s, a.seed) : 0ull;
+        const u64 parent = (a.flags & (KMC_FLAG_TRACE | KMC_FLAG_ENUM_MATCH)) ? kmc_fingerprint<W>(s, a.seed) : 0ull;
         typename M::Pre pre = M::extract(s);
 
         // Invariants of the states of THIS level (see KmcSink::report_violation)
@@ -1091,13 +1242,33 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
                 weight += __builtin_amdgcn_readfirstlane(x);
             }
             gen_lane += (lane == (u32)kind) ? weight : 0u;
-            if (e) {
-                const u32 pos = (head + count + kmc_rank_in(m)) & (KMC_RING - 1);
+            bool keep = e;
+            u64 mk = m;
+            if constexpr (M::HAS_CONSTRAINT) {
+                // TLC CONSTRAINT [TLC-recall, ModelChecker.doNext]: a successor outside the model counts
+                // as generated but is neither fingerprinted into the seen-set nor queued; its
+                // invariants ARE evaluated (each time it is generated: it is never "seen").
+                // ENUM lists the raw Next relation; the level-limit check pass (DRY) looks no further.
+                if (a.mode == KMC_MODE_LOCAL || a.mode == KMC_MODE_SHARDED) {
+                    const bool outside = e && !M::in_model(t);
+                    if (__ballot(outside)) {
+                        if (outside && a.inv_mask) {
+                            const u32 bad = M::violated(t, a.inv_mask);
+                            if (bad) KmcSink<M>::report_outside_violation(a, bad, kmc_fingerprint<W>(t, a.seed));
+                        }
+                        keep = e && !outside;
+                        mk = __ballot(keep);
+                    }
+                }
+            }
+            if (keep) {
+                const u32 pos = (head + count + kmc_rank_in(mk)) & (KMC_RING - 1);
 #pragma unroll
                 for (int k = 0; k < W; ++k) q[k * KMC_RING + pos] = t[k];
-                if (has_meta) q[W * KMC_RING + pos] = a.mode == KMC_MODE_ENUM ? (u64)kind : parent;
+                if (has_meta)
+                    q[W * KMC_RING + pos] = (a.mode == KMC_MODE_ENUM && !(a.flags & KMC_FLAG_ENUM_MATCH)) ? (u64)kind : parent;
             }
-            count += n;
+            count += __popcll(mk);
             if (count >= KMC_FLUSH_N) {
                 KMC_T(tf0);
                 flush(KMC_FLUSH_N);

@@ -46,8 +46,12 @@ int fail(int code, const char* fmt, ...) {
 
 const char* const MODEL_NAMES[] = {"IdSequence", "FiniteReplicatedLog", "KafkaTruncateToHighWatermark",
                                    "Kip101",     "Kip279",              "Kip320",
-                                   "Kip320FirstTry"};
+                                   "Kip320FirstTry", "AsyncIsr"};
 const char* const INV_NAMES[] = {"TypeOk", "WeakIsr", "StrongIsr", "LeaderInIsr"};
+// AsyncIsr.tla:62,161; LeaderOffsetInRange is defined in models/MCAsyncIsr.tla (not in the reference)
+const char* const INV_NAMES_ASYNC[] = {"TypeOk", "ValidHighWatermark", "LeaderOffsetInRange", "?"};
+const char* const KINDS_ASYNC[] = {"ControllerShrinkIsr", "ControllerHandleRequest", "LeaderRequestShrinkIsr",
+                                   "LeaderRequestExpandIsr", "LeaderWrite", "LeaderHandleUpdate", "FollowerReplicate"};
 
 const char* const KINDS_BASE[] = {"ControllerElectLeader", "ControllerShrinkIsr", "BecomeLeader",
                                   "LeaderExpandIsr",       "LeaderShrinkIsr",     "LeaderWrite",
@@ -94,6 +98,14 @@ bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::strin
         snprintf(buf, sizeof buf, "FiniteReplicatedLog_N%d_L%d_K%d", c.n_replicas, c.log_size, c.n_log_records);
         *name = buf;
         snprintf(buf, sizeof buf, "KmcFiniteReplicatedLog<%d,%d,%d>", c.n_replicas, c.log_size, c.n_log_records);
+        *inst = buf;
+        return true;
+    case KMC_ASYNC_ISR:  // log_size = MaxOffset, max_leader_epoch = MaxVersion (the constraint's bounds)
+        *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, 0, c.max_leader_epoch, 0);
+        if (!lay->valid || c.n_replicas < 1 || c.log_size < 1) return false;  // ASSUME MaxOffset > 0, AsyncIsr.tla:28
+        snprintf(buf, sizeof buf, "AsyncIsr_N%d_O%d_V%d", c.n_replicas, c.log_size, c.max_leader_epoch);
+        *name = buf;
+        snprintf(buf, sizeof buf, "KmcAsyncIsr<%d,%d,%d>", c.n_replicas, c.log_size, c.max_leader_epoch);
         *inst = buf;
         return true;
     case KMC_TRUNCATE_TO_HW:
@@ -161,7 +173,7 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
     std::string name, inst;
     if (!validate(cfg, &lay, &name, &inst))
         return fail(KMC_E_ARG, "unsupported model/constants (model=%d N=%d L=%d R=%d E=%d K=%d): need 2<=N<=8, "
-                               "L*bits(record)<=64, E<=7", cfg.model, cfg.n_replicas, cfg.log_size,
+                               "L*bits(record)<=64, E<=7 (AsyncIsr: N<=6, MaxVersion<=7)", cfg.model, cfg.n_replicas, cfg.log_size,
                     cfg.max_records, cfg.max_leader_epoch, cfg.n_log_records);
     *kname = name;
     // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_MIN_WAVES=5 -DKMC_PROFILE=1"
@@ -280,6 +292,8 @@ struct kmc_handle {
     std::vector<uint64_t> levels;
     std::vector<uint64_t> init_words, witness;
     bool have_witness = false, have_deadlock = false;
+    bool witness_outside = false;      // the witness is a successor outside the state constraint:
+    uint64_t witness_parent_fp = 0;    //   it is in no table; this is the expanded state it was generated from
     kmc_result res{};
     double t_start = 0;
     double dry_seconds = 0;
@@ -374,6 +388,37 @@ int find_state(kmc_handle* h, const u64* frontier, const uint64_t seg[KMC_SEGS],
     return KMC_OK;
 }
 
+// A violating successor outside the state constraint is in no table and no frontier: re-enumerate
+// the successors of the expanded level, keeping those whose fingerprint is `fp` (ENUM_MATCH), to
+// get its words and the parent it came from (the one with the smallest fingerprint).
+int find_outside_witness(kmc_handle* h, const u64* frontier, const uint64_t seg[KMC_SEGS], uint64_t fp) {
+    int rc = zero_ctl(h, 2);
+    if (rc) return rc;
+    KmcArgs a = base_args(h, 2);
+    a.fin = frontier;
+    uint64_t n = 0;
+    for (int sg = 0; sg < KMC_SEGS; ++sg) { a.seg_count[sg] = seg[sg]; n += seg[sg]; }
+    a.mode = KMC_MODE_ENUM;
+    a.flags |= KMC_FLAG_ENUM_MATCH;
+    a.match_fp = fp;
+    a.send = h->enum_out;
+    a.send_cap = h->enum_cap;
+    a.inv_mask = 0;
+    if ((rc = launch(h, h->f_expand, a, expand_grid(h, n)))) return rc;
+    if ((rc = read_ctl(h, 2))) return rc;
+    const uint64_t cnt = h->ctl_host->enum_count < h->enum_cap ? h->ctl_host->enum_count : h->enum_cap;
+    if (cnt == 0) return fail(KMC_E_STATE, "witness outside the constraint not found among the successors");
+    std::vector<uint64_t> recs(cnt * (h->W + 2));
+    HIP_TRY(hipMemcpy(recs.data(), h->enum_out, recs.size() * 8, hipMemcpyDeviceToHost));
+    uint64_t best = 0;
+    for (uint64_t i = 1; i < cnt; ++i)
+        if (recs[i * (h->W + 2) + h->W + 1] < recs[best * (h->W + 2) + h->W + 1]) best = i;
+    h->witness.assign(&recs[best * (h->W + 2)], &recs[best * (h->W + 2)] + h->W);
+    h->witness_parent_fp = recs[best * (h->W + 2) + h->W + 1];
+    h->witness_outside = true;
+    return KMC_OK;
+}
+
 int reset_run(kmc_handle* h) {
     HIP_TRY(hipMemsetAsync(h->table, 0, h->table_cap * 8, h->stream));
     if (h->pred) HIP_TRY(hipMemsetAsync(h->pred, 0, h->table_cap * 8, h->stream));
@@ -383,6 +428,8 @@ int reset_run(kmc_handle* h) {
     h->witness.clear();
     h->have_witness = false;
     h->have_deadlock = false;
+    h->witness_outside = false;
+    h->witness_parent_fp = 0;
     memset(&h->res, 0, sizeof h->res);
     h->res.violated_invariant = -1;
     h->res.table_capacity = h->table_cap;
@@ -417,6 +464,20 @@ bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, con
                     h->have_witness = *rc == KMC_OK;
                 }
                 break;
+            }
+        }
+        // successors outside the state constraint that violate an invariant: one level deeper than
+        // the expanded states, so a violation among those takes precedence
+        for (int k = 0; k < 4 && r.violated_invariant < 0; ++k) {
+            if ((h->cfg.invariant_mask >> k & 1u) && c.oviol_count[k]) {
+                r.violated_invariant = k;
+                r.violation_depth = h->level + 1;
+                r.violation_fp = ~c.oviol_fp_inv[k];
+                for (int j = 0; j < 4; ++j) r.violation_count[j] = c.oviol_count[j];
+                if (parent_frontier && h->cfg.n_shards == 1) {
+                    *rc = find_outside_witness(h, parent_frontier, parent_seg, r.violation_fp);
+                    h->have_witness = *rc == KMC_OK;
+                }
             }
         }
         if (r.violated_invariant >= 0) {
@@ -484,12 +545,17 @@ int do_begin(kmc_handle* h) {
 extern "C" {
 
 const char* kmc_last_error(void) { return g_err.c_str(); }
-const char* kmc_model_name(int32_t m) { return m >= 0 && m <= 6 ? MODEL_NAMES[m] : "?"; }
+const char* kmc_model_name(int32_t m) { return m >= 0 && m <= 7 ? MODEL_NAMES[m] : "?"; }
 const char* kmc_invariant_name(int32_t i) { return i >= 0 && i < 4 ? INV_NAMES[i] : "?"; }
+const char* kmc_model_invariant_name(int32_t model, int32_t i) {
+    if (i < 0 || i >= 4) return "?";
+    return model == KMC_ASYNC_ISR ? INV_NAMES_ASYNC[i] : INV_NAMES[i];
+}
 int32_t kmc_action_count(int32_t model) {
     switch (model) {
     case KMC_IDSEQUENCE: return 1;
     case KMC_FINITE_REPLICATED_LOG: return 3;
+    case KMC_ASYNC_ISR: return 7;
     case KMC_KIP320_FIRST_TRY: return 10;
     case KMC_TRUNCATE_TO_HW: case KMC_KIP101: case KMC_KIP279: case KMC_KIP320: return 9;
     default: return 0;
@@ -500,6 +566,7 @@ const char* kmc_action_name(int32_t model, int32_t kind) {
     switch (model) {
     case KMC_IDSEQUENCE: return "Next";
     case KMC_FINITE_REPLICATED_LOG: return KINDS_FRL[kind];
+    case KMC_ASYNC_ISR: return KINDS_ASYNC[kind];
     case KMC_KIP320: return KINDS_KIP320[kind];
     case KMC_KIP320_FIRST_TRY: return KINDS_FIRST[kind];
     default:
@@ -681,6 +748,7 @@ uint64_t kmc_canon_bytes(kmc_handle* h) {
     const KmcLayout& y = h->lay;
     if (y.model == KMC_IDSEQUENCE) return 8;
     if (y.model == KMC_FINITE_REPLICATED_LOG) return (uint64_t)y.N * (1 + y.L);
+    if (y.model == KMC_ASYNC_ISR) return 6 + y.N + (uint64_t)(y.E + 1) * (((1 << y.N) + 7) / 8) + (y.E + 1);
     return (uint64_t)y.N * (5 + y.L) + 5 + 2 * (y.E + 1);
 }
 
@@ -698,6 +766,24 @@ int kmc_unpack_state(kmc_handle* h, const uint64_t* words, uint8_t* c) {
             b[0] = (uint8_t)kmc_getbits(w, y.end_off[r], y.BO);
             for (int o = 0; o < y.L; ++o) b[1 + o] = (uint8_t)kmc_getbits(w, y.log_off[r] + o * y.BR, y.BR);
         }
+        return KMC_OK;
+    }
+    if (y.model == KMC_ASYNC_ISR) {
+        const int ns = 1 << y.N, rb = (ns + 7) / 8;
+        c[0] = (uint8_t)kmc_getbits(w, y.a_cisr, y.N);
+        c[1] = (uint8_t)kmc_getbits(w, y.a_cver, y.BV);
+        c[2] = (uint8_t)kmc_getbits(w, y.a_lisr, y.N);
+        c[3] = (uint8_t)kmc_getbits(w, y.a_lver, y.BV);
+        c[4] = (uint8_t)kmc_getbits(w, y.a_pisr, y.N);
+        c[5] = (uint8_t)kmc_getbits(w, y.a_pver, y.BV);
+        for (int r = 0; r < y.N; ++r) c[6 + r] = (uint8_t)kmc_getbits(w, y.a_off[r], y.BF);
+        uint8_t* q = c + 6 + y.N;
+        memset(q, 0, (size_t)(y.E + 1) * rb);
+        for (int v = 0; v <= y.E; ++v)
+            for (int m = 0; m < ns; ++m)
+                if (kmc_getbits(w, y.a_req + v * ns + m, 1)) q[v * rb + (m >> 3)] |= (uint8_t)(1u << (m & 7));
+        uint8_t* u = q + (y.E + 1) * rb;
+        for (int v = 0; v <= y.E; ++v) u[v] = (uint8_t)kmc_getbits(w, y.a_upd + v * y.N, y.N);
         return KMC_OK;
     }
     const int rs = 5 + y.L;
@@ -738,6 +824,21 @@ int kmc_pack_state(kmc_handle* h, const uint8_t* c, uint64_t* words) {
             kmc_setbits(w, y.end_off[r], y.BO, b[0]);
             for (int o = 0; o < y.L; ++o) kmc_setbits(w, y.log_off[r] + o * y.BR, y.BR, b[1 + o]);
         }
+    } else if (y.model == KMC_ASYNC_ISR) {
+        const int ns = 1 << y.N, rb = (ns + 7) / 8;
+        kmc_setbits(w, y.a_cisr, y.N, c[0]);
+        kmc_setbits(w, y.a_cver, y.BV, c[1]);
+        kmc_setbits(w, y.a_lisr, y.N, c[2]);
+        kmc_setbits(w, y.a_lver, y.BV, c[3]);
+        kmc_setbits(w, y.a_pisr, y.N, c[4]);
+        kmc_setbits(w, y.a_pver, y.BV, c[5]);
+        for (int r = 0; r < y.N; ++r) kmc_setbits(w, y.a_off[r], y.BF, c[6 + r]);
+        const uint8_t* q = c + 6 + y.N;
+        for (int v = 0; v <= y.E; ++v)
+            for (int m = 0; m < ns; ++m)
+                if (q[v * rb + (m >> 3)] >> (m & 7) & 1) kmc_setbits(w, y.a_req + v * ns + m, 1, 1);
+        const uint8_t* u = q + (y.E + 1) * rb;
+        for (int v = 0; v <= y.E; ++v) kmc_setbits(w, y.a_upd + v * y.N, y.N, u[v]);
     } else {
         const int rs = 5 + y.L;
         for (int r = 0; r < y.N; ++r) {
@@ -1043,6 +1144,10 @@ int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap
     // 1. walk predecessor fingerprints back to the initial state (pred == 0)
     std::vector<uint64_t> chain;
     uint64_t fp = h->res.violation_fp;
+    if (h->witness_outside) {  // not in the table: the chain starts at the parent it was generated from
+        chain.push_back(fp);
+        fp = h->witness_parent_fp;
+    }
     for (uint64_t guard = 0; guard < (1u << 20); ++guard) {
         chain.push_back(fp);
         uint64_t slot = 0;
@@ -1304,6 +1409,10 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
         for (int k = 0; k < 4; ++k) {
             info->violation_count[k] = c.viol_count[k];
             info->violation_fp[k] = c.viol_count[k] ? ~c.viol_fp_inv[k] : 0;
+        }
+        for (int k = 0; k < 4; ++k) {
+            info->outside_violation_count[k] = c.oviol_count[k];
+            info->outside_violation_fp[k] = c.oviol_count[k] ? ~c.oviol_fp_inv[k] : 0;
         }
         info->deadlocks_level = c.deadlock_count;
         info->send_filtered = c.send_filtered;

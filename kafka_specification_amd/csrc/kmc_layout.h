@@ -22,6 +22,19 @@
 //
 // FiniteReplicatedLog standalone: for r: log[r] (L x BK bits, record = 0 Nil | 1..K), then
 // for r: end[r] (BO).   IdSequence standalone: one 64-bit word = nextId.
+//
+// AsyncIsr standalone (AsyncIsr.tla:31-35), checked under the state constraint
+// offsets[Leader] <= L /\ controllerState.version <= E (L = MaxOffset, E = MaxVersion; replica 0 is
+// `Leader`); every field has room for the one value beyond the bound that a successor outside the
+// constraint can carry:
+//   controllerState: isr N | version BV (0..E+1)
+//   leaderState: isr N | version BV | pendingIsr N | pendingVersion+1 BV (Nil = -1 -> 0) |
+//                offsets[r] BF (0..L+1) for r in Replicas
+//   requests  (a set of [isr, version], version 0..E): (E+1) x 2^N bits, bit = version * 2^N + isr mask
+//   updates   (a set of [isr, version]): the controller is its only writer and always adds
+//             [isr, version = controllerState.version + 1] (AsyncIsr.tla:68-86), so the set is in
+//             bijection with the array, indexed by version 1..E+1, of the isr written at that
+//             version: (E+1) x N bits, zero while version > controllerState.version.
 #pragma once
 
 #define KMC_MAXN 8
@@ -35,6 +48,7 @@
 #define KMC_MODEL_KIP279 4
 #define KMC_MODEL_KIP320 5
 #define KMC_MODEL_KIP320_FIRST_TRY 6
+#define KMC_MODEL_ASYNC_ISR 7
 
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
 #define KMC_HD __host__ __device__
@@ -56,6 +70,9 @@ struct KmcLayout {
         isr_off[KMC_MAXN];
     int nextrec_off, nextep_off, qep_off, qldr_off, qisr_off;
     int reqldr_off[KMC_MAXE1], reqisr_off[KMC_MAXE1];
+    // AsyncIsr
+    int BV, BF;
+    int a_cisr, a_cver, a_lisr, a_lver, a_pisr, a_pver, a_off[KMC_MAXN], a_req, a_upd;
     int bits, W;
     int valid;  // 0 when the parameters cannot be packed (see kmc_make_layout)
 };
@@ -70,6 +87,23 @@ KMC_HD constexpr KmcLayout kmc_make_layout(int model, int N, int L, int R, int E
     }
     if (N < 1 || N > KMC_MAXN || L < 1) return y;
     int pos = 0;
+    if (model == KMC_MODEL_ASYNC_ISR) {
+        if (N > 6 || E < 0 || E + 1 > KMC_MAXE1 || L > 250) return y;  // 2^N request bits per version must fit one u64
+        y.BV = kmc_bits_for(E + 2);
+        y.BF = kmc_bits_for(L + 2);
+        y.a_cisr = pos; pos += N;
+        y.a_cver = pos; pos += y.BV;
+        y.a_lisr = pos; pos += N;
+        y.a_lver = pos; pos += y.BV;
+        y.a_pisr = pos; pos += N;
+        y.a_pver = pos; pos += y.BV;
+        for (int r = 0; r < N; ++r) { y.a_off[r] = pos; pos += y.BF; }
+        y.a_req = pos; pos += (E + 1) * (1 << N);
+        y.a_upd = pos; pos += (E + 1) * N;
+        y.bits = pos; y.W = (pos + 63) / 64;
+        y.valid = y.W >= 1 && y.W <= KMC_MAXW;
+        return y;
+    }
     y.BO = kmc_bits_for(L + 1);
     if (model == KMC_MODEL_FINITE_REPLICATED_LOG) {
         if (K < 1) return y;

@@ -87,7 +87,8 @@ class HipShardEngine:
     def finish(self):
         """Statistics of the expansion just completed: st[0] new states of the produced level,
         st[1..15] generated per action, st[17..20] invariant violations among the states of the
-        EXPANDED level, st[21] deadlocked states of the expanded level, st[22..24] error flags."""
+        EXPANDED level, st[21] deadlocked states of the expanded level, st[22..23] error flags, st[24]
+        filtered sends, st[25..28] violating successors outside the state constraint (AsyncIsr)."""
         info = nat.KmcLevelInfo()
         nat.check(self.lib.kmc_step_finish(self.mc.handle, C.byref(info)))
         st = np.zeros(N_STATS, dtype=np.int64)
@@ -96,6 +97,7 @@ class HipShardEngine:
             st[1 + k] = info.generated_level[k]
         for k in range(4):
             st[17 + k] = info.violation_count[k]
+            st[25 + k] = info.outside_violation_count[k]
         st[21] = info.deadlocks_level
         st[24] = info.send_filtered
         st[22] = 1 if info.error_flags & 2 else 0
@@ -219,7 +221,7 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
     """Level-synchronous BFS over all shards.  Returns the global result (identical on every
     rank).  `engines` are this process's shards."""
     t0 = time.perf_counter()
-    inv_names = nat.INVARIANT_NAMES
+    inv_names = tuple(n for n in nat.invariant_names(cfg.model) if n != "?")
     levels, generated, deadlocks = [], 0, 0
     filtered = 0  # remote successors dropped by the sender-side filters (all shards)
     action_generated = [0] * nat.KMC_MAX_KINDS
@@ -237,6 +239,16 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
                 verdict = "invariant"
                 if not cfg.continue_on_violation:
                     return True, 0          # the level this expansion produced is rolled back
+        if viol_inv is None:
+            # successors outside the state constraint that violate an invariant (AsyncIsr): they sit
+            # one level below the expanded states, which is why those were looked at first
+            counts = {n: int(st[25 + k]) for k, n in enumerate(inv_names)}
+            hit = [n for n in inv_names if n in cfg.invariants and counts[n]]
+            if hit:
+                viol_inv, viol_depth, viol_count = hit[0], parent_depth + 1, counts
+                verdict = "invariant"
+                if not cfg.continue_on_violation:
+                    return True, 0
         for k in range(15):
             action_generated[k] += int(st[1 + k])
             generated += int(st[1 + k])

@@ -814,6 +814,103 @@ class FiniteReplicatedLogModel:
 
 
 # ----------------------------------------------------------------------------------------
+# AsyncIsr.tla (standalone, EXTENDS Integers, Util — AsyncIsr.tla:20)
+# ----------------------------------------------------------------------------------------
+class AsyncIsrModel:
+    r"""AsyncIsr.tla:22-162.  The spec is unbounded (version: Nat, offsets: [Replicas -> Nat],
+    :40-56; LeaderWrite :117-119 increments forever; MaxOffset :25 only feeds the unused
+    `Offsets` :37), so it is checked under an explicit state CONSTRAINT that the reference
+    does not contain (models/MCAsyncIsr.tla):
+        leaderState.offsets[Leader] <= MaxOffset /\ controllerState.version <= MaxVersion
+    State = (cisr, cver, lisr, lver, pisr, pver, offsets, requests, updates); sets are
+    frozensets, messages are (isr, version) pairs, Leader is replica 0."""
+    action_names = ("ControllerShrinkIsr", "ControllerHandleRequest", "LeaderRequestShrinkIsr",
+                    "LeaderRequestExpandIsr", "LeaderWrite", "LeaderHandleUpdate", "FollowerReplicate")
+
+    def __init__(self, N, MaxOffset, MaxVersion):
+        assert MaxOffset > 0 and N >= 1  # ASSUME :27-29 (Leader \in Replicas by construction)
+        self.N, self.MaxOffset, self.MaxVersion = N, MaxOffset, MaxVersion
+        self.Replicas = tuple(range(N))
+        self.Leader = 0
+
+    def Init(self):  # :137-150
+        R = frozenset(self.Replicas)
+        return (R, 0, R, 0, frozenset(), -1, tuple(0 for _ in self.Replicas), frozenset(), frozenset())
+
+    def constraint(self, s):  # models/MCAsyncIsr.tla — not part of the reference
+        return s[6][self.Leader] <= self.MaxOffset and s[1] <= self.MaxVersion
+
+    def HighWatermark(self, s):  # :58-60
+        cisr, cver, lisr, lver, pisr, pver, offsets, requests, updates = s
+        potentialIsr = lisr | pisr
+        return Min({offsets[replica] for replica in potentialIsr})
+
+    def TypeOk(self, s):  # :62-66 with LeaderState :40-46, ControllerState :48-51, Message :53-56
+        cisr, cver, lisr, lver, pisr, pver, offsets, requests, updates = s
+        R = set(self.Replicas)
+        nat = lambda x: isinstance(x, int) and x >= 0
+        msg = lambda m: m[0] <= R and nat(m[1])
+        return (cisr <= R and nat(cver)
+                and lisr <= R and nat(lver) and pisr <= R and nat(pver)   # pendingVersion = Nil = -1 fails here (:38,:44,:146)
+                and all(nat(o) for o in offsets)
+                and all(msg(m) for m in requests) and all(msg(m) for m in updates))
+
+    def ValidHighWatermark(self, s):  # :161-162
+        cisr, offsets = s[0], s[6]
+        hw = self.HighWatermark(s)
+        return all(offsets[replica] >= hw for replica in cisr)
+
+    def LeaderOffsetInRange(self, s):  # models/MCAsyncIsr.tla (not in the reference): offsets[Leader] \in Offsets (:37)
+        return 0 <= s[6][self.Leader] <= self.MaxOffset
+
+    def Next(self, s):  # :152-159
+        cisr, cver, lisr, lver, pisr, pver, offsets, requests, updates = s
+        Leader, out = self.Leader, []
+        # ControllerShrinkIsr :72-79 (ControllerWriteIsr :68-70)
+        for replica in self.Replicas:
+            if replica != Leader and replica in cisr:
+                version = cver + 1
+                isr = cisr - {replica}
+                out.append((0, (isr, version, lisr, lver, pisr, pver, offsets, requests, updates | {(isr, version)})))
+        # ControllerHandleRequest :81-86
+        for message in sorted(requests, key=lambda m: (m[1], sorted(m[0]))):
+            if message[1] == cver:
+                version = cver + 1
+                out.append((1, (message[0], version, lisr, lver, pisr, pver, offsets, requests,
+                                updates | {(message[0], version)})))
+        # LeaderRequestShrinkIsr :88-100
+        for replica in sorted(lisr):
+            if replica != Leader:
+                isr = lisr - {replica}
+                version = lver
+                out.append((2, (cisr, cver, lisr, lver, pisr | isr, version, offsets,
+                                requests | {(isr, version)}, updates)))
+        # LeaderRequestExpandIsr :102-115
+        for replica in self.Replicas:
+            if replica not in lisr and offsets[replica] >= self.HighWatermark(s):
+                isr = lisr | {replica}
+                version = lver
+                out.append((3, (cisr, cver, lisr, lver, pisr | isr, version, offsets,
+                                requests | {(isr, version)}, updates)))
+        # LeaderWrite :117-119 — always enabled
+        out.append((4, (cisr, cver, lisr, lver, pisr, pver, _set(offsets, Leader, offsets[Leader] + 1),
+                        requests, updates)))
+        # LeaderHandleUpdate :121-129
+        for update in sorted(updates, key=lambda m: (m[1], sorted(m[0]))):
+            if update[1] > lver:
+                out.append((5, (cisr, cver, update[0], update[1], frozenset(), -1, offsets, requests, updates)))
+        # FollowerReplicate :131-135
+        for replica in self.Replicas:
+            if replica != Leader and offsets[replica] < offsets[Leader]:
+                out.append((6, (cisr, cver, lisr, lver, pisr, pver, _set(offsets, replica, offsets[replica] + 1),
+                                requests, updates)))
+        return out
+
+    def invariant(self, name):
+        return getattr(self, name)
+
+
+# ----------------------------------------------------------------------------------------
 # Level-synchronous exhaustive BFS (what TLC's Worker loop does, [TLC-recall]).
 # ----------------------------------------------------------------------------------------
 def bfs(model, invariants=("TypeOk",), check_deadlock=False, stop_on_violation=True,
@@ -855,8 +952,11 @@ def bfs(model, invariants=("TypeOk",), check_deadlock=False, stop_on_violation=T
                          per_invariant=per_inv, trace=[(None, init)])
         verdict = "invariant"
         frontier = []
+    constraint = getattr(model, "constraint", None)
+    outside_total = {}
     while frontier:
         nxt = []
+        outside, outside_first = {}, {}
         for s in frontier:
             succ = model.Next(s)
             if not succ:
@@ -864,12 +964,40 @@ def bfs(model, invariants=("TypeOk",), check_deadlock=False, stop_on_violation=T
             for ai, t in succ:
                 generated += 1
                 action_generated[model.action_names[ai]] += 1
+                if constraint is not None and not constraint(t):
+                    # TLC CONSTRAINT [TLC-recall: ModelChecker.doNext]: a successor outside the
+                    # model is neither fingerprinted nor queued, but its invariants ARE checked
+                    # (every time it is generated, since it is never "seen")
+                    for name in invariants:
+                        if not model.invariant(name)(t):
+                            outside[name] = outside.get(name, 0) + 1
+                            outside_first.setdefault(name, (s, ai, t))
+                    continue
                 if t not in parent:
                     parent[t] = (s, ai)
                     nxt.append(t)
         if check_deadlock and deadlocks and verdict == "ok":
             verdict = "deadlock"
             break
+        for name, cnt in outside.items():
+            outside_total[name] = outside_total.get(name, 0) + cnt
+        if outside and violation is None:
+            # violating successors outside the constraint sit at depth+1 and are seen while the
+            # current level is expanded, i.e. before the in-model states of depth+1 are checked
+            name = next(n for n in invariants if n in outside)
+            par, ai, st = outside_first[name]
+            trace = [(model.action_names[ai], st)]
+            cur = par
+            while cur is not None:
+                pp, pa = parent[cur]
+                trace.append((None if pa is None else model.action_names[pa], cur))
+                cur = pp
+            trace.reverse()
+            violation = dict(invariant=name, depth=depth + 1, count_at_depth=outside[name],
+                             per_invariant=dict(outside), trace=trace, outside_constraint=True)
+            if stop_on_violation:
+                verdict = "invariant"
+                break
         if not nxt:
             break
         depth += 1
@@ -900,7 +1028,7 @@ def bfs(model, invariants=("TypeOk",), check_deadlock=False, stop_on_violation=T
         verdict = "invariant"
     res = dict(distinct=len(parent), generated=generated, depth=depth, levels=levels,
                action_generated=action_generated, verdict=verdict, violation=violation,
-               deadlock_states=deadlocks)
+               deadlock_states=deadlocks, outside_violations=outside_total)
     if keep_states:
         res["level_states"] = level_states
     return res
@@ -911,6 +1039,8 @@ def make_model(model, **c):
         return IdSequenceModel(c["MaxId"])
     if model == "FiniteReplicatedLog":
         return FiniteReplicatedLogModel(c["N"], c["L"], c["K"])
+    if model == "AsyncIsr":  # L = MaxOffset, E = MaxVersion (the constraint's two bounds)
+        return AsyncIsrModel(c["N"], c["L"], c["E"])
     return Kafka(Params(c["N"], c["L"], c["R"], c["E"]), model)
 
 

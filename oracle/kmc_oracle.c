@@ -36,8 +36,9 @@
 #define KMO_MAXN 8
 #define KMO_MAXSB 160
 
-enum { M_IDSEQ = 0, M_FRL = 1, M_TRUNC_HW = 2, M_KIP101 = 3, M_KIP279 = 4, M_KIP320 = 5, M_KIP320_FIRST = 6 };
+enum { M_IDSEQ = 0, M_FRL = 1, M_TRUNC_HW = 2, M_KIP101 = 3, M_KIP279 = 4, M_KIP320 = 5, M_KIP320_FIRST = 6, M_ASYNC_ISR = 7 };
 enum { INV_TYPEOK = 0, INV_WEAKISR = 1, INV_STRONGISR = 2, INV_LEADERINISR = 3 };
+enum { INV_VALIDHW = 1 }; /* AsyncIsr: invariant index 1 is ValidHighWatermark (AsyncIsr.tla:161) */
 enum { V_OK = 0, V_INVARIANT = 1, V_DEADLOCK = 2, V_LIMIT = 3, V_ERROR = 4 };
 
 typedef struct {
@@ -58,6 +59,10 @@ typedef struct {
     uint64_t nlevels;
     uint64_t levels[KMO_MAX_LEVELS];
     double seconds;
+    /* a violating successor OUTSIDE the state constraint (AsyncIsr only): it is in no level, so
+     * it is handed over here together with its parent (viol_state_idx) and the action */
+    int32_t viol_outside, viol_action;
+    uint8_t viol_state[KMO_MAXSB];
 } kmo_result;
 
 typedef struct {
@@ -65,6 +70,7 @@ typedef struct {
     int64_t MaxId;
     int rstride, goff, sb, nact;
     int EP1; /* E+1 */
+    int a_req, a_rb, a_upd; /* AsyncIsr: byte offset of the requests bitset, bytes per version, offset of the updates array */
 } P;
 
 typedef void (*emit_fn)(void *ctx, int action, const uint8_t *succ);
@@ -577,6 +583,127 @@ static void BecomeFollower(const P *p, const uint8_t *s, int a, emit_fn emit, vo
         }
 }
 
+
+/* ==================================================================================== */
+/* AsyncIsr.tla (standalone).  Unbounded as written (version: Nat, offsets: [Replicas -> Nat],
+ * :40-56; LeaderWrite :117-119), so it runs under the explicit state constraint of
+ * models/MCAsyncIsr.tla (NOT part of the reference):
+ *     leaderState.offsets[Leader] <= MaxOffset /\ controllerState.version <= MaxVersion
+ * with MaxOffset = L and MaxVersion = E here; Leader is replica 0.  One byte per field:
+ *   [0] controllerState.isr  [1] controllerState.version
+ *   [2] leaderState.isr [3] .version [4] .pendingIsr [5] .pendingVersion+1 (Nil = -1 -> 0)
+ *   [6+r] leaderState.offsets[r]
+ *   requests (a set of [isr, version], versions 0..E): per version a bitset over the 2^N isr
+ *     masks, a_rb bytes each;
+ *   updates: only the controller adds to it, always [isr, version = old version + 1] (:68-79,
+ *     :81-86), so the set is in bijection with the array, indexed by version 1..E+1, of the isr
+ *     written at that version (zero while version > controllerState.version).
+ * Successors outside the constraint carry offsets[Leader] = L+1 or version = E+1: both fit.  */
+/* ==================================================================================== */
+#define A_CISR(s) ((s)[0])
+#define A_CVER(s) ((s)[1])
+#define A_LISR(s) ((s)[2])
+#define A_LVER(s) ((s)[3])
+#define A_PISR(s) ((s)[4])
+#define A_PVER1(s) ((s)[5])
+#define A_OFF(s, r) ((s)[6 + (r)])
+#define A_UPD(s, v) ((s)[p->a_upd + (v)-1]) /* v in 1..E+1 */
+static inline int a_has_req(const P *p, const uint8_t *s, int v, int isr) {
+    return s[p->a_req + v * p->a_rb + (isr >> 3)] >> (isr & 7) & 1;
+}
+static inline void a_add_req(const P *p, uint8_t *s, int v, int isr) {
+    s[p->a_req + v * p->a_rb + (isr >> 3)] |= (uint8_t)(1u << (isr & 7));
+}
+static void async_init(const P *p, uint8_t *s) { /* :137-150 */
+    memset(s, 0, p->sb);
+    A_CISR(s) = (uint8_t)((1u << p->N) - 1);
+    A_LISR(s) = (uint8_t)((1u << p->N) - 1);
+    A_PVER1(s) = 0; /* pendingVersion |-> Nil */
+}
+static int async_high_watermark(const P *p, const uint8_t *s) { /* :58-60; Leader is always in leaderState.isr, so the set is non-empty */
+    int potential = A_LISR(s) | A_PISR(s), hw = 1 << 30;
+    for (int r = 0; r < p->N; r++)
+        if (potential >> r & 1) hw = imin(hw, A_OFF(s, r));
+    return hw;
+}
+static int async_in_model(const P *p, const uint8_t *s) { return A_OFF(s, 0) <= p->L && A_CVER(s) <= p->E; }
+static int async_typeok(const P *p, const uint8_t *s) { /* :62-66: pendingVersion \in Nat (:44) is false while it is Nil (:38) */
+    (void)p;
+    return A_PVER1(s) != 0;
+}
+static int async_valid_hw(const P *p, const uint8_t *s) { /* :161-162 */
+    const int hw = async_high_watermark(p, s);
+    for (int r = 0; r < p->N; r++)
+        if ((A_CISR(s) >> r & 1) && A_OFF(s, r) < hw) return 0;
+    return 1;
+}
+static void async_expand(const P *p, const uint8_t *s, emit_fn emit, void *ctx) { /* Next :152-159 */
+    uint8_t t[KMO_MAXSB];
+    const int cver = A_CVER(s), lver = A_LVER(s);
+    /* ControllerShrinkIsr :72-79 (ControllerWriteIsr :68-70) */
+    for (int r = 1; r < p->N; r++)
+        if (A_CISR(s) >> r & 1) {
+            memcpy(t, s, p->sb);
+            A_CISR(t) = (uint8_t)(A_CISR(s) & ~(1u << r));
+            A_CVER(t) = (uint8_t)(cver + 1);
+            A_UPD(t, cver + 1) = A_CISR(t);
+            emit(ctx, 0, t);
+        }
+    /* ControllerHandleRequest :81-86 */
+    if (cver <= p->E)
+        for (int isr = 0; isr < (1 << p->N); isr++)
+            if (a_has_req(p, s, cver, isr)) {
+                memcpy(t, s, p->sb);
+                A_CISR(t) = (uint8_t)isr;
+                A_CVER(t) = (uint8_t)(cver + 1);
+                A_UPD(t, cver + 1) = (uint8_t)isr;
+                emit(ctx, 1, t);
+            }
+    /* LeaderRequestShrinkIsr :88-100 */
+    for (int r = 1; r < p->N; r++)
+        if (A_LISR(s) >> r & 1) {
+            const int isr = A_LISR(s) & ~(1 << r);
+            memcpy(t, s, p->sb);
+            a_add_req(p, t, lver, isr);
+            A_PISR(t) = (uint8_t)(A_PISR(s) | isr);
+            A_PVER1(t) = (uint8_t)(lver + 1);
+            emit(ctx, 2, t);
+        }
+    /* LeaderRequestExpandIsr :102-115 */
+    {
+        const int hw = async_high_watermark(p, s);
+        for (int r = 0; r < p->N; r++)
+            if (!(A_LISR(s) >> r & 1) && A_OFF(s, r) >= hw) {
+                const int isr = A_LISR(s) | (1 << r);
+                memcpy(t, s, p->sb);
+                a_add_req(p, t, lver, isr);
+                A_PISR(t) = (uint8_t)(A_PISR(s) | isr);
+                A_PVER1(t) = (uint8_t)(lver + 1);
+                emit(ctx, 3, t);
+            }
+    }
+    /* LeaderWrite :117-119 */
+    memcpy(t, s, p->sb);
+    A_OFF(t, 0)++;
+    emit(ctx, 4, t);
+    /* LeaderHandleUpdate :121-129 */
+    for (int v = lver + 1; v <= cver; v++) {
+        memcpy(t, s, p->sb);
+        A_LISR(t) = A_UPD(s, v);
+        A_LVER(t) = (uint8_t)v;
+        A_PISR(t) = 0;
+        A_PVER1(t) = 0;
+        emit(ctx, 5, t);
+    }
+    /* FollowerReplicate :131-135 */
+    for (int r = 1; r < p->N; r++)
+        if (A_OFF(s, r) < A_OFF(s, 0)) {
+            memcpy(t, s, p->sb);
+            A_OFF(t, r)++;
+            emit(ctx, 6, t);
+        }
+}
+
 typedef void (*action_fn)(const P *, const uint8_t *, int, emit_fn, void *);
 static const action_fn NEXT_TRUNC_HW[] = {/* KafkaTruncateToHighWatermark.tla:33-42 */
                                           ControllerElectLeader, ControllerShrinkIsr, BecomeLeader, LeaderExpandIsr,
@@ -605,6 +732,7 @@ static void model_expand(const P *p, const uint8_t *s, emit_fn emit, void *ctx) 
     switch (p->model) {
     case M_IDSEQ: idseq_expand(p, s, emit, ctx); return;
     case M_FRL: frl_expand(p, s, emit, ctx); return;
+    case M_ASYNC_ISR: async_expand(p, s, emit, ctx); return;
     case M_TRUNC_HW: acts = NEXT_TRUNC_HW; break;
     case M_KIP101: acts = NEXT_KIP101; break;
     case M_KIP279: acts = NEXT_KIP279; break;
@@ -613,9 +741,13 @@ static void model_expand(const P *p, const uint8_t *s, emit_fn emit, void *ctx) 
     }
     for (int a = 0; a < p->nact; a++) acts[a](p, s, a, emit, ctx);
 }
+/* TLC CONSTRAINT: only AsyncIsr has one */
+static int model_in_model(const P *p, const uint8_t *s) { return p->model == M_ASYNC_ISR ? async_in_model(p, s) : 1; }
 static int model_invariant(const P *p, int inv, const uint8_t *s) {
     if (p->model == M_IDSEQ) return inv == INV_TYPEOK ? idseq_typeok(p, s) : 1;
     if (p->model == M_FRL) return inv == INV_TYPEOK ? frl_typeok(p, s) : 1;
+    if (p->model == M_ASYNC_ISR) /* 2: LeaderOffsetInRange of models/MCAsyncIsr.tla (not in the reference) */
+        return inv == INV_TYPEOK ? async_typeok(p, s) : inv == INV_VALIDHW ? async_valid_hw(p, s) : inv == 2 ? A_OFF(s, 0) <= p->L : 1;
     switch (inv) {
     case INV_TYPEOK: return kafka_typeok(p, s);
     case INV_WEAKISR: return kafka_weakisr(p, s);
@@ -651,6 +783,10 @@ typedef struct {
     uint64_t parent;
     uint64_t generated, succ_of_state, deadlocks;
     uint64_t action_generated[KMO_MAX_ACTIONS];
+    /* violating successors outside the constraint seen by this worker */
+    uint64_t out_cnt[4], out_parent[4];
+    int out_action[4];
+    uint8_t out_state[4][KMO_MAXSB];
 } Worker;
 
 static inline uint8_t *rec_ptr(Engine *e, uint64_t idx) {
@@ -758,6 +894,20 @@ static void worker_emit(void *ctx, int action, const uint8_t *succ) {
     w->generated++;
     w->succ_of_state++;
     w->action_generated[action]++;
+    if (!model_in_model(&w->e->p, succ)) {
+        /* TLC CONSTRAINT [TLC-recall, ModelChecker.doNext]: not fingerprinted, not queued, but the
+         * invariants are evaluated — every time the state is generated, since it is never "seen" */
+        for (int inv = 0; inv < 4; inv++)
+            if ((w->e->cfg.inv_mask >> inv & 1) && !model_invariant(&w->e->p, inv, succ)) {
+                if (w->out_cnt[inv]++ == 0 ||
+                    memcmp(succ, w->out_state[inv], w->e->p.sb) < 0) { /* keep the smallest: deterministic */
+                    w->out_parent[inv] = w->parent;
+                    w->out_action[inv] = action;
+                    memcpy(w->out_state[inv], succ, w->e->p.sb);
+                }
+            }
+        return;
+    }
     engine_insert(w->e, succ, w->parent, action, NULL);
 }
 
@@ -791,6 +941,15 @@ static int setup_params(P *p, const kmo_config *c) {
         return c->MaxId >= 0;
     }
     if (c->N < 1 || c->N > KMO_MAXN || c->L < 1) return 0;
+    if (c->model == M_ASYNC_ISR) { /* L = MaxOffset, E = MaxVersion */
+        if (c->N > 6 || c->E < 0 || c->E > 14 || c->L > 250) return 0;
+        p->a_rb = ((1 << c->N) + 7) / 8;
+        p->a_req = 6 + c->N;
+        p->a_upd = p->a_req + (c->E + 1) * p->a_rb;
+        p->sb = p->a_upd + c->E + 1;
+        p->nact = 7;
+        return p->sb <= KMO_MAXSB;
+    }
     if (c->model == M_FRL) {
         p->sb = c->N * (1 + c->L); p->nact = 3;
         return p->sb <= KMO_MAXSB && c->K >= 1 && c->K < 255;
@@ -822,6 +981,8 @@ void *kmo_run(const kmo_config *cfg, kmo_result *res) {
     uint8_t init[KMO_MAXSB];
     if (e->p.model == M_IDSEQ || e->p.model == M_FRL)
         memset(init, 0, e->p.sb); /* IdSequence.tla:37 / FiniteReplicatedLog.tla:97 */
+    else if (e->p.model == M_ASYNC_ISR)
+        async_init(&e->p, init);
     else
         kafka_init(&e->p, init);
     engine_insert(e, init, 0xFFFFFFFFu, 255, NULL);
@@ -872,8 +1033,38 @@ void *kmo_run(const kmo_config *cfg, kmo_result *res) {
                 pthread_create(&th[t], NULL, worker_main, &ws[t]);
         }
         uint64_t dl = 0;
-        for (int t = 0; t < T; t++) {
+        for (int t = 0; t < T; t++)
             if (T > 1) pthread_join(th[t], NULL);
+        if (cfg->inv_mask && res->viol_inv < 0) { /* violating successors outside the constraint: depth nlevels+1 */
+            uint64_t cnt[4] = {0, 0, 0, 0};
+            int best[4] = {-1, -1, -1, -1};
+            for (int t = 0; t < T; t++)
+                for (int inv = 0; inv < 4; inv++)
+                    if (ws[t].out_cnt[inv]) {
+                        cnt[inv] += ws[t].out_cnt[inv];
+                        if (best[inv] < 0 || memcmp(ws[t].out_state[inv], ws[best[inv]].out_state[inv], e->p.sb) < 0)
+                            best[inv] = t;
+                    }
+            for (int inv = 0; inv < 4; inv++)
+                if (cnt[inv]) {
+                    const Worker *w = &ws[best[inv]];
+                    res->viol_inv = inv;
+                    res->viol_depth = res->nlevels + 1;
+                    res->viol_state_idx = w->out_parent[inv];
+                    res->viol_outside = 1;
+                    res->viol_action = w->out_action[inv];
+                    memcpy(res->viol_state, w->out_state[inv], e->p.sb);
+                    memcpy(res->viol_count, cnt, sizeof cnt);
+                    break;
+                }
+            if (res->viol_inv >= 0 && cfg->stop_on_violation) {
+                /* like the level-start check: the expansion that met the violation is not counted */
+                res->verdict = V_INVARIANT;
+                atomic_store(&e->nstates, hi);
+                break;
+            }
+        }
+        for (int t = 0; t < T; t++) {
             res->generated += ws[t].generated;
             dl += ws[t].deadlocks;
             for (int a = 0; a < KMO_MAX_ACTIONS; a++) res->action_generated[a] += ws[t].action_generated[a];
@@ -950,14 +1141,15 @@ void kmo_free(void *h) {
 
 #ifdef KMO_MAIN
 static const char *MODEL_NAMES[] = {"IdSequence", "FiniteReplicatedLog", "KafkaTruncateToHighWatermark",
-                                    "Kip101",     "Kip279",              "Kip320", "Kip320FirstTry"};
+                                    "Kip101",     "Kip279",              "Kip320", "Kip320FirstTry",
+                                    "AsyncIsr"};
 int main(int argc, char **argv) {
     kmo_config c = {.model = M_KIP320, .N = 3, .L = 2, .R = 2, .E = 1, .K = 2, .MaxId = 10,
                     .inv_mask = 1, .check_deadlock = 0, .stop_on_violation = 1, .threads = 1, .max_states = 0};
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--model") && i + 1 < argc) {
             c.model = -1;
-            for (int m = 0; m < 7; m++)
+            for (int m = 0; m < 8; m++)
                 if (!strcmp(argv[i + 1], MODEL_NAMES[m])) c.model = m;
             i++;
         } else if (!strcmp(argv[i], "--N")) c.N = atoi(argv[++i]);

@@ -10,9 +10,13 @@ LIB = os.path.join(ORACLE_DIR, "libkmc_oracle.so")
 KMO_MAX_LEVELS = 512
 KMO_MAX_ACTIONS = 16
 MODELS = {"IdSequence": 0, "FiniteReplicatedLog": 1, "KafkaTruncateToHighWatermark": 2, "Kip101": 3,
-          "Kip279": 4, "Kip320": 5, "Kip320FirstTry": 6}
+          "Kip279": 4, "Kip320": 5, "Kip320FirstTry": 6, "AsyncIsr": 7}
 INV_BITS = {"TypeOk": 1, "WeakIsr": 2, "StrongIsr": 4, "LeaderInIsr": 8}
 INV_NAMES = ("TypeOk", "WeakIsr", "StrongIsr", "LeaderInIsr")
+# AsyncIsr (N replicas, L = MaxOffset, E = MaxVersion) reuses the bit positions
+ASYNC_INV_BITS = {"TypeOk": 1, "ValidHighWatermark": 2, "LeaderOffsetInRange": 4}
+ASYNC_INV_NAMES = ("TypeOk", "ValidHighWatermark", "LeaderOffsetInRange", "?")
+KMO_MAXSB = 160
 VERDICTS = ("ok", "invariant", "deadlock", "limit", "error")
 
 
@@ -27,7 +31,8 @@ class Result(C.Structure):
                 ("verdict", C.c_int32), ("viol_inv", C.c_int32), ("viol_depth", C.c_uint64),
                 ("viol_state_idx", C.c_uint64), ("viol_count", C.c_uint64 * 4), ("deadlock_states", C.c_uint64),
                 ("action_generated", C.c_uint64 * KMO_MAX_ACTIONS), ("nlevels", C.c_uint64),
-                ("levels", C.c_uint64 * KMO_MAX_LEVELS), ("seconds", C.c_double)]
+                ("levels", C.c_uint64 * KMO_MAX_LEVELS), ("seconds", C.c_double),
+                ("viol_outside", C.c_int32), ("viol_action", C.c_int32), ("viol_state", C.c_uint8 * KMO_MAXSB)]
 
 
 _lib = None
@@ -69,7 +74,7 @@ def make_config(model, N=3, L=2, R=2, E=1, K=2, MaxId=10, invariants=("TypeOk",)
                 stop_on_violation=True, threads=4, max_states=0):
     mask = 0
     for n in invariants:
-        mask |= INV_BITS[n]
+        mask |= (ASYNC_INV_BITS if model == "AsyncIsr" else INV_BITS)[n]
     return Config(model=MODELS[model], N=N, L=L, R=R, E=E, K=K, MaxId=MaxId, inv_mask=mask,
                   check_deadlock=int(check_deadlock), stop_on_violation=int(stop_on_violation), threads=threads,
                   max_states=max_states)
@@ -85,14 +90,19 @@ class Run:
         r = self.res
         self.distinct, self.generated, self.depth = int(r.distinct), int(r.generated), int(r.depth)
         self.verdict = VERDICTS[r.verdict]
-        self.viol_inv = INV_NAMES[r.viol_inv] if r.viol_inv >= 0 else None
+        names = ASYNC_INV_NAMES if cfg.model == MODELS["AsyncIsr"] else INV_NAMES
+        self.viol_inv = names[r.viol_inv] if r.viol_inv >= 0 else None
         self.viol_depth = int(r.viol_depth)
-        self.viol_count = {INV_NAMES[k]: int(r.viol_count[k]) for k in range(4)}
+        self.viol_count = {names[k]: int(r.viol_count[k]) for k in range(4) if names[k] != "?"}
+        # a violating successor outside the state constraint: (parent index, action, state bytes)
+        self.viol_outside = bool(r.viol_outside)
+        self.viol_parent_idx, self.viol_action = int(r.viol_state_idx), int(r.viol_action)
         self.deadlock_states = int(r.deadlock_states)
         self.levels = [int(r.levels[i]) for i in range(min(int(r.nlevels), KMO_MAX_LEVELS))]
         self.action_generated = [int(x) for x in r.action_generated]
         self.seconds = float(r.seconds)
         self.sb = lib().kmo_state_bytes(self.h) if self.h else 0
+        self.viol_state = bytes(r.viol_state[:self.sb]) if self.viol_outside else None
 
     def level_states(self, k):
         """set of canonical-byte states first seen at level k (0-based)."""

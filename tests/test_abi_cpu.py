@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     # kmc_config: 6*i32 + i64 + u32 + 6*i32 + (pad) + 5*u64 + ptr ; kmc_result: see header
     assert C.sizeof(nat.KmcConfig) == 112
-    assert C.sizeof(nat.KmcLevelInfo) == 40 + 8 * 16 + 32 + 32 + 8 + 8 + 8
+    assert C.sizeof(nat.KmcLevelInfo) == 40 + 8 * 16 + 32 + 32 + 32 + 32 + 8 + 8 + 8
     assert C.sizeof(nat.KmcResult) == 8 * 4 + 8 + 8 + 32 + 8 + 8 + 8 * 16 + 8 * 3 + 16 + 8 + 16
 
 
@@ -45,6 +45,9 @@ def test_names():
     assert lib.kmc_action_name(2, 7) == b"BecomeFollowerTruncateToHighWatermark"
     assert lib.kmc_action_count(6) == 10 and lib.kmc_action_name(6, 9) == b"FollowerTruncate"
     assert lib.kmc_action_count(1) == 3 and lib.kmc_action_count(0) == 1
+    assert lib.kmc_model_name(7) == b"AsyncIsr" and lib.kmc_action_count(7) == 7
+    assert lib.kmc_action_name(7, 1) == b"ControllerHandleRequest" and lib.kmc_action_name(7, 6) == b"FollowerReplicate"
+    assert lib.kmc_model_invariant_name(7, 1) == b"ValidHighWatermark" and lib.kmc_model_invariant_name(5, 1) == b"WeakIsr"
 
 
 def test_specialises_for_gfx950_without_a_gpu(tmp_path):

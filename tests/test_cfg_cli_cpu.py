@@ -24,7 +24,8 @@ def test_headline_cfg_binds_to_the_headline_config():
 def test_every_shipped_cfg_parses_and_binds():
     for path in glob.glob(os.path.join(ROOT, "models", "*.cfg")):
         name = os.path.splitext(os.path.basename(path))[0]
-        module = {"Kip279_5brokers": "Kip279", "Kip320_7brokers": "Kip320", "LeaderInIsr": "Kip320"}.get(name, name)
+        module = {"Kip279_5brokers": "Kip279", "Kip320_7brokers": "Kip320", "LeaderInIsr": "Kip320",
+                  "MCAsyncIsr_small": "MCAsyncIsr", "MCAsyncIsr_outside": "MCAsyncIsr"}.get(name, name)
         c = to_checker_config(module, parse_cfg(open(path).read()))
         c.to_native()
 
@@ -50,7 +51,8 @@ def test_cfg_syntax():
     ("CONSTANTS Replicas = {b1, NONE}\nLogSize=1\nMaxRecords=1\nMaxLeaderEpoch=1", "Kip320"),  # ASSUME :42
     ("CONSTANTS Replicas = {b1, b2}\nLogSize=1\nMaxRecords=1", "Kip320"),     # MaxLeaderEpoch missing
     ("CONSTANT MaxId = 1\nINVARIANT StrongIsr", "IdSequence"),
-    ("CONSTANT MaxId = 1", "AsyncIsr"),                                        # out of scope: no lowered model
+    ("CONSTANT MaxId = 1", "AsyncIsr"),                                        # unbounded without MCAsyncIsr's constraint
+    ("CONSTANT MaxId = 1", "KafkaReplication"),                                # has no Next: no lowered model
     ("CONSTANT MaxId = 1\nPROPERTY Live", "IdSequence"),
 ])
 def test_cfg_rejections(text, module):
@@ -93,7 +95,10 @@ def test_native_cli_error_paths(tmp_path):
     assert r.returncode == 2 and "SYMMETRY is not supported" in r.stderr
     r = subprocess.run([exe, os.path.join(ROOT, "models", "AsyncIsr.tla"), "-config",
                         os.path.join(ROOT, "models", "IdSequence.cfg")], capture_output=True, text=True)
-    assert r.returncode == 2 and "no lowered model" in r.stderr
+    assert r.returncode == 2 and "unbounded" in r.stderr               # needs MCAsyncIsr's CONSTRAINT
+    r = subprocess.run([exe, os.path.join(ROOT, "models", "KafkaReplication.tla"), "-config",
+                        os.path.join(ROOT, "models", "IdSequence.cfg")], capture_output=True, text=True)
+    assert r.returncode == 2 and "no lowered model" in r.stderr        # KafkaReplication.tla has no Next
     import torch
     if not torch.cuda.is_available():
         r = subprocess.run([exe, os.path.join(ROOT, "models", "IdSequence.tla"), "-deadlock"],

@@ -18,7 +18,8 @@ from kafka_specification_amd import _native as nat
 from kafka_specification_amd.checker import CheckerConfig
 from kafka_specification_amd.sharded import DistExchange, LoopbackExchange, N_STATS, run_sharded
 
-INV_INDEX = {"TypeOk": 0, "WeakIsr": 1, "StrongIsr": 2, "LeaderInIsr": 3}
+INV_INDEX = {"TypeOk": 0, "WeakIsr": 1, "StrongIsr": 2, "LeaderInIsr": 3,
+             "ValidHighWatermark": 1, "LeaderOffsetInRange": 2}   # AsyncIsr reuses the positions
 
 
 class OracleShardEngine:
@@ -73,6 +74,12 @@ class OracleShardEngine:
                 self.st[21] += 1
             for a, t in succ:
                 self.st[1 + a] += 1
+                if self.cfg.model == "AsyncIsr" and (t[6] > self.cfg.log_size or t[1] > self.cfg.max_leader_epoch):
+                    # outside the state constraint: invariant-checked, neither kept nor shipped
+                    for name in self.cfg.invariants:
+                        if not kmo.check_invariant(self.kcfg, INV_INDEX[name], t):
+                            self.st[25 + INV_INDEX[name]] += 1
+                    continue
                 buckets[self.owner(t)].append(t)
         return [self._enc(b) for b in buckets]
 
@@ -95,7 +102,7 @@ class OracleShardEngine:
 
 
 def _names(cfg):
-    n = 10 if cfg.model == "Kip320FirstTry" else 9
+    n = 10 if cfg.model == "Kip320FirstTry" else 7 if cfg.model == "AsyncIsr" else 9
     return [f"a{k}" for k in range(n)]
 
 
@@ -188,3 +195,21 @@ def test_level_limit_and_deadlock_in_sharded_mode():
     od = kmo.Run(kmo.make_config("Kip320", N=2, L=1, R=1, E=1, check_deadlock=True))
     assert out[0]["verdict"] == out[1]["verdict"] == "deadlock" == od.verdict
     assert out[0]["levels"] == od.levels
+
+
+def test_async_isr_state_constraint_in_sharded_mode():
+    # AsyncIsr under its state constraint: successors outside it are counted as generated, checked
+    # against the invariants by the shard that generated them, and never shipped to an owner
+    kw = dict(model="AsyncIsr", n_replicas=3, log_size=2, max_leader_epoch=2)
+    o = kmo.Run(kmo.make_config("AsyncIsr", N=3, L=2, E=2, invariants=("ValidHighWatermark",)))
+    out = _run_world(dict(kw, invariants=("ValidHighWatermark",)))
+    r = out[0]
+    assert {k: v for k, v in out[1].items() if k != "local_seen"} == {k: v for k, v in r.items() if k != "local_seen"}
+    assert out[0]["local_seen"] + out[1]["local_seen"] == o.distinct
+    assert (r["verdict"], r["distinct"], r["generated"], r["levels"]) == ("ok", o.distinct, o.generated, o.levels)
+    assert r["actions"] == o.action_generated[:7]
+    inv = ("ValidHighWatermark", "LeaderOffsetInRange")
+    o = kmo.Run(kmo.make_config("AsyncIsr", N=3, L=2, E=2, invariants=inv))
+    r = _run_world(dict(kw, invariants=inv))[0]
+    assert (r["verdict"], r["viol"], r["viol_depth"]) == ("invariant", "LeaderOffsetInRange", o.viol_depth)
+    assert r["viol_count"] == o.viol_count and r["levels"] == o.levels and r["generated"] == o.generated
