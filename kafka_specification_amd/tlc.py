@@ -6,7 +6,7 @@
 Maps the root module's name to its lowered GPU model, reads constants / invariants from the
 .cfg (default: Spec.cfg next to the module), runs the exhaustive search on the GPU and prints
 TLC-style progress and summary lines.  -workers is accepted for command-line compatibility
-and ignored (the GPU's waves are the workers).  No TLA+ is parsed: only the seven modules of
+and ignored (the GPU's waves are the workers).  No TLA+ is parsed: only the modules of
 hachikuji/kafka-specification that have a Next are known.
 """
 from __future__ import annotations
