@@ -43,6 +43,24 @@ RANDOM_LOADS_PER_S = 49.8e9
 RANDOM_CAS_PER_S = 17.3e9
 
 
+def device_info():
+    """Clocks / power state of the box, for the record: identical code has measured 37 ms and 61 ms per
+    step on different boxes of the pool (every variant of a sweep equally), so a slow number needs context."""
+    import subprocess
+    info = {}
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showperflevel", "--json"],
+                             capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "performance level")):
+                info[k] = v
+    except Exception as e:  # no rocm-smi, no GPU, unexpected format: the bench does not depend on it
+        info["unavailable"] = str(e)[:80]
+    return info
+
+
 def headline_config():
     from kafka_specification_amd.configs import HEADLINE
     return dict(HEADLINE)
@@ -174,7 +192,11 @@ def main():
                                              "source": "profiles/r01_randbench.txt"},
                      "note": "aggregate over the step's per-level launches (HIP events on the engine stream); "
                              "random 8-B probes move >= one 64-B sector each, so 12.5 % useful bytes is the ceiling "
-                             "for the probe part"},
+                             "for the probe part.  Ablation on the same kernel (profiles/r01_ablation.txt): 29.6 ms "
+                             "of it is ALU work with the table untouched, read-only probes add 2.4 ms, claims 2.8 ms, "
+                             "frontier append 2.8 ms - the random-access floor is hidden under the ALU work, "
+                             "which is what bounds the kernel now"},
+        "device": device_info(),
     }
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(c, a.cpu_states)

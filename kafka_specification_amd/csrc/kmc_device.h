@@ -30,7 +30,18 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+// KMC_HOST_EMU (tests/host_emu.cpp only): the model templates below — pure integer code — are also
+// compiled by g++ so that the CPU test-suite can run every guard and effect of the device models
+// against the oracle without a GPU.  The kernels, the sink and everything wave-level are left out.
+#ifdef KMC_HOST_EMU
+#define KMC_DEV inline
+#define KMC_OPAQUE(x) ((void)0)
+#define KMC_OPAQUE_PURE(x) ((void)0)
+#else
 #define KMC_DEV __device__ __forceinline__
+#define KMC_OPAQUE(x) asm volatile("" : "+v"(x))   // opaque redefinition the optimiser may not move or delete
+#define KMC_OPAQUE_PURE(x) asm("" : "+v"(x))       // opaque, but deletable when the result is unused
+#endif
 
 #define KMC_MODE_LOCAL 0u    // probe/insert the local table, append winners to the next frontier
 #define KMC_MODE_SHARDED 1u  // bucket successors by owner(fp) into per-destination send buffers
@@ -65,6 +76,18 @@ typedef unsigned int u32;
 #endif
 #ifndef KMC_SC1_PROBE
 #define KMC_SC1_PROBE 0   // 1: probe with agent-scope (L2-bypassing) loads: fewer stale "empty" reads -> fewer lost CASes
+#endif
+#ifndef KMC_ERRCHK_TILE
+#define KMC_ERRCHK_TILE 1 // 1: the "table already full" early-out reads the error word once per tile (issued with the
+                          //    frontier loads) instead of once per flush (a dependent L2 round trip in front of every
+                          //    probe batch): -0.7 ms on the headline
+#endif
+#ifndef KMC_SETPRIO
+#define KMC_SETPRIO 1     // 1: a wave raises its issue priority while it fingerprints and probes a batch, so memory
+                          //    requests leave early and the other waves' ALU work fills the wait: -0.4 ms
+#endif
+#ifndef KMC_GUARD_VOLATILE
+#define KMC_GUARD_VOLATILE 0  // 1: the old volatile guard asm (kept every guard chain alive in every effect leaf)
 #endif
 #ifndef KMC_PREFETCH
 #define KMC_PREFETCH 0    // 1: request the next tile's state words while the current tile is processed (measured: no gain)
@@ -164,6 +187,7 @@ template <int LO, int HI, class F> KMC_DEV void kmc_dispatch(int i, F&& f) {
     }
 }
 
+#ifndef KMC_HOST_EMU
 KMC_DEV u32 kmc_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 KMC_DEV u32 kmc_rank_in(u64 mask) {  // number of set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
@@ -172,6 +196,7 @@ KMC_DEV u64 kmc_bcast64(u64 v, int src) {
     u32 lo = __builtin_amdgcn_readlane((u32)v, src), hi = __builtin_amdgcn_readlane((u32)(v >> 32), src);
     return ((u64)hi << 32) | lo;
 }
+#endif
 KMC_DEV u32 kmc_min(u32 a, u32 b) { return a < b ? a : b; }
 // Opaque redefinition: stops LICM from hoisting every action instance's guard/effect out of
 // the instance loop (they only depend on the loop-invariant state), which would keep all of
@@ -182,13 +207,21 @@ KMC_DEV u32 kmc_min(u32 a, u32 b) { return a < b ? a : b; }
 // scalar unit was the busiest pipe of the kernel).
 KMC_DEV u32 kmc_and(u32 g, bool c) {
     u32 r = c ? g : 0u;
-    asm volatile("" : "+v"(r));  // opaque: stops the fold back into select(c1 & c2, ...) = SGPR mask logic
+    // opaque: stops the fold back into select(c1 & c2, ...) = SGPR mask logic.  NOT volatile: pass 2
+    // calls inst<I> for the effect only, and a volatile asm kept every (dead) guard chain alive in
+    // every effect leaf — 29 % of the leaves' instructions, 1.1 ms of the headline kernel.  A plain
+    // asm is just as opaque to the folder but is deleted when its result is unused.
+#if KMC_GUARD_VOLATILE
+    KMC_OPAQUE(r);
+#else
+    KMC_OPAQUE_PURE(r);
+#endif
     return r;
 }
 KMC_DEV u32 kmc_bit(u32 m, int k) { return (m >> k) & 1u; }
 KMC_DEV u32 kmc_bit64(u64 m, int k) { return (u32)(m >> k) & 1u; }
-KMC_DEV void kmc_launder(u32& x) { asm volatile("" : "+v"(x)); }
-KMC_DEV void kmc_launder(u64& x) { asm volatile("" : "+v"(x)); }
+KMC_DEV void kmc_launder(u32& x) { KMC_OPAQUE(x); }
+KMC_DEV void kmc_launder(u64& x) { KMC_OPAQUE(x); }
 
 // 64-bit fingerprint of a packed state.  Never 0 (0 marks an empty table slot).
 // Every state word is absorbed through a full-avalanche bijection (the splitmix64 / murmur3
@@ -866,6 +899,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
 // ========================================================================================
 // successor sink: table probe/insert + frontier append, or owner bucketing, or enumeration
 // ========================================================================================
+#ifndef KMC_HOST_EMU  // ---- everything below is wave-level device code ----
 // Per-wave output stager: winners wait in an LDS ring (W planes x KMC_QCAP) until 64 of them
 // can be appended with ONE atomicAdd and W fully coalesced 512-byte plane stores.  (A single
 // device-scope counter saturates near 90 M atomics/s; one atomic per flush of ~20 winners
@@ -1024,11 +1058,14 @@ template <class M> struct KmcSink {
             return;
         }
         if (a.mode == KMC_MODE_LOCAL) {
-            // once any wave has found the table full the level is lost anyway: stop probing (one
-            // fresh 4-byte read per flush) so the launch ends promptly instead of walking full chains
+            // once any wave has found the table full the level is lost anyway: stop probing so the
+            // launch ends promptly instead of walking full chains (k_expand reads the flag once per
+            // tile and masks the batch, see KMC_ERRCHK_TILE; this is the per-flush variant)
+#if !KMC_ERRCHK_TILE
             if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) &
                 KMC_ERR_TABLE_FULL)
                 return;
+#endif
             // (A per-wave LDS filter of recently resolved fingerprints was tried here to skip
             // duplicate probes: only 4.9 % of the successors hit it — duplicates are not local to
             // a wave — so it was dropped.)
@@ -1115,13 +1152,20 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     out.prof = prof_acc;
 #endif
 
+    u32 table_full = 0;  // wave-uniform; KMC_ERRCHK_TILE: refreshed once per tile
     auto flush = [&](u32 nv) {  // nv <= KMC_FLUSH_N queued successors leave the ring
         u64 t0[W];
         const u32 pos0 = (head + lane) & (KMC_RING - 1);
 #pragma unroll
         for (int k = 0; k < W; ++k) t0[k] = q[k * KMC_RING + pos0];
         const u64 meta0 = has_meta ? q[W * KMC_RING + pos0] : 0ull;
-        KmcSink<M>::process(a, out, lane < nv, t0, meta0);
+#if KMC_SETPRIO
+        __builtin_amdgcn_s_setprio(2);
+#endif
+        KmcSink<M>::process(a, out, lane < nv && !table_full, t0, meta0);
+#if KMC_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         head = (head + nv) & (KMC_RING - 1);
         count -= nv;
     };
@@ -1167,8 +1211,14 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         }
 #else
         const u64 idx = seg_base + j;
+#if KMC_ERRCHK_TILE
+        const u32 errv = __hip_atomic_load(&a.ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 #pragma unroll
         for (int k = 0; k < W; ++k) s[k] = valid ? a.fin[(u64)k * a.fin_stride + idx] : 0ull;
+#if KMC_ERRCHK_TILE
+        table_full = __builtin_amdgcn_readfirstlane(errv) & KMC_ERR_TABLE_FULL;
+#endif
 #endif
         const u64 parent = (a.flags & (KMC_FLAG_TRACE | KMC_FLAG_ENUM_MATCH)) ? kmc_fingerprint<W>(s, a.seed) : 0ull;
         typename M::Pre pre = M::extract(s);
@@ -1376,3 +1426,4 @@ template <class M> KMC_DEV void kmc_find_body(const KmcArgs& a) {
     extern "C" __global__ __launch_bounds__(KMC_BLOCK) void kmc_find_##NAME(KmcArgs a) {                 \
         kmc_find_body<__VA_ARGS__>(a);                                                                   \
     }
+#endif  // !KMC_HOST_EMU

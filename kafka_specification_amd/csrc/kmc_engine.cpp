@@ -167,6 +167,28 @@ bool read_file(const std::string& path, std::vector<char>* out) {
     return ok;
 }
 
+// .vgpr_spill_count of one kernel, read from the code object's AMDGPU metadata note (msgpack: the
+// keys of a kernel's map are sorted, so the count follows the kernel's ".name" value).  -1 = not found.
+#define KMC_MAX_VGPR_SPILLS 8
+long expand_vgpr_spills(const std::vector<char>& code, const std::string& kernel) {
+    const std::string blob(code.begin(), code.end());
+    size_t at = blob.find(kernel);
+    while (at != std::string::npos) {  // the name also occurs in the symbol table: take the one inside the metadata
+        const size_t key = blob.find(".vgpr_spill_count", at);
+        const size_t next_name = blob.find(".name", at + kernel.size());
+        if (key != std::string::npos && (next_name == std::string::npos || key < next_name || key - at < 2048)) {
+            const unsigned char* q = (const unsigned char*)blob.data() + key + 17;
+            if (q[0] <= 0x7f) return q[0];
+            if (q[0] == 0xcc) return q[1];
+            if (q[0] == 0xcd) return (q[1] << 8) | q[2];
+            if (q[0] == 0xce) return ((long)q[1] << 24) | (q[2] << 16) | (q[3] << 8) | q[4];
+            return -1;
+        }
+        at = blob.find(kernel, at + 1);
+    }
+    return -1;
+}
+
 // Compile (or fetch from the cache) the code object specialised for cfg.
 int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<char>* code, std::string* kname) {
     KmcLayout lay;
@@ -206,26 +228,43 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
     const std::string path = dir + "/" + name + "-" + arch + "-" + key + ".hsaco";
     if (read_file(path, code)) return KMC_OK;
 
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "kmc_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
-        return fail(KMC_E_COMPILE, "hiprtcCreateProgram failed");
-    const std::string archopt = "--offload-arch=" + arch;
-    std::vector<const char*> opts = {archopt.c_str(), "-O3", "-std=c++17"};
-    for (const std::string& d : defines) opts.push_back(d.c_str());
-    hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
-    if (r != HIPRTC_SUCCESS) {
-        size_t n = 0;
-        hiprtcGetProgramLogSize(prog, &n);
-        std::string log(n, 0);
-        if (n) hiprtcGetProgramLog(prog, &log[0]);
-        hiprtcDestroyProgram(&prog);
-        return fail(KMC_E_COMPILE, "hiprtc failed for %s: %s\n%.1500s", name.c_str(), hiprtcGetErrorString(r), log.c_str());
-    }
+    // k_expand is compiled for 6 waves/SIMD (80 VGPRs).  Wide configurations (7-8 replicas: hundreds of
+    // action instances, several words of state) do not fit: at 184 spilled VGPRs on top of 466 spilled
+    // SGPRs, Kip320 with 7 replicas lost successors (six missing states at BFS level 3; the same code is
+    // right at -O1, at -O0 and with a larger register budget, and the model templates are right when
+    // compiled for the host — tests/test_device_models_on_host.py).  So the register budget follows the
+    // kernel: recompile with fewer waves per SIMD until k_expand spills (almost) no VGPRs.  An explicit
+    // -DKMC_MIN_WAVES in KMC_JIT_DEFINES is respected as given.
+    const bool waves_forced = defines_key.find("KMC_MIN_WAVES") != std::string::npos;
     size_t n = 0;
-    hiprtcGetCodeSize(prog, &n);
-    code->resize(n);
-    hiprtcGetCode(prog, code->data());
-    hiprtcDestroyProgram(&prog);
+    for (int waves = 6; waves >= 1;) {
+        hiprtcProgram prog;
+        if (hiprtcCreateProgram(&prog, src.c_str(), "kmc_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+            return fail(KMC_E_COMPILE, "hiprtcCreateProgram failed");
+        const std::string archopt = "--offload-arch=" + arch;
+        const std::string wavesopt = "-DKMC_MIN_WAVES=" + std::to_string(waves);
+        std::vector<const char*> opts = {archopt.c_str(), "-O3", "-std=c++17"};
+        if (!waves_forced) opts.push_back(wavesopt.c_str());
+        for (const std::string& d : defines) opts.push_back(d.c_str());
+        hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+        if (r != HIPRTC_SUCCESS) {
+            size_t ln = 0;
+            hiprtcGetProgramLogSize(prog, &ln);
+            std::string log(ln, 0);
+            if (ln) hiprtcGetProgramLog(prog, &log[0]);
+            hiprtcDestroyProgram(&prog);
+            return fail(KMC_E_COMPILE, "hiprtc failed for %s: %s\n%.1500s", name.c_str(), hiprtcGetErrorString(r), log.c_str());
+        }
+        hiprtcGetCodeSize(prog, &n);
+        code->resize(n);
+        hiprtcGetCode(prog, code->data());
+        hiprtcDestroyProgram(&prog);
+        const long spills = expand_vgpr_spills(*code, "kmc_expand_" + name);
+        if (waves_forced || spills < 0 || spills <= KMC_MAX_VGPR_SPILLS || waves == 1) break;
+        // (these kernels take up to minutes to compile: jump by the size of the overflow, do not crawl)
+        const int next = spills > 64 ? 2 : spills > 24 ? 3 : 4;
+        waves = next < waves ? next : waves - 1;
+    }
     // best-effort cache write (atomic rename)
     mkdir(dir.c_str(), 0755);
     const std::string tmp = path + ".tmp" + std::to_string((long)getpid());

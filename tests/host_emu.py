@@ -1,0 +1,70 @@
+"""Test-side binding of tests/host_emu.cpp: the DEVICE model templates compiled for the host.
+Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_emu.cpp")
+LIB = os.path.join(HERE, "_host_emu.so")
+DEPS = [SRC, os.path.join(HERE, "..", "kafka_specification_amd", "csrc", "kmc_device.h"),
+        os.path.join(HERE, "..", "kafka_specification_amd", "csrc", "kmc_layout.h")]
+_lib = None
+
+
+def build():
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS):
+        return
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        l = C.CDLL(LIB)
+        six = [C.c_int] * 6
+        l.emu_configs.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        l.emu_words.argtypes = six
+        l.emu_successors.argtypes = six + [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
+        l.emu_violated.argtypes = six + [C.POINTER(C.c_uint64), C.c_uint]
+        l.emu_init.argtypes = six + [C.POINTER(C.c_uint64)]
+        l.emu_in_model.argtypes = six + [C.POINTER(C.c_uint64)]
+        _lib = l
+    return _lib
+
+
+def configs():
+    out = (C.c_int * 6)()
+    n = lib().emu_configs(-1, out)
+    res = []
+    for i in range(n):
+        lib().emu_configs(i, out)
+        res.append(tuple(out))
+    return res
+
+
+def successors(cfg6, words, cap=4096):
+    W = lib().emu_words(*cfg6)
+    w = (C.c_uint64 * W)(*words)
+    out = (C.c_uint64 * (cap * (W + 1)))()
+    n = lib().emu_successors(*cfg6, w, out, cap)
+    assert 0 <= n <= cap
+    return [(int(out[i * (W + 1) + W]), tuple(int(out[i * (W + 1) + k]) for k in range(W))) for i in range(n)]
+
+
+def violated(cfg6, words, mask):
+    W = lib().emu_words(*cfg6)
+    return lib().emu_violated(*cfg6, (C.c_uint64 * W)(*words), mask)
+
+
+def init(cfg6):
+    W = lib().emu_words(*cfg6)
+    w = (C.c_uint64 * W)()
+    assert lib().emu_init(*cfg6, w) == 0
+    return [int(x) for x in w]
+
+
+def in_model(cfg6, words):
+    W = lib().emu_words(*cfg6)
+    return bool(lib().emu_in_model(*cfg6, (C.c_uint64 * W)(*words)))

@@ -8,6 +8,8 @@
 //   mode 5: random atomicMax without using the result (no-return atomic)
 //   mode 6: random agent-scope (sc1, L2-bypassing) loads
 // Prints G accesses/s.  Build: hipcc --offload-arch=gfx950 -O3 randbench.hip -o randbench
+// Usage: randbench [first_mode [log2_slots ...]]  — with sizes given, every mode runs on a table of
+// each size (footprint sweep: does a seen-set partition that fits L2 / Infinity Cache probe faster?)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -46,10 +48,15 @@ __global__ __launch_bounds__(256) void k(u64* table, u64 mask, int iters, int mo
     if (acc == 0x1234) sink[0] = acc;
 }
 int main(int argc, char** argv) {
-    const u64 slots = 1ull << 30;  // 8 GiB
+    const u64 max_slots = 1ull << 30;  // 8 GiB
     u64 *table, *sink;
-    hipMalloc(&table, slots * 8); hipMalloc(&sink, 8);
+    hipMalloc(&table, max_slots * 8); hipMalloc(&sink, 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    int sizes[16] = {30}, nsizes = 1;
+    if (argc > 2) { nsizes = 0; for (int i = 2; i < argc && nsizes < 16; ++i) sizes[nsizes++] = atoi(argv[i]); }
+    for (int si = 0; si < nsizes; ++si) {
+    const u64 slots = 1ull << (sizes[si] < 10 ? 10 : sizes[si] > 30 ? 30 : sizes[si]);
+    if (nsizes > 1 || argc > 2) printf("# table of 2^%d slots = %.1f MiB\n", sizes[si], slots * 8 / 1048576.0);
     for (int mode = (argc > 1 ? atoi(argv[1]) : 0); mode < 7; ++mode)
         for (int bpc : {8}) {
             hipMemset(table, 0, slots * 8);
@@ -64,5 +71,6 @@ int main(int argc, char** argv) {
             printf("mode %d blocks/CU %d: %.1f M accesses in %.2f ms = %.1f G/s (%.2f TB/s of 64-B sectors)\n", mode, bpc,
                    n / 1e6, ms, n / ms / 1e6, n * 64 / ms / 1e9);
         }
+    }
     return 0;
 }
