@@ -40,7 +40,7 @@ HBM_PEAK_BPS = 8.0e12  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # Random-access roofline of the seen-set's pattern, measured with tools/membench/randbench on an
 # MI355X (profiles/r01_randbench.txt): uniformly random 8-byte accesses over an 8 GiB table.
 RANDOM_LOADS_PER_S = 49.8e9
-RANDOM_CAS_PER_S = 17.3e9
+RANDOM_CAS_PER_S = 30.0e9   # a CAS that follows a load of the same line (randbench mode 3); 17.3e9 when issued cold
 
 
 def device_info():
@@ -189,7 +189,8 @@ def main():
                      "random_access_floor_s": mem_floor_s,
                      "frac_of_random_access_floor": mem_floor_s / max(kernel_s, 1e-12),
                      "random_access_rates": {"loads_per_s": RANDOM_LOADS_PER_S, "cas_per_s": RANDOM_CAS_PER_S,
-                                             "source": "profiles/r01_randbench.txt"},
+                                             "source": "profiles/r01_randbench.txt (loads: mode 1; claims: mode 3, "
+                                                       "load then CAS on the same line)"},
                      "note": "aggregate over the step's per-level launches (HIP events on the engine stream); "
                              "random 8-B probes move >= one 64-B sector each, so 12.5 % useful bytes is the ceiling "
                              "for the probe part.  Ablation on the same kernel (profiles/r01_ablation.txt): 29.6 ms "
