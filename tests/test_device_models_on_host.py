@@ -45,3 +45,33 @@ def test_device_model_matches_oracle_state_by_state(cfg6):
                     assert host_emu.in_model(cfg6, t) == (tb[6] <= L and tb[1] <= E)
                     for inv in range(n_inv):
                         assert bool(host_emu.violated(cfg6, t, 1 << inv)) == (not kmo.check_invariant(ocfg, inv, tb))
+
+
+@pytest.mark.parametrize("cfg6", [c for c in CONFIGS if c[0] >= 2], ids=_ids)
+def test_device_model_matches_oracle_along_random_walks(cfg6):
+    """The breadth-first prefix above only reaches shallow states; random walks through the oracle's
+    Next relation reach full logs, exhausted epochs / versions and long request histories."""
+    import random
+    model, N, L, R, E, K = cfg6
+    name = MODEL_NAMES[model]
+    ocfg = kmo.make_config(name, N=N, L=L, R=max(R, 1), E=E, K=max(K, 1), invariants=(), max_states=1, threads=1)
+    o = kmo.Run(ocfg)
+    init, sb = o.state(0), o.sb
+    n_inv = 3 if name == "AsyncIsr" else 4
+    rng = random.Random(12345 + model * 1000 + N * 100 + L * 10 + E)
+    consts = dict(n_replicas=N, log_size=L, max_records=max(R, 1), max_leader_epoch=E)
+    with ModelChecker(CheckerConfig(model=name, device=-1, **consts)) as mc:
+        for _walk in range(12):
+            s = init
+            for _step in range(80):
+                w = mc.pack(s)
+                want = sorted(kmo.successors(ocfg, s, sb))
+                got = sorted((k, mc.unpack(t)) for (k, t) in host_emu.successors(cfg6, w))
+                assert got == want
+                for inv in range(n_inv):
+                    assert bool(host_emu.violated(cfg6, w, 1 << inv)) == (not kmo.check_invariant(ocfg, inv, s))
+                nxt = [t for (_a, t) in want
+                       if name != "AsyncIsr" or (t[6] <= L and t[1] <= E)]   # stay inside the state constraint
+                if not nxt:
+                    break
+                s = rng.choice(nxt)
