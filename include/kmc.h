@@ -199,6 +199,12 @@ int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap
 int kmc_contains(kmc_handle* h, const uint64_t* words, int32_t* present);
 /* The witness of the reported violation / deadlock as a packed state. */
 int kmc_witness(kmc_handle* h, uint64_t* words);
+/* Building blocks of a trace across shards (keep_trace): the predecessor fingerprint recorded for a
+ * fingerprint this handle owns (*found = 0 when it is not in this shard's table; 0 = the initial state),
+ * and the packed initial state.  The multi-GPU driver walks the chain owner by owner, then replays it
+ * with kmc_successors on any shard. */
+int kmc_pred_of(kmc_handle* h, uint64_t fp, uint64_t* pred, int32_t* found);
+int kmc_init_state(kmc_handle* h, uint64_t* words);
 
 const char* kmc_model_name(int32_t model);
 const char* kmc_action_name(int32_t model, int32_t kind);

@@ -1174,6 +1174,26 @@ int kmc_contains(kmc_handle* h, const uint64_t* words, int32_t* present) {
     return KMC_OK;
 }
 
+int kmc_pred_of(kmc_handle* h, uint64_t fp, uint64_t* pred, int32_t* found) {
+    if (!h || !pred || !found) return fail(KMC_E_ARG, "null argument");
+    if (!h->pred) return fail(KMC_E_STATE, "kmc_pred_of needs keep_trace=1");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    uint64_t slot = 0;
+    *found = table_lookup(h, fp, &slot) == KMC_OK;
+    g_err.clear();
+    *pred = 0;
+    if (*found) HIP_TRY(hipMemcpy(pred, h->pred + slot, 8, hipMemcpyDeviceToHost));
+    return KMC_OK;
+}
+
+int kmc_init_state(kmc_handle* h, uint64_t* words) {
+    if (!h || !words) return fail(KMC_E_ARG, "null argument");
+    if (h->init_words.empty()) return fail(KMC_E_STATE, "no run has started on this handle");
+    for (int k = 0; k < h->W; ++k) words[k] = h->init_words[k];
+    return KMC_OK;
+}
+
 int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap, uint64_t* n_out) {
     if (!h || !n_out) return fail(KMC_E_ARG, "null argument");
     if (!h->pred) return fail(KMC_E_STATE, "kmc_trace needs keep_trace=1");

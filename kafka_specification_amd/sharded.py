@@ -57,6 +57,7 @@ class HipShardEngine:
         self.send = torch.zeros((n_shards, subs, scap, self.record_words), dtype=torch.int64, device=self.device)
         nat.check(self.lib.kmc_step_set_send_buffer(self.mc.handle, C.c_void_p(self.send.data_ptr()), scap))
         self._last = None
+        self._viol_fp = [0, 0, 0, 0]
 
     def close(self):
         self.torch.cuda.synchronize(self.device)
@@ -102,10 +103,39 @@ class HipShardEngine:
         st[24] = info.send_filtered
         st[22] = 1 if info.error_flags & 2 else 0
         st[23] = 1 if info.error_flags & (1 | 4) else 0
+        self._viol_fp = [int(info.violation_fp[k]) for k in range(4)]
         return st
 
     def result(self) -> CheckResult:
         return self.mc.result()
+
+    # -- trace reconstruction across shards (keep_trace) ------------------------------------------
+    def violation_fp(self, inv_index: int) -> int:
+        """Smallest fingerprint of this shard's states of the last expanded level that violate invariant k."""
+        return self._viol_fp[inv_index]
+
+    def owner(self, fp: int) -> int:
+        return (fp >> 40) % self.n_shards          # kmc_owner (csrc/kmc_device.h)
+
+    def pred_of(self, fp: int):
+        """Predecessor fingerprint recorded for fp in this shard's table, None when fp is not here."""
+        pred, found = C.c_uint64(), C.c_int32()
+        nat.check(self.lib.kmc_pred_of(self.mc.handle, C.c_uint64(fp), C.byref(pred), C.byref(found)))
+        return int(pred.value) if found.value else None
+
+    def init_words(self):
+        w = (C.c_uint64 * self.W)()
+        nat.check(self.lib.kmc_init_state(self.mc.handle, w))
+        return [int(x) for x in w]
+
+    def successors(self, words):
+        return self.mc.successors(words)            # [(words, fingerprint, action kind)], ENUM mode: no table access
+
+    def fingerprint(self, words) -> int:
+        return self.mc.fingerprint(words)
+
+    def canonical(self, words) -> bytes:
+        return self.mc.unpack(words)
 
 
 class LoopbackExchange:
@@ -302,6 +332,10 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
         pending_depth = depth
     if depth >= max_levels and new > 0 and verdict == "ok":
         verdict = "level_limit"  # (the unexpanded last frontier is not invariant-checked in sharded mode)
+    trace = []
+    if verdict == "invariant" and cfg.keep_trace and viol_depth <= len(levels):
+        # (a witness outside the state constraint, viol_depth = len(levels) + 1, is in no shard's table)
+        trace = _sharded_trace(engines, exchange, inv_names.index(viol_inv), action_names)
     local = [e.result() for e in engines]
     run_sharded.last_send_filtered = filtered  # observability for tests / bench
     return CheckResult(
@@ -312,7 +346,61 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
         table_capacity=sum(r.table_capacity for r in local), frontier_capacity=sum(r.frontier_capacity for r in local),
         seconds_total=time.perf_counter() - t0, seconds_expand=max(r.seconds_expand for r in local),
         expand_launches=max(r.expand_launches for r in local), state_words=local[0].state_words,
-        state_bits=local[0].state_bits)
+        state_bits=local[0].state_bits, trace=trace)
+
+
+def _split64(x):
+    return [x & 0xFFFFFFFF, x >> 32]
+
+
+def _sharded_trace(engines, exchange, inv_index, action_names):
+    """Counterexample of a sharded run (keep_trace): [(action name or None, canonical bytes)] from Init to
+    the witness.  Every rank executes the same steps: (1) the witness is the smallest violating
+    fingerprint over all shards (one small reduction); (2) the predecessor chain is walked owner by
+    owner — the owner of a fingerprint looks it up in its table (kmc_pred_of), one small reduction per
+    step carries the answer to everybody; (3) the chain is replayed forward from Init with the device's
+    own successor enumeration, locally, picking at each step the successor whose fingerprint is next —
+    what TLC does with its trace file [TLC-recall]."""
+    P = engines[0].n_shards
+    v = np.zeros(2 * P, dtype=np.int64)
+    for e in engines:
+        v[2 * e.shard_id:2 * e.shard_id + 2] = _split64(e.violation_fp(inv_index))
+    v = exchange.all_reduce_sum([v])
+    cands = [int(v[2 * i]) | (int(v[2 * i + 1]) << 32) for i in range(P)]
+    cands = [c for c in cands if c]
+    if not cands:
+        return []
+    chain = [min(cands)]
+    for _guard in range(1 << 16):
+        fp = chain[-1]
+        a = np.zeros(3, dtype=np.int64)
+        for e in engines:
+            if e.owner(fp) == e.shard_id:
+                pred = e.pred_of(fp)
+                if pred is not None:
+                    a[0], a[1], a[2] = 1, *_split64(pred)
+        a = exchange.all_reduce_sum([a])
+        if int(a[0]) != 1:
+            raise RuntimeError(f"trace: fingerprint {fp:016x} is in no shard's table")
+        pred = int(a[1]) | (int(a[2]) << 32)
+        if pred == 0:
+            break
+        chain.append(pred)
+    chain.reverse()
+    e0 = engines[0]
+    cur = e0.init_words()
+    if e0.fingerprint(cur) != chain[0]:
+        raise RuntimeError("trace does not start at Init")
+    out = [(None, e0.canonical(cur))]
+    for want in chain[1:]:
+        for words, fp, kind in e0.successors(cur):
+            if fp == want:
+                cur = list(words)
+                out.append((action_names[kind], e0.canonical(cur)))
+                break
+        else:
+            raise RuntimeError("trace replay lost the path")
+    return out
 
 
 def check_loopback(cfg: CheckerConfig, n_shards: int, device: int = 0, progress=None) -> CheckResult:

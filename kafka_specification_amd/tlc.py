@@ -72,9 +72,8 @@ def main(argv=None) -> int:
     try:
         if a.gpus > 1:
             from .sharded import check_loopback
-            cc.keep_trace = False
             res = check_loopback(cc, a.gpus, a.device, progress)
-            trace = []
+            trace = res.trace   # walked owner by owner through the shards' predecessor tables
         else:
             with ModelChecker(cc) as mc:
                 res = mc.run(progress)

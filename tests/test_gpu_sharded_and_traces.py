@@ -281,3 +281,29 @@ def test_sender_side_filter_drops_duplicates_but_not_states():
     finally:
         del os.environ["KMC_NO_SEND_FILTER"]
     assert (r2.distinct, r2.generated, r2.levels) == (r.distinct, r.generated, r.levels)
+
+
+@pytest.mark.parametrize("P", [2, 3])
+@pytest.mark.parametrize("model", ["Kip101", "Kip320FirstTry"])
+def test_counterexample_trace_across_shards(P, model):
+    """keep_trace with P shards: predecessor fingerprints travel with the exchanged records, the chain is
+    walked owner by owner (kmc_pred_of) and replayed with the device's successor enumeration."""
+    N, L, R, E = 3, 2, 2, 2
+    inv = ("TypeOk", "StrongIsr")
+    ocfg = kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv)
+    o = kmo.Run(ocfg)
+    assert o.verdict == "invariant"
+    cfg = CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, invariants=inv,
+                        keep_trace=True, table_capacity=1 << 20, frontier_capacity=1 << 18, send_capacity=1 << 18)
+    r = check_loopback(cfg, P)
+    assert (r.verdict, r.violated_invariant, r.violation_depth) == ("invariant", o.viol_inv, o.viol_depth)
+    assert r.levels == o.levels and r.generated == o.generated
+    trace = r.trace
+    assert len(trace) == o.viol_depth and trace[0] == (None, o.state(0))
+    with ModelChecker(CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E,
+                                    device=-1)) as mc:
+        names = mc.action_names()
+    for (_, prev), (act, cur) in zip(trace, trace[1:]):
+        assert (names.index(act), cur) in kmo.successors(ocfg, prev, o.sb)
+        assert all(kmo.check_invariant(ocfg, INV_INDEX[i], prev) for i in inv)
+    assert not kmo.check_invariant(ocfg, INV_INDEX[o.viol_inv], trace[-1][1])

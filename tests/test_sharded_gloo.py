@@ -4,8 +4,8 @@ world_size 2, backend gloo, CPU only.  The GPU engine is replaced by an oracle-b
 that implements the same begin/expand/insert/finish interface (tests may use the oracle; the
 product engine is HipShardEngine, covered by the -m gpu loopback tests)."""
 import os
+import hashlib
 import socket
-import zlib
 
 import numpy as np
 import pytest
@@ -23,8 +23,13 @@ INV_INDEX = {"TypeOk": 0, "WeakIsr": 1, "StrongIsr": 2, "LeaderInIsr": 3,
 
 
 class OracleShardEngine:
+    """Oracle-backed stand-in for HipShardEngine: same begin/expand/insert/finish interface, plus the
+    trace hooks (violation_fp / owner / pred_of / init_words / successors / fingerprint / canonical).
+    A "packed state" here is the canonical byte string padded to 8-byte words."""
+
     def __init__(self, cfg: CheckerConfig, rank, world):
         self.cfg, self.rank, self.world = cfg, rank, world
+        self.shard_id, self.n_shards = rank, world
         self.kcfg = kmo.make_config(cfg.model, N=cfg.n_replicas, L=cfg.log_size, R=cfg.max_records,
                                     E=cfg.max_leader_epoch, invariants=())
         probe = kmo.Run(kmo.make_config(cfg.model, N=cfg.n_replicas, L=cfg.log_size, R=cfg.max_records,
@@ -33,42 +38,54 @@ class OracleShardEngine:
         self.init = probe.state(0)
         probe.close()
         self.words = (self.sb + 7) // 8
-        self.seen, self.frontier, self.next = set(), [], []
+        self.rec_words = self.words + (1 if cfg.keep_trace else 0)   # the predecessor fingerprint travels for traces
+        self.seen, self.frontier, self.next = {}, [], []             # seen: state -> predecessor fingerprint
         self.level = 0
+        self._viol_fp = [0, 0, 0, 0]
         self.reset_level()
 
     def reset_level(self):
         self.st = np.zeros(N_STATS, dtype=np.int64)
 
-    def owner(self, state: bytes):
-        return zlib.crc32(state) % self.world
+    @staticmethod
+    def fp(state: bytes) -> int:
+        return int.from_bytes(hashlib.blake2b(state, digest_size=8).digest(), "little") | 1
 
-    def _enc(self, states):
-        buf = np.zeros((len(states), self.words * 8), dtype=np.uint8)
-        for i, s in enumerate(states):
+    def owner(self, fp: int) -> int:
+        return (fp >> 40) % self.world
+
+    def _enc(self, items):  # items: [(state, predecessor fingerprint)]
+        buf = np.zeros((len(items), self.rec_words * 8), dtype=np.uint8)
+        for i, (s, pred) in enumerate(items):
             buf[i, :self.sb] = np.frombuffer(s, dtype=np.uint8)
-        return torch.from_numpy(buf.view(np.int64).reshape(len(states), self.words))
+            if self.cfg.keep_trace:
+                buf[i, self.words * 8:] = np.frombuffer(pred.to_bytes(8, "little"), dtype=np.uint8)
+        return torch.from_numpy(buf.view(np.int64).reshape(len(items), self.rec_words))
 
-    def _admit(self, s: bytes):
+    def _admit(self, s: bytes, pred: int):
         if s in self.seen:
             return
-        self.seen.add(s)
+        self.seen[s] = pred
         self.next.append(s)
 
     def begin(self):
         self.reset_level()
-        if self.owner(self.init) == self.rank:
-            self._admit(self.init)
+        if self.owner(self.fp(self.init)) == self.rank:
+            self._admit(self.init, 0)
             self.st[16] = 1
         return self._close_level()
 
     def expand(self):
         self.reset_level()
+        viol = [0, 0, 0, 0]
         buckets = [[] for _ in range(self.world)]
         for s in self.frontier:
+            fps = self.fp(s)
             for name in self.cfg.invariants:  # like the GPU engine: a state is checked when it is expanded
                 if not kmo.check_invariant(self.kcfg, INV_INDEX[name], s):
-                    self.st[17 + INV_INDEX[name]] += 1
+                    k = INV_INDEX[name]
+                    self.st[17 + k] += 1
+                    viol[k] = fps if viol[k] == 0 else min(viol[k], fps)
             succ = kmo.successors(self.kcfg, s, self.sb)
             if not succ:
                 self.st[21] += 1
@@ -80,15 +97,18 @@ class OracleShardEngine:
                         if not kmo.check_invariant(self.kcfg, INV_INDEX[name], t):
                             self.st[25 + INV_INDEX[name]] += 1
                     continue
-                buckets[self.owner(t)].append(t)
+                buckets[self.owner(self.fp(t))].append((t, fps))
+        self._viol_next = viol
         return [self._enc(b) for b in buckets]
 
     def insert(self, records):
-        raw = records.contiguous().numpy().view(np.uint8).reshape(records.shape[0], self.words * 8)
+        raw = records.contiguous().numpy().view(np.uint8).reshape(records.shape[0], self.rec_words * 8)
         for i in range(raw.shape[0]):
-            self._admit(raw[i, :self.sb].tobytes())
+            pred = int.from_bytes(raw[i, self.words * 8:].tobytes(), "little") if self.cfg.keep_trace else 0
+            self._admit(raw[i, :self.sb].tobytes(), pred)
 
     def finish(self):
+        self._viol_fp = self._viol_next
         return self._close_level()
 
     def _close_level(self):
@@ -99,6 +119,31 @@ class OracleShardEngine:
     def result(self):
         from kafka_specification_amd.checker import CheckResult
         return CheckResult(0, len(self.seen), 0, 0, "ok", None, 0, {}, 0, 0, {}, [], 0, 0, 0.0, 0.0, 0, self.words, 0)
+
+    # -- trace hooks -----------------------------------------------------------------------------
+    def violation_fp(self, k):
+        return self._viol_fp[k]
+
+    def pred_of(self, fp):
+        for s, pred in self.seen.items():
+            if self.fp(s) == fp:
+                return pred
+        return None
+
+    def _pack(self, s: bytes):
+        return [int(x) for x in np.frombuffer(s.ljust(self.words * 8, b"\0"), dtype=np.uint64)]
+
+    def canonical(self, words) -> bytes:
+        return np.array(words, dtype=np.uint64).tobytes()[:self.sb]
+
+    def init_words(self):
+        return self._pack(self.init)
+
+    def fingerprint(self, words):
+        return self.fp(self.canonical(words))
+
+    def successors(self, words):
+        return [(tuple(self._pack(t)), self.fp(t), a) for a, t in kmo.successors(self.kcfg, self.canonical(words), self.sb)]
 
 
 def _names(cfg):
@@ -120,7 +165,7 @@ def _worker(rank, world, port, cfg_kw, out, round_bytes=None):
         out[rank] = dict(distinct=r.distinct, generated=r.generated, depth=r.depth, levels=r.levels, verdict=r.verdict,
                          viol=r.violated_invariant, viol_depth=r.violation_depth, viol_count=r.violation_count,
                          deadlocks=r.deadlock_states, actions=list(r.action_generated.values()),
-                         local_seen=len(eng.seen))
+                         local_seen=len(eng.seen), trace=[(a, bytes(b)) for a, b in r.trace])
     finally:
         dist.destroy_process_group()
 
@@ -213,3 +258,25 @@ def test_async_isr_state_constraint_in_sharded_mode():
     r = _run_world(dict(kw, invariants=inv))[0]
     assert (r["verdict"], r["viol"], r["viol_depth"]) == ("invariant", "LeaderOffsetInRange", o.viol_depth)
     assert r["viol_count"] == o.viol_count and r["levels"] == o.levels and r["generated"] == o.generated
+
+
+@pytest.mark.parametrize("model", ["KafkaTruncateToHighWatermark", "Kip279"])
+def test_counterexample_trace_across_two_ranks(model):
+    """keep_trace in sharded mode: predecessor fingerprints travel with the records, the chain is walked
+    owner by owner with one small reduction per step, and both ranks replay the same behaviour."""
+    inv = ("TypeOk", "StrongIsr")
+    kw = dict(model=model, n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1, invariants=inv, keep_trace=True)
+    ocfg = kmo.make_config(model, N=3, L=2, R=2, E=1, invariants=inv)
+    o = kmo.Run(ocfg)
+    assert o.verdict == "invariant"
+    out = _run_world(kw)
+    r = out[0]
+    assert out[1]["trace"] == r["trace"]                      # identical on every rank
+    assert (r["verdict"], r["viol"], r["viol_depth"]) == ("invariant", o.viol_inv, o.viol_depth)
+    trace = r["trace"]
+    assert len(trace) == o.viol_depth and trace[0] == (None, o.state(0))
+    names = _names(CheckerConfig(**kw))
+    for (_, prev), (act, cur) in zip(trace, trace[1:]):
+        assert (names.index(act), cur) in kmo.successors(ocfg, prev, o.sb)
+        assert all(kmo.check_invariant(ocfg, INV_INDEX[i], prev) for i in inv)
+    assert not kmo.check_invariant(ocfg, INV_INDEX[o.viol_inv], trace[-1][1])
