@@ -54,7 +54,9 @@ def precompile_list():
     for (N, M, V) in [(1, 1, 3), (1, 5, 3), (1, 9, 3), (1, 3, 2), (2, 1, 1), (2, 2, 2), (3, 1, 2), (3, 2, 2), (3, 2, 3),
                       (4, 1, 2), (3, 3, 4), (4, 2, 3), (5, 1, 2), (2, 6, 7), (2, 3, 1), (4, 2, 2), (2, 3, 7), (4, 3, 4)]:
         out.append(dict(model="AsyncIsr", n_replicas=N, log_size=M, max_leader_epoch=V))
-    for c in BASELINE_CONFIGS.values():
+    for name, c in BASELINE_CONFIGS.items():
+        if name == "config4_kip320_7brokers_log8":
+            continue  # 357 action instances, 9-word states: minutes of hiprtc time; specialised on first use instead
         out.append({k: v for k, v in c.items() if k != "invariants"})
     seen, uniq = set(), []
     for c in out:

@@ -511,7 +511,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
 
     // A lazy view over the packed state: fields are re-extracted on demand (one or two VALU ops
     // with compile-time offsets) instead of living in ~35 registers across the whole instance
-    // loop — the kernel is bound by waves per SIMD, not by VALU work.
+    // loop: 80 VGPRs = 6 waves/SIMD (with 95 VGPRs and 5 waves the kernel is 1.8 ms slower).
     struct Pre {
         const u64* w;  // the packed state words (the caller's registers)
         KMC_DEV u32 end(int r) const { return (u32)kmc_getbits(w, Y.end_off[r], Y.BO); }
@@ -1257,9 +1257,11 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         KMC_T(tp2);
         KMC_TADD(1, tp1, tp2);
         // Pass 2 — wave-uniform walk over the instances; only those some lane enabled dispatch
-        // to their (statically specialised) effect.  (A fall-through `switch` that only dispatches
-        // when resuming after a flush cut the branches 5x and was no faster: the kernel is bound by
-        // per-wave latency (compute chain + exposed memory waits), not by issue or branch counts.)
+        // to their (statically specialised) effect.  This loop is where the kernel's time goes
+        // (ALU-bound, ~45 % of the VALU work): an effect leaf runs for the whole
+        // wave although ~3.4 of 64 lanes enabled it.  Measured and dropped here: a fall-through
+        // `switch`, walking only the set bits of the wave-wide OR of en32 (s_ff1), per-kind
+        // `generated` counters in scalars (the array lands in scratch) or bumped with v_writelane.
         u32 cur = 0;
 #pragma clang loop unroll(disable)
         for (int i = 0; i < M::NINST; ++i) {

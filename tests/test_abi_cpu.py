@@ -198,3 +198,29 @@ def test_pack_unpack_property_random_fields():
     for mc in handles.values():
         if mc is not None:
             mc.close()
+
+
+def test_no_cached_expand_kernel_spills_vector_registers():
+    """The register budget follows the kernel (kmc_engine.cpp, get_code_object): k_expand is recompiled
+    with fewer waves per SIMD until it spills at most 8 VGPRs.  At 184 spilled VGPRs the 7-replica Kip320
+    kernel lost successors, so every code object the build step cached is checked here."""
+    import glob
+    import shutil
+    import subprocess
+    readelf = shutil.which("llvm-readelf") or "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not available")
+    files = glob.glob(os.path.join(ROOT, "kafka_specification_amd", "kmc_cache", "*.hsaco"))
+    if not files:
+        pytest.skip("kernel cache not populated (python __graft_entry__.py)")
+    seen_wide = False
+    for f in files:
+        notes = subprocess.run([readelf, "--notes", f], capture_output=True, text=True).stdout
+        blocks = notes.split(".name:")[1:]
+        expand = [b for b in blocks if b.strip().startswith("kmc_expand_")]
+        assert len(expand) == 1, f
+        spills = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", expand[0]).group(1))
+        vgprs = int(re.search(r"\.vgpr_count:\s*(\d+)", expand[0]).group(1))
+        assert spills <= 8, f"{os.path.basename(f)}: k_expand spills {spills} VGPRs at {vgprs}"
+        seen_wide = seen_wide or vgprs > 128
+    assert seen_wide   # the wide-replica kernels did get the larger budget
