@@ -52,7 +52,8 @@ def precompile_list():
         out.append(dict(model="FiniteReplicatedLog", n_replicas=2, log_size=4, n_log_records=K))
     # AsyncIsr under the state constraint of models/MCAsyncIsr.tla: (N, MaxOffset, MaxVersion)
     for (N, M, V) in [(1, 1, 3), (1, 5, 3), (1, 9, 3), (1, 3, 2), (2, 1, 1), (2, 2, 2), (3, 1, 2), (3, 2, 2), (3, 2, 3),
-                      (4, 1, 2), (3, 3, 4), (4, 2, 3), (5, 1, 2), (2, 6, 7), (2, 3, 1), (4, 2, 2), (2, 3, 7), (4, 3, 4)]:
+                      (4, 1, 2), (3, 3, 4), (4, 2, 3), (5, 1, 2), (2, 6, 7), (2, 3, 1), (4, 2, 2), (2, 3, 7), (4, 3, 4),
+                      (2, 1, 0), (2, 2, 0), (2, 3, 0), (2, 5, 0)]:
         out.append(dict(model="AsyncIsr", n_replicas=N, log_size=M, max_leader_epoch=V))
     for name, c in BASELINE_CONFIGS.items():
         if name == "config4_kip320_7brokers_log8":

@@ -227,6 +227,8 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
     const std::string dir = cfg.cache_dir ? std::string(cfg.cache_dir) : default_cache_dir();
     const std::string path = dir + "/" + name + "-" + arch + "-" + key + ".hsaco";
     if (read_file(path, code)) return KMC_OK;
+    if (getenv("KMC_VERBOSE"))
+        fprintf(stderr, "[kmc] specialising kernels for %s (first use; wide configurations take minutes)\n", name.c_str());
 
     // k_expand is compiled for 6 waves/SIMD (80 VGPRs).  Wide configurations (7-8 replicas: hundreds of
     // action instances, several words of state) do not fit: at 184 spilled VGPRs on top of 466 spilled

@@ -59,6 +59,21 @@ def test_single_replica_is_a_chain(M):
         assert (distinct, generated, depth, verdict) == (M + 1, M + 2, M + 1, "ok")
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 5])
+def test_two_replicas_version_zero_closed_form(M):
+    # N = 2, MaxVersion = 0: every controller step leaves the constraint, so in-model the controller and
+    # the leader's isr never change; what varies is whether the leader has asked to shrink ({Leader}, 0)
+    # and the offsets 0 <= o1 <= o0 <= M  =>  2 * (M+1)(M+2)/2 distinct states, the farthest after M
+    # writes, M replications and the request.  Generated, per state: ControllerShrinkIsr (outside), LeaderRequestShrinkIsr
+    # and LeaderWrite always, ControllerHandleRequest once the request exists (outside), FollowerReplicate when o1 < o0.
+    distinct = (M + 1) * (M + 2)
+    generated = 1 + 3 * distinct + distinct // 2 + M * (M + 1)
+    a = A.bfs(A.make_model("AsyncIsr", N=2, L=M, E=0), invariants=("ValidHighWatermark",))
+    o = kmo.Run(kmo.make_config("AsyncIsr", N=2, L=M, E=0, invariants=("ValidHighWatermark",)))
+    assert (a["distinct"], a["generated"], a["depth"], a["verdict"]) == (distinct, generated, 2 * M + 2, "ok")
+    assert (o.distinct, o.generated, o.depth, o.verdict) == (distinct, generated, 2 * M + 2, "ok")
+
+
 def test_typeok_is_false_in_the_initial_state():
     # pendingVersion |-> Nil (:146) with Nil == -1 (:38) is not in Nat (:44)
     a = A.bfs(A.make_model("AsyncIsr", N=3, L=2, E=2), invariants=("TypeOk",))

@@ -50,6 +50,15 @@ def test_single_replica_closed_form():
         assert (r.verdict, r.distinct, r.generated, r.depth) == ("ok", M + 1, M + 2, M + 1)
 
 
+def test_two_replicas_version_zero_closed_form():
+    for M in (1, 2, 3, 5):  # (M+1)(M+2) states: see tests/test_async_isr_cpu.py for the derivation
+        with ModelChecker(cfg_of(2, M, 0)) as mc:
+            r = mc.run()
+        distinct = (M + 1) * (M + 2)
+        assert (r.verdict, r.distinct, r.generated, r.depth) == \
+            ("ok", distinct, 1 + 3 * distinct + distinct // 2 + M * (M + 1), 2 * M + 2)
+
+
 @pytest.mark.parametrize("N,M,V", [(3, 3, 4), (4, 2, 3), (5, 1, 2), (2, 6, 7)])
 def test_larger_counts(N, M, V):
     o = kmo.Run(kmo.make_config("AsyncIsr", N=N, L=M, E=V, invariants=VHW, threads=8))
