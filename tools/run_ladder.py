@@ -31,6 +31,15 @@ RUNS = {
 }
 
 
+# level sizes of the first BFS levels from the C oracle (oracle/kmc_oracle --max-states 30000000, 8 threads):
+# the configurations that cannot be exhausted are at least checked on the prefix the CPU can reach
+ORACLE_PREFIX = {
+    "config3_kip279_5brokers_levels": [1, 10, 110, 1220, 9000, 46140, 173465, 537555, 1489900, 3772630, 8765995, 18824715],
+    "stretch_kip279_5brokers_exhaustive": [1, 10, 110, 1220, 9000, 46140, 173465, 537555, 1489900, 3772630, 8765995, 18824715],
+    "config4_kip320_7brokers_log8_levels": [1, 14, 182, 2282, 27650, 130095, 1112202, 6530965, 33198956],
+}
+
+
 def child(name):
     import kafka_specification_amd as kmc
     c = RUNS[name]
@@ -45,7 +54,12 @@ def child(name):
                seconds_total=r.seconds_total, seconds_expand=r.seconds_expand, open_seconds=t_open,
                distinct_per_s=r.distinct / max(r.seconds_total, 1e-9), state_words=r.state_words,
                state_bits=r.state_bits, table_capacity=r.table_capacity, frontier_capacity=r.frontier_capacity,
-               widest_level=max(r.levels) if r.levels else 0, trace_len=trace_len, levels_tail=r.levels[-5:])
+               widest_level=max(r.levels) if r.levels else 0, trace_len=trace_len, levels_tail=r.levels[-5:],
+               levels_head=r.levels[:12])
+    if name in ORACLE_PREFIX:
+        k = min(len(ORACLE_PREFIX[name]), len(r.levels))
+        out["oracle_prefix_levels"] = k
+        out["oracle_prefix_ok"] = r.levels[:k] == ORACLE_PREFIX[name][:k]
     print("LADDER " + json.dumps(out), flush=True)
 
 
