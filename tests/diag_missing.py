@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Diagnostic: run one Kafka-family configuration on the GPU and in the C oracle, find the first BFS
+"""Diagnostic (test infrastructure: it calls the oracle): run one Kafka-family configuration on the GPU and in the C oracle, find the first BFS
 level whose state sets differ, and say for each missing state which (parent, action) should have
 produced it and whether the device lists it among that parent's successors (ENUM mode).
-usage: tools/diag_missing.py Kip320 7 1 1 0"""
+usage: python tests/diag_missing.py Kip320 7 1 1 0"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))  # kmo = the oracle's test-side binding
 import kmo
 from kafka_specification_amd import CheckerConfig, ModelChecker
 
