@@ -200,6 +200,48 @@ def test_pack_unpack_property_random_fields():
             mc.close()
 
 
+def test_async_isr_pack_unpack_property_random_fields():
+    """hypothesis, AsyncIsr layout: random constants and random in-range field values — including the one
+    spare value per bounded field that a successor outside the state constraint carries — round-trip
+    through pack/unpack, and flipping one request bit changes the packed words."""
+    from hypothesis import given, settings, strategies as st
+
+    handles = {}
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.integers(1, 6), st.integers(1, 40), st.integers(0, 7), st.randoms(use_true_random=False))
+    def run(N, M, V, rnd):
+        key = (N, M, V)
+        if key not in handles:
+            handles[key] = ModelChecker(CheckerConfig(model="AsyncIsr", n_replicas=N, log_size=M, max_leader_epoch=V,
+                                                      device=-1))
+        mc = handles[key]
+        full = (1 << N) - 1
+        rb = ((1 << N) + 7) // 8
+        cver = rnd.randint(0, V + 1)
+        b = bytearray([rnd.randint(0, full), cver, rnd.randint(0, full), rnd.randint(0, V), rnd.randint(0, full),
+                       rnd.randint(0, V + 1)])
+        b += bytes(rnd.randint(0, M + 1) for _ in range(N))
+        req = bytearray((V + 1) * rb)
+        for v in range(V + 1):
+            for mask in range(1 << N):
+                if rnd.random() < 0.2:
+                    req[v * rb + (mask >> 3)] |= 1 << (mask & 7)
+        b += req
+        b += bytes(rnd.randint(1, full) if v < cver else 0 for v in range(V + 1))
+        b = bytes(b)
+        assert len(b) == mc.canon_bytes == 6 + N + (V + 1) * rb + V + 1
+        w = mc.pack(b)
+        assert mc.unpack(w) == b and len(w) == mc.state_words
+        b2 = bytearray(b)
+        b2[6 + N] ^= 1                                    # the request [isr {}, version 0]
+        assert mc.pack(bytes(b2)) != w
+
+    run()
+    for mc in handles.values():
+        mc.close()
+
+
 def test_no_cached_expand_kernel_spills_vector_registers():
     """The register budget follows the kernel (kmc_engine.cpp, get_code_object): k_expand is recompiled
     with fewer waves per SIMD until it spills at most 8 VGPRs.  At 184 spilled VGPRs the 7-replica Kip320
