@@ -122,6 +122,19 @@ def run_single(c, steps, warmup):
     return results, dt
 
 
+def self_launch(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,17 +143,33 @@ def main():
     ap.add_argument("--cpu-states", type=int, default=6_000_000, help="cpu_baseline sample size (distinct states)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: a small configuration instead of the headline")
+    ap.add_argument("--workload", default=None, metavar="MODEL,N,L,R,E",
+                    help="debug / tests: another Kafka-family binding instead of the headline (never a bench line)")
+    ap.add_argument("--backend", default=os.environ.get("KMC_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
+                    help="process-group backend of the N>1 leg: nccl (= RCCL, the product) or gloo (CPU launch-path test)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher — one rank per GPU under torch.distributed.run
+        # on this node (the driver's own invocation shape), and pass its exit code on.  Rank 0 prints the line.
+        sys.exit(self_launch(a.gpus))
 
     c = headline_config()
     if a.small:
         c.update(log_size=3, max_records=3)
+    if a.workload:
+        m, n, l, r, e = a.workload.split(",")
+        c.update(model=m, n_replicas=int(n), log_size=int(l), max_records=int(r), max_leader_epoch=int(e))
+        if m != "Kip320":
+            c["invariants"] = ("TypeOk",)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
 
     if a.gpus > 1 or world > 1:
         from kafka_specification_amd.sharded import bench_sharded
-        results, dt, extra = bench_sharded(c, a.steps, a.warmup)
+        if world != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+        results, dt, extra = bench_sharded(c, a.steps, a.warmup, backend=a.backend)
         scaling, parallelism = "strong", f"fingerprint-sharded x{world}, all-to-all per BFS level"
     else:
         results, dt = run_single(c, a.steps, a.warmup)

@@ -89,6 +89,16 @@ typedef unsigned int u32;
 #ifndef KMC_GUARD_VOLATILE
 #define KMC_GUARD_VOLATILE 0  // 1: the old volatile guard asm (kept every guard chain alive in every effect leaf)
 #endif
+#ifndef KMC_RING_FENCE
+#define KMC_RING_FENCE 0  // 1 (diagnostic): an explicit workgroup-scope fence between the LDS ring writes of a push and the
+                          //    reads of a flush / drain.  A wave's LDS operations are executed in order, so this must change
+                          //    nothing; it exists to rule the cross-lane ring idiom out when results differ
+#endif
+#if KMC_RING_FENCE
+#define KMC_FENCE_LDS() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#else
+#define KMC_FENCE_LDS() ((void)0)
+#endif
 #ifndef KMC_PREFETCH
 #define KMC_PREFETCH 0    // 1: request the next tile's state words while the current tile is processed (measured: no gain)
 #endif
@@ -254,6 +264,7 @@ template <long long MAXID> struct KmcIdSequence {
     struct Pre { u64 nextId; };
     static KMC_DEV void init(u64* w) { w[0] = 0; }  // IdSequence.tla:37
     static KMC_DEV Pre extract(const u64* s) { return Pre{s[0]}; }
+    static KMC_DEV Pre effect_view(const u64* s) { return extract(s); }
     static KMC_DEV void launder(Pre& p) { kmc_launder(p.nextId); }
     template <int I> static KMC_DEV u32 inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
         // Next == \E id \in IdSet : NextId(id)   (IdSequence.tla:39, NextId :30-33)
@@ -292,6 +303,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
         });
         return p;
     }
+    static KMC_DEV Pre effect_view(const u64* s) { return extract(s); }
     static KMC_DEV void launder(Pre& p) {
         for (int r = 0; r < N; ++r) { kmc_launder(p.end[r]); kmc_launder(p.logv[r]); }
     }
@@ -392,6 +404,7 @@ template <int N, int MO, int V> struct KmcAsyncIsr {
         p.reqcur = p.cver <= (u32)V ? kmc_getbits(s, Y.a_req + (int)p.cver * NS, NS) : 0ull;
         return p;
     }
+    static KMC_DEV Pre effect_view(const u64* s) { return extract(s); }
     static KMC_DEV void launder(Pre& p) {
         kmc_launder(p.cisr); kmc_launder(p.cver); kmc_launder(p.lisr); kmc_launder(p.lver);
         kmc_launder(p.pisr); kmc_launder(p.pver1); kmc_launder(p.hw); kmc_launder(p.reqcur);
@@ -564,6 +577,13 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
         return p;
     }
 
+    // the effects read fields through the lazy getters only; the guard masks are not needed for them
+    static KMC_DEV Pre effect_view(const u64* s) {
+        Pre p;
+        p.w = s;
+        p.one = 1u; p.epok = 0; p.pm = 0; p.tm = 0; p.hm = 0; p.fm = 0;
+        return p;
+    }
     static KMC_DEV void launder(Pre& p) {  // (the state words themselves are laundered by the caller)
         kmc_launder(p.one); kmc_launder(p.epok); kmc_launder(p.pm); kmc_launder(p.tm); kmc_launder(p.hm);
         kmc_launder(p.fm);
@@ -916,6 +936,7 @@ template <int W> struct KmcStager {
     KMC_DEV void drain(const KmcArgs& a, u32 n) {  // n <= 64 staged states -> next frontier
         const u32 lane = kmc_lane();
         const u32 seg = blockIdx.x % KMC_SEGS;
+        KMC_FENCE_LDS();
         u64 base = 0;
         if (lane == 0) base = atomicAdd(&a.ctl->next_count[seg].v, (u64)n);
         base = kmc_bcast64(base, 0);
@@ -1155,6 +1176,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     u32 table_full = 0;  // wave-uniform; KMC_ERRCHK_TILE: refreshed once per tile
     auto flush = [&](u32 nv) {  // nv <= KMC_FLUSH_N queued successors leave the ring
         u64 t0[W];
+        KMC_FENCE_LDS();
         const u32 pos0 = (head + lane) & (KMC_RING - 1);
 #pragma unroll
         for (int k = 0; k < W; ++k) t0[k] = q[k * KMC_RING + pos0];
@@ -1351,6 +1373,217 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     if (lane == 0 && deadlocks) atomicAdd(&a.ctl->deadlock_count, (u64)deadlocks);
 }
 
+#ifndef KMC_SUPERTILE
+#define KMC_SUPERTILE 0   // EXPERIMENTAL (compiled, never run): k_expand processes 4 tiles per wave iteration and runs
+                          // each effect leaf once for the enabled states of all four (see kmc_expand_body_st)
+#endif
+#if KMC_SUPERTILE
+// Super-tile variant of k_expand (NEXT.md item 1).  The per-tile kernel above runs an effect leaf for a
+// whole wave although ~3.4 of 64 lanes enabled the instance.  Here a wave takes KMC_ST_K consecutive tiles:
+//   phase A, per tile: coalesced load, invariants, all guards -> the lane's enabled-instance words, kept in
+//     registers; the state registers are not kept;
+//   phase B, per instance: one ballot per tile; every enabled (tile, lane) writes its one-byte id into a
+//     per-wave LDS list at its rank; lanes below the total read an id back, gather that state's W words from
+//     the frontier planes (read a moment ago: L1 hits), and the effect leaf runs on FULL lanes.
+// Everything downstream (ring, flush, sink, stager) is unchanged.
+#ifndef KMC_ST_K
+#define KMC_ST_K 4
+#endif
+#if KMC_ST_K <= 4
+typedef unsigned char kmc_stid_t;
+#else
+typedef unsigned short kmc_stid_t;
+#endif
+template <class M> KMC_DEV void kmc_expand_body_st(const KmcArgs& a) {
+    constexpr int W = M::W;
+    constexpr int NW = (M::NINST + 63) / 64;
+    constexpr int NH = 2 * NW;  // 32-bit words of the per-lane "enabled instances" bitset
+    extern __shared__ __attribute__((aligned(16))) u64 kmc_lds[];
+    __shared__ kmc_stid_t kmc_ids[KMC_BLOCK / 64][KMC_ST_K * 64];
+    const u32 lane = kmc_lane();
+    const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    kmc_stid_t* ids = kmc_ids[wib];
+    const bool has_meta = (a.flags & KMC_FLAG_META) != 0;
+    const u32 ring_planes = W + (has_meta ? 1u : 0u);
+    u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + W * KMC_QCAP);
+    KmcStager<W> out;
+    out.init(q + ring_planes * KMC_RING);
+    u32 head = 0, count = 0;
+    u32 gen_lane = 0;
+    u32 deadlocks = 0;
+#if KMC_PROFILE
+    u64 prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    out.prof = prof_acc;
+#endif
+    u32 table_full = 0;
+    auto flush = [&](u32 nv) {
+        u64 t0[W];
+        KMC_FENCE_LDS();
+        const u32 pos0 = (head + lane) & (KMC_RING - 1);
+#pragma unroll
+        for (int k = 0; k < W; ++k) t0[k] = q[k * KMC_RING + pos0];
+        const u64 meta0 = has_meta ? q[W * KMC_RING + pos0] : 0ull;
+#if KMC_SETPRIO
+        __builtin_amdgcn_s_setprio(2);
+#endif
+        KmcSink<M>::process(a, out, lane < nv && !table_full, t0, meta0);
+#if KMC_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        head = (head + nv) & (KMC_RING - 1);
+        count -= nv;
+    };
+
+    const u32 nwaves = gridDim.x * KMC_WAVES;
+    const u32 wave0 = blockIdx.x * KMC_WAVES + wib;
+#pragma clang loop unroll(disable)
+    for (int sg = 0; sg < KMC_SEGS; ++sg) {
+        const u64 seg_n = a.seg_count[sg];
+        const u64 seg_base = (u64)sg * a.seg_cap;
+        const u64 seg_supers = (seg_n + KMC_ST_K * 64 - 1) / (KMC_ST_K * 64);
+        const u32 first = (wave0 + nwaves - (u32)((sg * 977u) % nwaves)) % nwaves;
+#pragma clang loop unroll(disable)
+        for (u64 st = first; st < seg_supers; st += nwaves) {
+            const u64 super_base = st * (KMC_ST_K * 64);  // first state of this super-tile within the segment
+            // ---- phase A: guards of every tile; en[t][h] live in registers -------------------------
+            u32 en[KMC_ST_K][NH];
+#pragma unroll
+            for (int t = 0; t < KMC_ST_K; ++t)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) en[t][h] = 0;
+            const u32 errv = __hip_atomic_load(&a.ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma clang loop unroll(disable)
+            for (int t = 0; t < KMC_ST_K; ++t) {
+                const u64 j = super_base + (u64)t * 64 + lane;
+                const bool valid = j < seg_n;
+                u64 s[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) s[k] = valid ? a.fin[(u64)k * a.fin_stride + seg_base + j] : 0ull;
+                typename M::Pre pre = M::extract(s);
+                if (a.inv_mask && a.mode != KMC_MODE_ENUM && !(a.flags & KMC_FLAG_X_NOINV)) {
+                    const u32 bad = valid ? M::violated_pre(pre, a.inv_mask) : 0u;
+                    if (__ballot(bad != 0)) {
+                        if (bad) KmcSink<M>::report_violation(a, bad, kmc_fingerprint<W>(s, a.seed));
+                    }
+                }
+                u32 e32[NH];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) e32[h] = 0;
+                const u32 valid01 = valid ? 1u : 0u;
+                kmc_static_for<0, M::NINST>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    u64 tt[W];
+                    int kd;
+                    u32 ex;
+                    const u32 g01 = M::template inst<i>(pre, s, tt, kd, ex) & valid01;
+                    e32[i >> 5] |= g01 << (i & 31);
+                    kmc_launder(e32[i >> 5]);
+                });
+                u32 nsucc = 0;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) nsucc += __popc(e32[h]);
+                const u64 dm = __ballot(valid && nsucc == 0);
+                if (dm) {
+                    deadlocks += __popcll(dm);
+                    if (valid && nsucc == 0) atomicMax(&a.ctl->deadlock_fp_inv, ~kmc_fingerprint<W>(s, a.seed));
+                }
+                // park this tile's words in their registers (t is a loop variable: select, do not index)
+#pragma unroll
+                for (int tt2 = 0; tt2 < KMC_ST_K; ++tt2)
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) en[tt2][h] = (t == tt2) ? e32[h] : en[tt2][h];
+            }
+            table_full = __builtin_amdgcn_readfirstlane(errv) & KMC_ERR_TABLE_FULL;
+
+            // ---- phase B: per instance, the enabled states of all tiles on full lanes --------------
+            u32 cur[KMC_ST_K];
+#pragma clang loop unroll(disable)
+            for (int i = 0; i < M::NINST; ++i) {
+                if ((i & 31) == 0) {
+#pragma unroll
+                    for (int t = 0; t < KMC_ST_K; ++t) {
+                        cur[t] = en[t][0];
+#pragma unroll
+                        for (int h = 1; h < NH; ++h)
+                            if ((i >> 5) == h) cur[t] = en[t][h];
+                    }
+                }
+                u32 total = 0;
+#pragma unroll
+                for (int t = 0; t < KMC_ST_K; ++t) {
+                    const bool e = cur[t] & 1u;
+                    cur[t] >>= 1;
+                    const u64 m = __ballot(e);
+                    if (e) ids[total + kmc_rank_in(m)] = (kmc_stid_t)((t << 6) | lane);
+                    total += __popcll(m);
+                }
+                if (total == 0) continue;
+#pragma clang loop unroll(disable)
+                for (u32 c0 = 0; c0 < total; c0 += 64) {
+                    const bool active = c0 + lane < total;
+                    const u32 id = active ? ids[c0 + lane] : 0u;
+                    const u64 j = super_base + id;  // id = tile * 64 + source lane
+                    u64 s[W];
+#pragma unroll
+                    for (int k = 0; k < W; ++k) s[k] = active ? a.fin[(u64)k * a.fin_stride + seg_base + j] : 0ull;
+                    const u64 parent =
+                        (a.flags & (KMC_FLAG_TRACE | KMC_FLAG_ENUM_MATCH)) ? kmc_fingerprint<W>(s, a.seed) : 0ull;
+                    typename M::Pre pre = M::effect_view(s);
+                    M::launder(pre);
+#pragma unroll
+                    for (int k = 0; k < W; ++k) kmc_launder(s[k]);
+                    int kind = 0;
+                    u32 extra = 0;
+                    u64 t[W];
+                    kmc_dispatch<0, M::NINST>(i, [&](auto I) {
+                        (void)M::template inst<decltype(I)::value>(pre, s, t, kind, extra);
+                    });
+                    const u64 m = __ballot(active);
+                    const u32 n = __popcll(m);
+                    u32 weight = n;
+                    if constexpr (M::HAS_EXTRA) {
+                        u32 x = active ? extra : 0u;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+                        weight += __builtin_amdgcn_readfirstlane(x);
+                    }
+                    gen_lane += (lane == (u32)kind) ? weight : 0u;
+                    bool keep = active;
+                    u64 mk = m;
+                    if constexpr (M::HAS_CONSTRAINT) {
+                        if (a.mode == KMC_MODE_LOCAL || a.mode == KMC_MODE_SHARDED) {
+                            const bool outside = active && !M::in_model(t);
+                            if (__ballot(outside)) {
+                                if (outside && a.inv_mask) {
+                                    const u32 bad = M::violated(t, a.inv_mask);
+                                    if (bad) KmcSink<M>::report_outside_violation(a, bad, kmc_fingerprint<W>(t, a.seed));
+                                }
+                                keep = active && !outside;
+                                mk = __ballot(keep);
+                            }
+                        }
+                    }
+                    if (keep) {
+                        const u32 pos = (head + count + kmc_rank_in(mk)) & (KMC_RING - 1);
+#pragma unroll
+                        for (int k = 0; k < W; ++k) q[k * KMC_RING + pos] = t[k];
+                        if (has_meta)
+                            q[W * KMC_RING + pos] =
+                                (a.mode == KMC_MODE_ENUM && !(a.flags & KMC_FLAG_ENUM_MATCH)) ? (u64)kind : parent;
+                    }
+                    count += __popcll(mk);
+                    if (count >= KMC_FLUSH_N) flush(KMC_FLUSH_N);
+                }
+            }
+        }
+    }
+    while (count) flush(count < KMC_FLUSH_N ? count : KMC_FLUSH_N);
+    out.finish(a);
+    if (lane < (u32)M::NKINDS && gen_lane) atomicAdd(&a.ctl->generated[lane], (u64)gen_lane);
+    if (lane == 0 && deadlocks) atomicAdd(&a.ctl->deadlock_count, (u64)deadlocks);
+}
+#endif  // KMC_SUPERTILE
+
 // dynamic LDS bytes k_expand needs for a state of W words
 KMC_HD inline unsigned kmc_expand_lds_bytes(int W, bool has_meta) {
     return (unsigned)(KMC_WAVES * ((W + (has_meta ? 1 : 0)) * KMC_RING + W * KMC_QCAP) * 8);
@@ -1415,9 +1648,14 @@ template <class M> KMC_DEV void kmc_find_body(const KmcArgs& a) {
 #ifndef KMC_MIN_WAVES
 #define KMC_MIN_WAVES 6   // __launch_bounds__ second argument for k_expand: minimum waves per SIMD (LDS admits 6 blocks/CU)
 #endif
+#if KMC_SUPERTILE
+#define KMC_EXPAND_BODY kmc_expand_body_st
+#else
+#define KMC_EXPAND_BODY kmc_expand_body
+#endif
 #define KMC_INSTANTIATE(NAME, ...)                                                                       \
     extern "C" __global__ __launch_bounds__(KMC_BLOCK, KMC_MIN_WAVES) void kmc_expand_##NAME(KmcArgs a) { \
-        kmc_expand_body<__VA_ARGS__>(a);                                                                 \
+        KMC_EXPAND_BODY<__VA_ARGS__>(a);                                                                 \
     }                                                                                                    \
     extern "C" __global__ __launch_bounds__(KMC_BLOCK) void kmc_insert_##NAME(KmcArgs a) {               \
         kmc_insert_body<__VA_ARGS__>(a);                                                                 \

@@ -109,6 +109,9 @@ class HipShardEngine:
     def result(self) -> CheckResult:
         return self.mc.result()
 
+    def action_names(self):
+        return self.mc.action_names()
+
     # -- trace reconstruction across shards (keep_trace) ------------------------------------------
     def violation_fp(self, inv_index: int) -> int:
         """Smallest fingerprint of this shard's states of the last expanded level that violate invariant k."""
@@ -165,13 +168,19 @@ class DistExchange:
     """torch.distributed: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
     One engine per process."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, record_words: Optional[int] = None):
+        """`record_words` is the engine's exchange record size (state words, +1 when predecessor
+        fingerprints travel).  It must be given by the caller — every rank has to size its receive
+        buffers and its rounds identically, also a rank that has nothing to send in this level (then
+        there is no outgoing chunk to read a width from: that was a bug, non-owner ranks of BFS level 1
+        allocated 1-word receive records and the collective's counts diverged)."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.device = device if device is not None else torch.device("cpu")
+        self.record_words = record_words
 
     # all_to_all_single corrupts messages above 2 GiB on this RCCL / torch build (probe:
     # tools/a2a_probe.py — half of a 2.24 GiB message arrives wrong), so a level's exchange is
@@ -203,8 +212,14 @@ class DistExchange:
     def _deliver(self, chunks, allc):
         torch, dist = self.torch, self.dist
         P, me = self.world, self.rank
-        words = next((int(c.shape[1]) for cs in chunks for c in cs), 1)
-        dtype = next((c.dtype for cs in chunks for c in cs), torch.int64)
+        words = self.record_words
+        if words is None:
+            raise RuntimeError("DistExchange needs the engine's record_words (a rank with nothing to send cannot infer it)")
+        for cs in chunks:
+            for c in cs:
+                if int(c.shape[1]) != words:
+                    raise RuntimeError(f"exchange record width {int(c.shape[1])} != engine record_words {words}")
+        dtype = torch.int64
         if int(allc.max().item()) == 0:
             return [[]]                                  # nothing moves this level (every successor was local)
         per_dst = [torch.cat(cs, dim=0) if len(cs) > 1 else (cs[0] if cs else torch.empty((0, words), dtype=dtype,
@@ -414,50 +429,83 @@ def check_loopback(cfg: CheckerConfig, n_shards: int, device: int = 0, progress=
             e.close()
 
 
+def make_exchange(eng, device):
+    """The per-level exchange of a one-shard-per-rank job: torch.distributed's all-gather + all-to-all
+    ("nccl" = RCCL on GPUs, "gloo" on CPU)."""
+    return DistExchange(device, eng.record_words)
+
+
 def check_distributed(cfg: CheckerConfig, progress=None) -> CheckResult:
     """One shard per rank of the default process group (launch with torch.distributed.run)."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
     local = int(os.environ.get("LOCAL_RANK", rank))
-    eng = HipShardEngine(cfg, rank, world, local)
+    eng = _engine_factory()(cfg, rank, world, local)
+    device = torch.device("cuda", local) if dist.get_backend() == "nccl" else torch.device("cpu")
     try:
-        return run_sharded([eng], DistExchange(torch.device("cuda", local)), cfg, eng.mc.action_names(), progress)
+        return run_sharded([eng], make_exchange(eng, device), cfg, eng.action_names(), progress)
     finally:
         eng.close()
 
 
-def bench_sharded(c: dict, steps: int, warmup: int):
-    """bench.py's N>1 leg: strong scaling of the headline check over the ranks of this job."""
+def _engine_factory():
+    """The shard engine of the N>1 legs.  Always HipShardEngine (libkmc.so on a GPU) unless
+    KMC_SHARD_ENGINE="module:callable" names a stand-in with the same (cfg, shard, n_shards, device)
+    signature — used by the CPU test of bench.py's launch path (tests/test_bench_launch_cpu.py), which has
+    no GPU to give the real engine."""
+    spec = os.environ.get("KMC_SHARD_ENGINE")
+    if not spec:
+        return HipShardEngine
+    import importlib
+    mod, _, name = spec.partition(":")
+    return getattr(importlib.import_module(mod), name)
+
+
+def bench_sharded(c: dict, steps: int, warmup: int, backend: str = "nccl"):
+    """bench.py's N>1 leg: strong scaling of the headline check over the ranks of this job.
+    backend "nccl" (= RCCL over xGMI) is the product; "gloo" exists so that the launch / rendezvous /
+    timing / rank-0-prints path can be exercised on a CPU box with a stand-in engine."""
     import torch
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not dist.is_initialized():
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend=backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     local = int(os.environ.get("LOCAL_RANK", rank))
-    torch.cuda.set_device(local)
+    on_gpu = backend == "nccl"
+    if on_gpu:
+        if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+            raise RuntimeError(f"bench.py --gpus {world}: rank {rank} needs HIP device {local}, "
+                               f"{torch.cuda.device_count() if torch.cuda.is_available() else 0} visible "
+                               "(there is no CPU fallback)")
+        torch.cuda.set_device(local)
+    device = torch.device("cuda", local) if on_gpu else torch.device("cpu")
     per = max(1, world)
     # per rank: table for its 1/P of the states at load <= 0.5, frontier for its share of the widest
     # level (2.6e7 states) with 2x slack, send sub-buffers for its share of that level's successors
     cfg = CheckerConfig(**c, table_capacity=int(os.environ.get("KMC_BENCH_TABLE", max(1 << 27, (1 << 30) // per))),
                         frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", max(1 << 23, (1 << 26) // per))),
                         send_capacity=int(os.environ.get("KMC_BENCH_SEND", max(1 << 18, (1 << 25) // (per * per)))))
-    eng = HipShardEngine(cfg, rank, world, local)
-    ex = DistExchange(torch.device("cuda", local))
-    names = eng.mc.action_names()
+    eng = _engine_factory()(cfg, rank, world, local)
+    ex = make_exchange(eng, device)
+    names = eng.action_names()
     results = []
+
+    def sync():
+        dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
     try:
         for _ in range(warmup):
             run_sharded([eng], ex, cfg, names)
-        dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             results.append(run_sharded([eng], ex, cfg, names))
-        dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         dt = ex.all_reduce_max(time.perf_counter() - t0)
     finally:
         eng.close()
-    return results, dt, {"shards": world}
+    return results, dt, {"shards": world, "exchange": type(ex).__name__}
