@@ -37,10 +37,53 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_BPS = 8.0e12  # MI355X HBM3E peak (MI355X_MICROARCH.md)
-# Random-access roofline of the seen-set's pattern, measured with tools/membench/randbench on an
-# MI355X (profiles/r01_randbench.txt): uniformly random 8-byte accesses over an 8 GiB table.
-RANDOM_LOADS_PER_S = 49.8e9
-RANDOM_CAS_PER_S = 30.0e9   # a CAS that follows a load of the same line (randbench mode 3); 17.3e9 when issued cold
+
+
+def device_source_sha256():
+    """Identity of the device code the numbers belong to (profiles record it; a stale profile is not quoted)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kmc_layout.h", "kmc_device.h"):
+        h.update(open(os.path.join(ROOT, "kafka_specification_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def newest_profile(suffix):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return files[-1] if files else None
+
+
+def randbench_rates():
+    """The chip's random-access ceilings for the seen-set's pattern, read from the newest committed
+    profiles/rNN_randbench.txt (tools/membench/randbench: uniformly random 8-byte accesses over an 8 GiB table).
+    -> ({mode: best G accesses/s}, file) ; nothing is hard-coded here that the file could contradict."""
+    import re
+    path = newest_profile("randbench.txt")
+    rates = {}
+    if path:
+        for line in open(path):
+            m = re.match(r"mode (\d+).*=\s*([0-9.]+) G/s", line)
+            if m:
+                k, v = int(m.group(1)), float(m.group(2)) * 1e9
+                rates[k] = max(rates.get(k, 0.0), v)
+    return rates, (os.path.relpath(path, ROOT) if path else None)
+
+
+def measured_traffic():
+    """HBM bytes per k_expand launch from the newest committed PMC summary — only when it was measured on THIS
+    device code (the summary carries the sha256 of the device sources); otherwise null, with the reason."""
+    path = newest_profile("pmc_summary.json")
+    if not path:
+        return None, "no PMC summary under profiles/"
+    try:
+        j = json.load(open(path))
+    except Exception as e:
+        return None, f"{os.path.relpath(path, ROOT)}: {e}"
+    if j.get("device_source_sha256") != device_source_sha256():
+        return None, (f"{os.path.relpath(path, ROOT)} was measured on other device code "
+                      f"({str(j.get('device_source_sha256'))[:12]}..., now {device_source_sha256()[:12]}...): not quoted")
+    return j.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
 
 
 def device_info():
@@ -80,14 +123,14 @@ def expected_counts(c):
     return None
 
 
-def cpu_baseline(c, budget_states):
+def cpu_baseline(c, budget_states, total_states):
     """The C oracle (exact-state BFS, a port — TLC itself cannot run here) on all host cores,
     on a bounded prefix of the same workload: it stops after the BFS level that crosses
     `budget_states` distinct states."""
     import kmo
-    # the oracle's shared append counter and table stop scaling beyond a few dozen threads (256
-    # threads were measured slower than 8), so it runs on at most 32 of the host's cores
-    threads = min(os.cpu_count() or 1, int(os.environ.get("KMC_CPU_THREADS", 32)))
+    # every host core (round 1 capped this at 32: the level-start phases — invariants, re-hashing — ran on one
+    # thread and the rest could not help; they are sliced over the threads now)
+    threads = min(os.cpu_count() or 1, int(os.environ.get("KMC_CPU_THREADS", 256)))
     cfg = kmo.make_config(c["model"], N=c["n_replicas"], L=c["log_size"], R=c["max_records"],
                           E=c["max_leader_epoch"], invariants=c["invariants"], threads=threads,
                           max_states=budget_states)
@@ -95,9 +138,9 @@ def cpu_baseline(c, budget_states):
     run = kmo.Run(cfg)
     dt = time.time() - t0
     out = dict(value=run.distinct / max(run.seconds, 1e-9), unit="distinct states/s", cores=threads, kind="port",
-               sample=(f"first {run.depth} BFS levels of the same workload ({run.distinct} distinct states, "
-                       f"{run.seconds:.1f} s) with oracle/kmc_oracle.c, {threads} threads; "
-                       "not TLC (no JVM on this box)"),
+               sample=(f"first {run.depth} BFS levels of the same workload ({run.distinct} distinct states = "
+                       f"{100.0 * run.distinct / max(total_states, 1):.1f} % of the reachable set, {run.seconds:.1f} s) with "
+                       f"oracle/kmc_oracle.c, {threads} threads; not TLC (no JVM on this box)"),
                seconds=round(dt, 2))
     run.close()
     return out
@@ -140,7 +183,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-states", type=int, default=6_000_000, help="cpu_baseline sample size (distinct states)")
+    ap.add_argument("--cpu-states", type=int, default=0,
+                    help="cpu_baseline sample size in distinct states (default: 10 %% of the workload's reachable set; the "
+                         "oracle stops after the BFS level that crosses it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: a small configuration instead of the headline")
     ap.add_argument("--workload", default=None, metavar="MODEL,N,L,R,E",
@@ -191,16 +236,22 @@ def main():
     kernel_s = sum(x.seconds_expand for x in results) / len(results)
     launches = r.expand_launches
     achieved = alg_bytes_per_state * distinct / max(kernel_s, 1e-12)
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    # memory floor of this run under the measured random-access rates: one probe load per generated
-    # successor, one CAS per claim (about 1.11 per distinct state: ties between racing lanes)
-    mem_floor_s = generated / RANDOM_LOADS_PER_S + 1.115 * distinct / RANDOM_CAS_PER_S
+    traffic, traffic_source = measured_traffic()
+    # Secondary view — the seen-set's probes are uniformly random 8-byte accesses, which this memory system serves
+    # at a fraction of its streaming rate.  The ceilings come from tools/membench/randbench (profiles/): loads =
+    # mode 1, claims = mode 3 (a load, then a CAS on the slot when it was empty: the claim sequence itself).
+    # The two streams overlap in the kernel, so the bound is the larger of the two times, not their sum (round 1
+    # quoted the sum with a constant the profile contradicted; it exceeded the kernel's own time).
+    rates, rates_file = randbench_rates()
+    claims = 1.115 * distinct   # one CAS per new state plus the lost races (TCC_EA0_ATOMIC / distinct in profiles/)
+    random_access = None
+    if rates.get(1) and rates.get(3):
+        lb = max(generated / rates[1], claims / rates[3])
+        random_access = {
+            "probe_loads_per_s": generated / max(kernel_s, 1e-12), "probe_loads_per_s_ceiling": rates[1],
+            "claims_per_s": claims / max(kernel_s, 1e-12), "claims_per_s_ceiling": rates[3],
+            "lower_bound_s": lb, "frac_of_lower_bound": min(1.0, lb / max(kernel_s, 1e-12)),
+            "source": rates_file + " (modes 1 and 3)"}
     out = {
         "metric": "distinct states/sec + time-to-exhaustive, KafkaReplication 3-broker",
         "value": value, "unit": "distinct states/s", "n_gpus": max(a.gpus, world), "steps": a.steps,
@@ -215,21 +266,17 @@ def main():
                      "kernel": "kmc_expand_*", "kernel_seconds_per_step": kernel_s, "launches_per_step": launches,
                      "algorithmic_bytes_per_launch": alg_bytes_per_state * distinct / max(launches, 1),
                      "algorithmic_bytes_per_distinct_state": alg_bytes_per_state,
-                     "random_access_floor_s": mem_floor_s,
-                     "frac_of_random_access_floor": mem_floor_s / max(kernel_s, 1e-12),
-                     "random_access_rates": {"loads_per_s": RANDOM_LOADS_PER_S, "cas_per_s": RANDOM_CAS_PER_S,
-                                             "source": "profiles/r01_randbench.txt (loads: mode 1; claims: mode 3, "
-                                                       "load then CAS on the same line)"},
-                     "note": "aggregate over the step's per-level launches (HIP events on the engine stream); "
-                             "random 8-B probes move >= one 64-B sector each, so 12.5 % useful bytes is the ceiling "
-                             "for the probe part.  Ablation on the same kernel (profiles/r01_ablation.txt): 29.6 ms "
-                             "of it is ALU work with the table untouched, read-only probes add 2.4 ms, claims 2.8 ms, "
-                             "frontier append 2.8 ms - the random-access floor is hidden under the ALU work, "
-                             "which is what bounds the kernel now"},
+                     "traffic_source": traffic_source, "random_access": random_access,
+                     "device_source_sha256": device_source_sha256()[:16],
+                     "note": "achieved = algorithmic bytes (2*S + 8*g + 8 per distinct state) over the summed durations "
+                             "of the step's per-level k_expand launches (HIP events on the engine stream); random 8-B "
+                             "probes move >= one 64-B sector each, so 12.5 % useful bytes is the ceiling for the probe "
+                             "part.  The kernel is bound by integer ALU work, not by HBM (profiles/: ablation, "
+                             "instruction counts)"},
         "device": device_info(),
     }
     if not a.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(c, a.cpu_states)
+        out["cpu_baseline"] = cpu_baseline(c, a.cpu_states or max(1_000_000, distinct // 10), distinct)
     print(json.dumps(out))
 
 

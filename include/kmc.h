@@ -58,6 +58,8 @@ extern "C" {
 #define KMC_MAX_KINDS 16
 #define KMC_MAX_SHARDS 8
 #define KMC_SEND_SUBS 8     /* sub-buffers per destination in the send area (spreads the append counters) */
+#define KMC_COMM_ID_BYTES 128   /* an RCCL unique id (ncclUniqueId) */
+#define KMC_EXCHANGE_STATS 64   /* longest statistics vector that can ride on a level's count exchange */
 
 /* status codes */
 #define KMC_OK 0
@@ -226,6 +228,46 @@ int kmc_step_set_send_buffer(kmc_handle* h, void* dev_ptr, uint64_t records_per_
 int kmc_step_insert(kmc_handle* h, const void* dev_records, uint64_t n_records);
 int kmc_step_finish(kmc_handle* h, kmc_level_info* info); /* info->new_states: this shard's next frontier */
 int kmc_step_set_verdict(kmc_handle* h, int32_t verdict); /* driver-decided global stop reason */
+/* Invariant-only pass over the CURRENT (unexpanded) frontier — the last level under max_levels; fills
+ * info->violation_count / violation_fp. */
+int kmc_step_check_frontier(kmc_handle* h, kmc_level_info* info);
+/* KMC_ASYNC_ISR: look for a violating successor outside the state constraint (it is in no table) among the
+ * successors of the level the last kmc_step_finish retired; valid until the next kmc_step_expand. */
+int kmc_step_find_outside(kmc_handle* h, uint64_t fp, uint64_t* words, uint64_t* parent_fp, int32_t* found);
+
+/* --- the per-level exchange under the ABI (one process per GPU, RCCL over xGMI) -----------
+ * Stands where distributed TLC's FPSet servers / state queues would stand [TLC-recall]; the reference defines
+ * nothing here.  Bootstrap: rank 0 calls kmc_comm_unique_id and hands the 128 bytes to the other ranks by any
+ * means (the Python driver broadcasts them through torch.distributed's store); every rank then calls
+ * kmc_comm_init on its handle (rank = cfg.shard_id, size = cfg.n_shards).  librccl is bound with dlopen at that
+ * point — single-GPU users never need it.  Per BFS level, after kmc_step_expand:
+ *   kmc_step_exchange_counts   all-gather of the send counts + a caller-defined statistics vector (summed over
+ *                              ranks into stats_sum: the caller decides termination / verdicts from it); one
+ *                              stream synchronisation;
+ *   kmc_step_exchange_payload  grouped ncclSend/ncclRecv of every non-empty run straight from the send area into
+ *                              the receive area, then ONE k_insert over what arrived, all queued on the engine's
+ *                              stream (no host wait);
+ *   kmc_step_finish            as before.
+ * The engine must own the send area (no kmc_step_set_send_buffer). */
+int kmc_comm_unique_id(uint8_t* id /* KMC_COMM_ID_BYTES */);
+int kmc_comm_init(kmc_handle* h, const uint8_t* id /* KMC_COMM_ID_BYTES */);
+/* all-gather + a send/receive ring of a known pattern on the handle's communicator and stream, verified */
+int kmc_comm_selftest(kmc_handle* h);
+int kmc_step_exchange_counts(kmc_handle* h, const int64_t* stats, int32_t n_stats, int64_t* stats_sum,
+                             uint64_t* recv_records);
+int kmc_step_exchange_payload(kmc_handle* h);
+/* The same level step for n_shards handles living in one process on one device (RCCL refuses two ranks on one
+ * device): counts and statistics ([n_shards][n_stats]) are combined on the host, runs move device-to-device. */
+int kmc_step_exchange_local(kmc_handle** shards, int32_t n_shards, const int64_t* stats, int32_t n_stats,
+                            int64_t* stats_sum);
+int kmc_step_deliver_local(kmc_handle** shards, int32_t n_shards);
+/* The plan both transports execute, as a pure function (testable without a device).  counts[(s*P + d)*KMC_SEND_SUBS
+ * + sub] = records shard s sends to shard d from sub-buffer sub.  Writes up to cap (peer, offset_words, words)
+ * triples per list: the messages shard `me` sends (offsets into its send area) and receives (offsets into its
+ * receive area), in posting order. */
+int kmc_exchange_plan(const uint64_t* counts, int32_t n_shards, int32_t me, uint64_t send_cap, uint64_t rec_words,
+                      uint64_t* sends, uint64_t* recvs, uint64_t cap, uint64_t* n_sends, uint64_t* n_recvs,
+                      uint64_t* recv_records);
 
 #ifdef __cplusplus
 }

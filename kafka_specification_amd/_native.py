@@ -11,6 +11,8 @@ LIB_PATH = os.environ.get("KMC_LIB_PATH") or os.path.join(_HERE, "libkmc.so")  #
 KMC_MAX_KINDS = 16
 KMC_MAX_SHARDS = 8
 KMC_SEND_SUBS = 8
+KMC_COMM_ID_BYTES = 128
+KMC_EXCHANGE_STATS = 64
 
 MODELS = {
     "IdSequence": 0,
@@ -110,6 +112,18 @@ SYMBOLS = [
     ("kmc_step_insert", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("kmc_step_finish", C.c_int, [_H, C.POINTER(KmcLevelInfo)]),
     ("kmc_step_set_verdict", C.c_int, [_H, C.c_int32]),
+    ("kmc_step_check_frontier", C.c_int, [_H, C.POINTER(KmcLevelInfo)]),
+    ("kmc_step_find_outside", C.c_int, [_H, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    ("kmc_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),
+    ("kmc_comm_init", C.c_int, [_H, C.POINTER(C.c_uint8)]),
+    ("kmc_comm_selftest", C.c_int, [_H]),
+    ("kmc_step_exchange_counts", C.c_int, [_H, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
+    ("kmc_step_exchange_payload", C.c_int, [_H]),
+    ("kmc_step_exchange_local", C.c_int, [C.POINTER(_H), C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int64)]),
+    ("kmc_step_deliver_local", C.c_int, [C.POINTER(_H), C.c_int32]),
+    ("kmc_exchange_plan", C.c_int, [C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_uint64, C.c_uint64,
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 ]
 
 _lib = None

@@ -1,24 +1,162 @@
 // kmc_cli.cpp — native `tlc`-shaped front end over the C ABI (include/kmc.h); the C++ twin of
 // kafka_specification_amd/tlc.py, for hosts without Python/torch.
 //
-//   tlc [-config X.cfg] [-deadlock] [-continue] [-workers N] [-fp SEED] [-table SLOTS]
+//   tlc [-config X.cfg] [-deadlock] [-continue] [-workers N] [-fp SEED] [-fpcheck] [-verify] [-force] [-table SLOTS]
 //       [-frontier STATES] [-device D] [-notrace] Spec.tla
 //
 // [TLC-recall] flag names and output lines follow tlc2.TLC; TLC itself is not part of the
 // reference repository.  The module name selects one of the lowered models; constants
 // and invariants come from the .cfg (CONSTANT(S), INIT, NEXT, SPECIFICATION, INVARIANT(S),
-// CHECK_DEADLOCK).  No TLA+ is parsed.
+// CHECK_DEADLOCK).  No TLA+ is parsed — therefore the spec file given (and every module it EXTENDS / INSTANCEs that
+// is found beside it) is hashed against the revision the kernels were lowered from; an edited spec is refused unless
+// -force (see kafka_specification_amd/spec_revision.py, the same table).  -fpcheck repeats the search with a second
+// fingerprint seed and compares the counts; the summary prints TLC's collision-probability estimate.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <cmath>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
 #include "../../include/kmc.h"
 
 namespace {
+
+// ---- spec identity: sha256 of the reference's modules (sha256sum /root/reference/*.tla) ------------------------
+const char* const SPEC_SHA256[][2] = {
+    {"AsyncIsr", "6c29fa0de4174c9a36b1b933b43df115f53254f727cdf6b05b1c6306e77f3e46"},
+    {"FiniteReplicatedLog", "cc6193fcc9bc75be6ce2b4ab9719d9bb645c0e0441e53fda630097e13edde747"},
+    {"IdSequence", "bf8a9f74c8ccad8aa2ee4139df4297942f9a8a429afffb2e1f032833b6912654"},
+    {"KafkaReplication", "80fffc6c9e430106cb0be059f542239fa85079ffe5834493f96cbadfe122ed9a"},
+    {"KafkaTruncateToHighWatermark", "97b38e8c1d41113173784cee59c884b54554a9608ac7ddad442f80eed7af6d35"},
+    {"Kip101", "77a8ea39557ae7e19c975eb62cc1b4253761a22426c562c1e891fc361f918f6f"},
+    {"Kip279", "9568ffd395b77367722757b8a3aab999b682ab657e4fb13d41629c3696b4e39f"},
+    {"Kip320", "4f2dccca13414af26dbebeffbdb105b46973f55c79a46c04be76cde73aa963ca"},
+    {"Kip320FirstTry", "b2985bc5dad379d15cc88e838f0e3bce8e232a52a197c7f5dcd941821467d705"},
+    {"Util", "56a9514e28ac684657a91456f1f8985351bf23c9ec29d65e69a65987cfc9b385"},
+};
+
+std::string sha256_hex(const std::string& data) {  // FIPS 180-4
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+        0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+        0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+        0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+        0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    std::string m = data;
+    const uint64_t bits = (uint64_t)data.size() * 8;
+    m += (char)0x80;
+    while (m.size() % 64 != 56) m += (char)0;
+    for (int i = 7; i >= 0; --i) m += (char)(bits >> (8 * i));
+    auto rotr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+    for (size_t off = 0; off < m.size(); off += 64) {
+        uint32_t w[64];
+        for (int i = 0; i < 16; ++i)
+            w[i] = ((uint32_t)(unsigned char)m[off + 4 * i] << 24) | ((uint32_t)(unsigned char)m[off + 4 * i + 1] << 16) |
+                   ((uint32_t)(unsigned char)m[off + 4 * i + 2] << 8) | (uint32_t)(unsigned char)m[off + 4 * i + 3];
+        for (int i = 16; i < 64; ++i) {
+            const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+            const uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; ++i) {
+            const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g);
+            const uint32_t t1 = hh + S1 + ch + K[i] + w[i];
+            const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), maj = (a & b) ^ (a & c) ^ (b & c);
+            const uint32_t t2 = S0 + maj;
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    char out[65];
+    for (int i = 0; i < 8; ++i) snprintf(out + 8 * i, 9, "%08x", h[i]);
+    return out;
+}
+
+bool slurp(const std::string& path, std::string* out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[4096];
+    size_t n;
+    out->clear();
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
+    fclose(f);
+    return true;
+}
+
+std::string strip_comments(const std::string& in);
+
+// 0 = every module of the closure that exists matches, 1 = the root module file is absent, 2 = mismatch
+int check_spec(const std::string& path, const std::string& self_exe) {
+    std::string text;
+    if (!slurp(path, &text)) {
+        fprintf(stderr, "Warning: %s does not exist: checking the built-in lowering (reference revision, sha256 table in "
+                        "the front end)\n", path.c_str());
+        return 1;
+    }
+    const size_t slash = path.find_last_of('/');
+    const std::string dir = slash == std::string::npos ? "." : path.substr(0, slash);
+    std::string root = path.substr(slash == std::string::npos ? 0 : slash + 1);
+    if (root.size() > 4) root.resize(root.size() - 4);
+    static const std::set<std::string> standard = {"Integers", "Naturals", "Sequences", "FiniteSets", "TLC", "Reals", "Bags"};
+    std::vector<std::string> todo = {root};
+    std::set<std::string> seen;
+    bool bad = false;
+    while (!todo.empty()) {
+        const std::string mod = todo.back();
+        todo.pop_back();
+        if (seen.count(mod) || standard.count(mod)) continue;
+        seen.insert(mod);
+        std::string data;
+        const std::string file = dir + "/" + mod + ".tla";
+        if (!slurp(file, &data)) {
+            fprintf(stderr, "Warning: module %s: %s not found (not verified)\n", mod.c_str(), file.c_str());
+            continue;
+        }
+        std::string want;
+        for (const auto& e : SPEC_SHA256)
+            if (mod == e[0]) want = e[1];
+        if (want.empty() && mod == "MCAsyncIsr") {  // authored in this repository: compare with the copy beside the binary
+            std::string mine;
+            const size_t k = self_exe.find_last_of('/');
+            const std::string base = k == std::string::npos ? "." : self_exe.substr(0, k);
+            if (slurp(base + "/../models/MCAsyncIsr.tla", &mine)) want = sha256_hex(mine);
+        }
+        const std::string got = sha256_hex(data);
+        if (want.empty()) {
+            fprintf(stderr, "Error: module %s: not a module of the lowered revision\n", mod.c_str());
+            bad = true;
+        } else if (want != got) {
+            fprintf(stderr, "Error: module %s: %s differs from the revision the kernels were lowered from (sha256 %.16s..., "
+                            "expected %.16s...)\n", mod.c_str(), file.c_str(), got.c_str(), want.c_str());
+            bad = true;
+        }
+        const std::string t = strip_comments(data);
+        for (size_t at = t.find("EXTENDS"); at != std::string::npos; at = t.find("EXTENDS", at + 7)) {
+            size_t e = t.find('\n', at);
+            std::string line = t.substr(at + 7, (e == std::string::npos ? t.size() : e) - at - 7), name;
+            for (char ch : line + ",") {
+                if (isalnum((unsigned char)ch) || ch == '_') name += ch;
+                else { if (!name.empty()) todo.push_back(name); name.clear(); }
+            }
+        }
+        for (size_t at = t.find("INSTANCE"); at != std::string::npos; at = t.find("INSTANCE", at + 8)) {
+            size_t i = at + 8;
+            while (i < t.size() && isspace((unsigned char)t[i])) ++i;
+            std::string name;
+            while (i < t.size() && (isalnum((unsigned char)t[i]) || t[i] == '_')) name += t[i++];
+            if (!name.empty()) todo.push_back(name);
+        }
+    }
+    return bad ? 2 : 0;
+}
 
 struct Cfg {
     std::map<std::string, std::string> constants;  // raw value text ("{b1, b2}" or "6")
@@ -239,7 +377,7 @@ int main(int argc, char** argv) {
     memset(&c, 0, sizeof c);
     c.n_shards = 1;
     c.keep_trace = 1;
-    bool no_deadlock = false;
+    bool no_deadlock = false, fpcheck = false, force = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&](const char* what) -> const char* {
@@ -255,6 +393,9 @@ int main(int argc, char** argv) {
         else if (a == "-frontier") c.frontier_capacity = strtoull(val("-frontier"), nullptr, 0);
         else if (a == "-device") c.device = atoi(val("-device"));
         else if (a == "-notrace") c.keep_trace = 0;
+        else if (a == "-fpcheck") fpcheck = true;
+        else if (a == "-force") force = true;
+        else if (a == "-verify") setenv("KMC_VERIFY", "1", 1);  // every level is regenerated by a second build of the kernels
         else if (!a.empty() && a[0] == '-') { fprintf(stderr, "Error: unknown option %s\n", a.c_str()); return 2; }
         else spec = a;
     }
@@ -334,6 +475,15 @@ int main(int argc, char** argv) {
     }
     c.check_deadlock = no_deadlock ? 0 : cfg.check_deadlock;
 
+    if (check_spec(spec, argv[0]) == 2) {
+        if (!force) {
+            fprintf(stderr, "Error: the spec differs from the revision the GPU kernels were lowered from; nothing was checked "
+                            "(-force checks the built-in lowering anyway)\n");
+            return 2;
+        }
+        fprintf(stderr, "Warning: -force: checking the BUILT-IN lowering, not the text of the spec given\n");
+    }
+
     printf("kafka_specification_amd model checker (MI355X, native CLI) — module %s, config %s\n", module.c_str(), cfg_path.c_str());
     printf("Running breadth-first search Model-Checking with fp seed %llu on GPU %d.\n", (unsigned long long)c.hash_seed, c.device);
     printf("Computing initial states...\n");
@@ -386,6 +536,31 @@ int main(int argc, char** argv) {
     printf("%llu states generated, %llu distinct states found, %llu states left on queue.\n", (unsigned long long)r.generated,
            (unsigned long long)r.distinct, (unsigned long long)r.queue_left);
     printf("The depth of the complete state graph search is %llu.\n", (unsigned long long)r.depth);
+    // TLC's closing estimate [TLC-recall: "calculated (optimistic)" = distinct x (generated - distinct) / 2^64]
+    printf("The seen-set stores 64-bit fingerprints; estimates of the probability that not all reachable states were checked "
+           "because two distinct states had the same fingerprint:\n");
+    printf("  calculated (optimistic):  val = %.2E\n",
+           (double)r.distinct * (double)(r.generated > r.distinct ? r.generated - r.distinct : 0) / std::pow(2.0, 64));
+    printf("  birthday bound on the stored fingerprints:  val = %.2E\n", (double)r.distinct * (double)r.distinct / std::pow(2.0, 65));
+    if (fpcheck) {  // a collision moves with the seed: equal counts under two seeds make a silent loss very unlikely
+        kmc_close(h);
+        h = nullptr;
+        kmc_config c2 = c;
+        c2.hash_seed = c.hash_seed * 0x9E3779B97F4A7C15ull + 0x5851F42D4C957F2Dull;
+        c2.keep_trace = 0;
+        kmc_result r2;
+        if (kmc_open(&c2, &h) != KMC_OK || kmc_run(h, nullptr, nullptr) != KMC_OK || kmc_result_get(h, &r2) != KMC_OK) {
+            fprintf(stderr, "Error: %s\n", kmc_last_error());
+            if (h) kmc_close(h);
+            return 3;
+        }
+        const bool same = r2.verdict == r.verdict && r2.distinct == r.distinct && r2.generated == r.generated && r2.depth == r.depth;
+        printf("Fingerprint check: second run with fp seed %llu: %llu states generated, %llu distinct states found, depth %llu - %s\n",
+               (unsigned long long)c2.hash_seed, (unsigned long long)r2.generated, (unsigned long long)r2.distinct,
+               (unsigned long long)r2.depth,
+               same ? "identical to the first run." : "DIFFERENT from the first run: a fingerprint collision dropped states in at least one of them.");
+        if (!same && rc == 0) rc = 13;
+    }
     printf("Finished in %.3fs (%.0f distinct states/s; %.3fs in the expand kernel) at (%s)\n", r.seconds_total,
            r.distinct / (r.seconds_total > 1e-9 ? r.seconds_total : 1e-9), r.seconds_expand, now().c_str());
     kmc_close(h);

@@ -99,6 +99,11 @@ typedef unsigned int u32;
 #else
 #define KMC_FENCE_LDS() ((void)0)
 #endif
+#ifdef KMC_CONST_INV_MASK     // tuning / code-size experiments: the checked invariants as a compile-time constant
+#define KMC_INV_MASK(a) ((u32)(KMC_CONST_INV_MASK))
+#else
+#define KMC_INV_MASK(a) ((a).inv_mask)
+#endif
 #ifndef KMC_PREFETCH
 #define KMC_PREFETCH 0    // 1: request the next tile's state words while the current tile is processed (measured: no gain)
 #endif
@@ -127,7 +132,6 @@ struct alignas(128) KmcCounterLine {
 // One per BFS level; the host zeroes it before the level runs and reads it back after.
 struct alignas(128) KmcLevelCtl {
     KmcCounterLine next_count[KMC_SEGS];  // states appended to each segment of the next frontier
-    KmcCounterLine send_count[KMC_MAX_SHARDS][KMC_SEGS];  // SHARDED: records bucketed per (destination, sub-buffer)
     u64 generated[KMC_MAX_KINDS];    // successors generated per action kind (Next disjunct)
     u64 viol_count[4];               // states of the EXPANDED level violating invariant k
     u64 viol_fp_inv[4];              // max over violators of ~fp  (=> min fp), 0 = none
@@ -139,8 +143,11 @@ struct alignas(128) KmcLevelCtl {
     u64 oviol_fp_inv[4];             // max over those of ~fp
     u64 prof[8];                     // KMC_PROFILE: summed per-wave s_memtime ticks per phase (tuning aid)
     u32 err;
-    u32 pad;
+    u32 halt;                        // chained launches: this level was not expanded because an earlier one ended the search
+    // (everything above is what a single-GPU level reports: the host copies the block only up to here)
+    alignas(128) KmcCounterLine send_count[KMC_MAX_SHARDS][KMC_SEGS];  // SHARDED: records bucketed per (destination, sub-buffer)
 };
+#define KMC_CTL_LOCAL_BYTES (__builtin_offsetof(KmcLevelCtl, send_count))
 
 struct KmcArgs {
     // Frontiers are SoA: word k of the state at slot i lives at f[k*stride + i].  A frontier is
@@ -169,6 +176,12 @@ struct KmcArgs {
     u32 shard;         // this handle's shard id (SHARDED mode keeps its own successors local)
     u32 rec_words;     // exchange record size in words: W, or W+1 when predecessor fingerprints travel (trace)
     u64 match_fp;      // ENUM with KMC_FLAG_ENUM_MATCH: list only successors with this fingerprint (meta = parent fp)
+    // Chained launches (kmc_run without a progress callback): the host queues several BFS levels back to back and
+    // waits once per batch instead of once per level.  The level then takes its input sizes from the control block of
+    // the level that produced `fin`, and does nothing when that level (or one before it) ended the search.
+    const KmcLevelCtl* prev;  // null: seg_count[] above is authoritative
+    u32 stop_mask;            // invariants whose violation ends the search (0 under -continue)
+    u32 stop_deadlock;        // CHECK_DEADLOCK: a state without successors ends the search
 };
 
 // ----------------------------------------------------------------------------------------
@@ -264,7 +277,6 @@ template <long long MAXID> struct KmcIdSequence {
     struct Pre { u64 nextId; };
     static KMC_DEV void init(u64* w) { w[0] = 0; }  // IdSequence.tla:37
     static KMC_DEV Pre extract(const u64* s) { return Pre{s[0]}; }
-    static KMC_DEV Pre effect_view(const u64* s) { return extract(s); }
     static KMC_DEV void launder(Pre& p) { kmc_launder(p.nextId); }
     template <int I> static KMC_DEV u32 inst(const Pre& p, const u64* s, u64* t, int& kind, u32& extra) {
         // Next == \E id \in IdSet : NextId(id)   (IdSequence.tla:39, NextId :30-33)
@@ -303,7 +315,6 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
         });
         return p;
     }
-    static KMC_DEV Pre effect_view(const u64* s) { return extract(s); }
     static KMC_DEV void launder(Pre& p) {
         for (int r = 0; r < N; ++r) { kmc_launder(p.end[r]); kmc_launder(p.logv[r]); }
     }
@@ -404,7 +415,6 @@ template <int N, int MO, int V> struct KmcAsyncIsr {
         p.reqcur = p.cver <= (u32)V ? kmc_getbits(s, Y.a_req + (int)p.cver * NS, NS) : 0ull;
         return p;
     }
-    static KMC_DEV Pre effect_view(const u64* s) { return extract(s); }
     static KMC_DEV void launder(Pre& p) {
         kmc_launder(p.cisr); kmc_launder(p.cver); kmc_launder(p.lisr); kmc_launder(p.lver);
         kmc_launder(p.pisr); kmc_launder(p.pver1); kmc_launder(p.hw); kmc_launder(p.reqcur);
@@ -577,13 +587,6 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
         return p;
     }
 
-    // the effects read fields through the lazy getters only; the guard masks are not needed for them
-    static KMC_DEV Pre effect_view(const u64* s) {
-        Pre p;
-        p.w = s;
-        p.one = 1u; p.epok = 0; p.pm = 0; p.tm = 0; p.hm = 0; p.fm = 0;
-        return p;
-    }
     static KMC_DEV void launder(Pre& p) {  // (the state words themselves are laundered by the caller)
         kmc_launder(p.one); kmc_launder(p.epok); kmc_launder(p.pm); kmc_launder(p.tm); kmc_launder(p.hm);
         kmc_launder(p.fm);
@@ -867,46 +870,106 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
     // ---- invariants; bit k of the result = invariant k violated ---------------------------
     // 0 TypeOk (:101-107)  1 WeakIsr (:320-326)  2 StrongIsr (:334-340)  3 LeaderInIsr (:345)
     static KMC_DEV u32 violated(const u64* t, u32 inv_mask) { return violated_pre(extract(t), inv_mask); }
+    // --- TypeOk's log part, per replica (ReplicaLog!TypeOk, FiniteReplicatedLog.tla:90-95 with LogRecords of
+    // KafkaReplication.tla:82): slots below endOffset hold an element of LogRecords, slots from endOffset on are Nil.
+    // Evaluated in the integer domain on the whole log word (a bool chain per slot was 400 VALU instructions per
+    // tile, a fifth of k_expand's arithmetic):
+    //   * fold every slot onto its lowest bit ("slot is non-Nil"); the non-Nil slots must be exactly the prefix
+    //     [0, endOffset) — one compare against the prefix mask covers both "written below" and "Nil above";
+    //   * every slot's code must be Nil or a member of LogRecords: a 2^BR-bit membership map indexed by the code
+    //     (id+1 in 1..R, epoch in 0..E), one extract + one lookup per slot.
+    static constexpr u64 valid_code_map() {  // bit c: code c is Nil or \in LogRecords  (meaningful when BR <= 6)
+        u64 m = 1ull;
+        for (int c = 1; c < (Y.BR <= 6 ? (1 << Y.BR) : 1); ++c) {
+            const int id1 = c >> Y.BEr, ep = c & ((1 << Y.BEr) - 1);
+            if (id1 >= 1 && id1 <= R && ep <= E) m |= 1ull << c;
+        }
+        return m;
+    }
+    static constexpr LogT low_bits() {  // the lowest bit of every slot
+        LogT m = 0;
+        for (int o = 0; o < L; ++o) m |= (LogT)((LogT)1 << (o * Y.BR));
+        return m;
+    }
+    template <int r> static KMC_DEV u32 log_type_bad(const Pre& p) {  // 0 = ReplicaLog!TypeOk holds for replica r
+        const LogT lv = p.logv(r);
+        const u32 end = p.end(r);
+        LogT fold = lv;
+#pragma unroll
+        for (int b = 1; b < Y.BR; ++b) fold |= (LogT)(lv >> b);
+        fold &= low_bits();
+        // end > L is rejected on its own (the caller tests end <= L); keep_below saturates there
+        u32 bad = fold != (LogT)(keep_below(end) & low_bits()) ? 1u : 0u;
+        if constexpr (Y.BR <= 6) {
+            constexpr u64 MAP = valid_code_map();
+            u32 okall = 1u;
+            kmc_static_for<0, L>([&](auto O) {
+                constexpr int o = decltype(O)::value;
+                const u32 c = rec_at(lv, o);
+                if constexpr (Y.BR <= 5) okall &= ((u32)MAP >> c);
+                else okall &= (u32)(MAP >> c);
+            });
+            bad |= (okall & 1u) ^ 1u;
+        } else {
+            kmc_static_for<0, L>([&](auto O) {
+                constexpr int o = decltype(O)::value;
+                const u32 c = rec_at(lv, o);
+                const u32 id1 = c >> Y.BEr;
+                bad |= (c != 0 && !(id1 >= 1 && id1 <= (u32)R && rec_epoch(c) <= (u32)E)) ? 1u : 0u;
+            });
+        }
+        return bad;
+    }
+
     static KMC_DEV u32 violated_pre(const Pre& p, u32 inv_mask) {
         if (inv_mask == 0) return 0;
         u32 bad = 0;
         if (inv_mask & 1u) {
-            bool ok = p.nextEp() <= (u32)(E + 1) && p.nextRec() <= (u32)R && p.qep1() <= (u32)(E + 1) && p.qldr1() <= (u32)N;
+            // TypeOk (KafkaReplication.tla:101-107); comparisons a field's width already implies fold away
+            u32 nb = (p.nextEp() > (u32)(E + 1) ? 1u : 0u) | (p.nextRec() > (u32)R ? 1u : 0u) |
+                     (p.qep1() > (u32)(E + 1) ? 1u : 0u) | (p.qldr1() > (u32)N ? 1u : 0u);
             kmc_static_for<0, N>([&](auto RR) {
                 constexpr int r = decltype(RR)::value;
-                ok = ok && p.end(r) <= (u32)L && p.hw(r) <= (u32)L && p.ep1(r) <= (u32)(E + 1) && p.ldr1(r) <= (u32)N;
-                kmc_static_for<0, L>([&](auto O) {
-                    constexpr int o = decltype(O)::value;
-                    const u32 c = rec_at(p.logv(r), o);
-                    const u32 id1 = c >> Y.BEr;
-                    const bool in_records = id1 >= 1 && id1 <= (u32)R && rec_epoch(c) <= (u32)E;
-                    ok = ok && ((u32)o < p.end(r) ? in_records : c == 0);
-                });
+                nb |= (p.end(r) > (u32)L ? 1u : 0u) | (p.hw(r) > (u32)L ? 1u : 0u) | (p.ep1(r) > (u32)(E + 1) ? 1u : 0u) |
+                      (p.ldr1(r) > (u32)N ? 1u : 0u);
+                nb |= log_type_bad<r>(p);
             });
             kmc_static_for<0, E + 1>([&](auto EE) {
                 constexpr int e = decltype(EE)::value;
-                if ((u32)e < p.nextEp()) ok = ok && p.rldr1(e) <= (u32)N;
+                nb |= ((u32)e < p.nextEp() && p.rldr1(e) > (u32)N) ? 1u : 0u;
             });
-            if (!ok) bad |= 1u;
+            bad |= nb & 1u;
         }
         if (inv_mask & 6u) {
-            bool weak = true, strong = true;
+            // WeakIsr (:320-326) / StrongIsr (:334-340), integer domain: for a replica r1 that presumes leadership
+            // with hw > 0, every r2 of its isr (weak) / of quorumState.isr (strong) must agree with it below hw:
+            // \A offset < hw : \E record : HasEntry(r1, ..) /\ HasEntry(r2, ..)  <=>  hw <= end1, hw <= end2 and the two
+            // logs are equal on the slots below hw.
+            u32 wbad = 0, sbad = 0;
+            const u32 qisr = p.qisr();
             kmc_static_for<0, N>([&](auto R1) {
                 constexpr int r1 = decltype(R1)::value;
                 const u32 hw = p.hw(r1);
-                if (presumes<r1>(p) && hw > 0) {
-                    kmc_static_for<0, N>([&](auto R2) {
-                        constexpr int r2 = decltype(R2)::value;
-                        // \A offset < hw : \E record : HasEntry(r1,..) /\ HasEntry(r2,..)
-                        const bool same = hw <= p.end(r1) && hw <= p.end(r2) &&
-                                          ((p.logv(r1) ^ p.logv(r2)) & keep_below(hw)) == 0;
-                        if (p.isr(r1) >> r2 & 1u) weak = weak && same;
-                        if (p.qisr() >> r2 & 1u) strong = strong && same;
-                    });
-                }
+                const u32 act = (presumes<r1>(p) && hw > 0) ? 1u : 0u;
+                const LogT kb = keep_below(hw);
+                const LogT l1 = p.logv(r1);
+                const u32 short1 = hw > p.end(r1) ? 1u : 0u;
+                u32 differs = 0;  // bit r2: r2 does NOT agree with r1 below hw
+                kmc_static_for<0, N>([&](auto R2) {
+                    constexpr int r2 = decltype(R2)::value;
+                    u32 d = short1;
+                    if constexpr (r2 != r1) {
+                        d |= hw > p.end(r2) ? 1u : 0u;
+                        d |= ((LogT)((l1 ^ p.logv(r2)) & kb)) != 0 ? 1u : 0u;
+                    }
+                    differs |= d << r2;
+                });
+                const u32 m = act ? differs : 0u;
+                wbad |= m & p.isr(r1);
+                sbad |= m & qisr;
             });
-            if ((inv_mask & 2u) && !weak) bad |= 2u;
-            if ((inv_mask & 4u) && !strong) bad |= 4u;
+            if ((inv_mask & 2u) && wbad) bad |= 2u;
+            if ((inv_mask & 4u) && sbad) bad |= 4u;
         }
         if (inv_mask & 8u) {
             const bool ok = p.qldr1() != 0 && (p.qisr() >> (p.qldr1() - 1) & 1u);
@@ -1197,9 +1260,26 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     // SGPRs for the whole kernel.)
     const u32 nwaves = gridDim.x * KMC_WAVES;
     const u32 wave0 = blockIdx.x * KMC_WAVES + wib;
+    if (a.prev) {
+        // chained launch: every wave reads the finished control block of the producing level (wave-uniform values)
+        const KmcLevelCtl* pv = a.prev;
+        u32 stop = pv->halt | pv->err;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            stop |= ((a.stop_mask >> k & 1u) && (pv->viol_count[k] | pv->oviol_count[k])) ? 1u : 0u;
+        if (a.stop_deadlock && pv->deadlock_count) stop |= 1u;
+        if (__builtin_amdgcn_readfirstlane(stop)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl->halt = 1u;
+            return;
+        }
+    }
 #pragma clang loop unroll(disable)
     for (int sg = 0; sg < KMC_SEGS; ++sg) {
-    const u64 seg_n = a.seg_count[sg];
+    u64 seg_n = a.seg_count[sg];
+    if (a.prev) {
+        const u64 made = a.prev->next_count[sg].v;
+        seg_n = made < a.seg_cap ? made : a.seg_cap;
+    }
     const u64 seg_base = (u64)sg * a.seg_cap;
     const u64 seg_tiles = (seg_n + 63) >> 6;
     // rotate the starting wave per segment so that short segments do not always land on the same waves
@@ -1246,8 +1326,8 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         typename M::Pre pre = M::extract(s);
 
         // Invariants of the states of THIS level (see KmcSink::report_violation)
-        if (a.inv_mask && a.mode != KMC_MODE_ENUM && !(a.flags & KMC_FLAG_X_NOINV)) {
-            const u32 bad = valid ? M::violated_pre(pre, a.inv_mask) : 0u;
+        if (KMC_INV_MASK(a) && a.mode != KMC_MODE_ENUM && !(a.flags & KMC_FLAG_X_NOINV)) {
+            const u32 bad = valid ? M::violated_pre(pre, KMC_INV_MASK(a)) : 0u;
             if (__ballot(bad != 0)) {
                 if (bad) KmcSink<M>::report_violation(a, bad, kmc_fingerprint<W>(s, a.seed));
             }
@@ -1373,217 +1453,6 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     if (lane == 0 && deadlocks) atomicAdd(&a.ctl->deadlock_count, (u64)deadlocks);
 }
 
-#ifndef KMC_SUPERTILE
-#define KMC_SUPERTILE 0   // EXPERIMENTAL (compiled, never run): k_expand processes 4 tiles per wave iteration and runs
-                          // each effect leaf once for the enabled states of all four (see kmc_expand_body_st)
-#endif
-#if KMC_SUPERTILE
-// Super-tile variant of k_expand (NEXT.md item 1).  The per-tile kernel above runs an effect leaf for a
-// whole wave although ~3.4 of 64 lanes enabled the instance.  Here a wave takes KMC_ST_K consecutive tiles:
-//   phase A, per tile: coalesced load, invariants, all guards -> the lane's enabled-instance words, kept in
-//     registers; the state registers are not kept;
-//   phase B, per instance: one ballot per tile; every enabled (tile, lane) writes its one-byte id into a
-//     per-wave LDS list at its rank; lanes below the total read an id back, gather that state's W words from
-//     the frontier planes (read a moment ago: L1 hits), and the effect leaf runs on FULL lanes.
-// Everything downstream (ring, flush, sink, stager) is unchanged.
-#ifndef KMC_ST_K
-#define KMC_ST_K 4
-#endif
-#if KMC_ST_K <= 4
-typedef unsigned char kmc_stid_t;
-#else
-typedef unsigned short kmc_stid_t;
-#endif
-template <class M> KMC_DEV void kmc_expand_body_st(const KmcArgs& a) {
-    constexpr int W = M::W;
-    constexpr int NW = (M::NINST + 63) / 64;
-    constexpr int NH = 2 * NW;  // 32-bit words of the per-lane "enabled instances" bitset
-    extern __shared__ __attribute__((aligned(16))) u64 kmc_lds[];
-    __shared__ kmc_stid_t kmc_ids[KMC_BLOCK / 64][KMC_ST_K * 64];
-    const u32 lane = kmc_lane();
-    const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    kmc_stid_t* ids = kmc_ids[wib];
-    const bool has_meta = (a.flags & KMC_FLAG_META) != 0;
-    const u32 ring_planes = W + (has_meta ? 1u : 0u);
-    u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + W * KMC_QCAP);
-    KmcStager<W> out;
-    out.init(q + ring_planes * KMC_RING);
-    u32 head = 0, count = 0;
-    u32 gen_lane = 0;
-    u32 deadlocks = 0;
-#if KMC_PROFILE
-    u64 prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    out.prof = prof_acc;
-#endif
-    u32 table_full = 0;
-    auto flush = [&](u32 nv) {
-        u64 t0[W];
-        KMC_FENCE_LDS();
-        const u32 pos0 = (head + lane) & (KMC_RING - 1);
-#pragma unroll
-        for (int k = 0; k < W; ++k) t0[k] = q[k * KMC_RING + pos0];
-        const u64 meta0 = has_meta ? q[W * KMC_RING + pos0] : 0ull;
-#if KMC_SETPRIO
-        __builtin_amdgcn_s_setprio(2);
-#endif
-        KmcSink<M>::process(a, out, lane < nv && !table_full, t0, meta0);
-#if KMC_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        head = (head + nv) & (KMC_RING - 1);
-        count -= nv;
-    };
-
-    const u32 nwaves = gridDim.x * KMC_WAVES;
-    const u32 wave0 = blockIdx.x * KMC_WAVES + wib;
-#pragma clang loop unroll(disable)
-    for (int sg = 0; sg < KMC_SEGS; ++sg) {
-        const u64 seg_n = a.seg_count[sg];
-        const u64 seg_base = (u64)sg * a.seg_cap;
-        const u64 seg_supers = (seg_n + KMC_ST_K * 64 - 1) / (KMC_ST_K * 64);
-        const u32 first = (wave0 + nwaves - (u32)((sg * 977u) % nwaves)) % nwaves;
-#pragma clang loop unroll(disable)
-        for (u64 st = first; st < seg_supers; st += nwaves) {
-            const u64 super_base = st * (KMC_ST_K * 64);  // first state of this super-tile within the segment
-            // ---- phase A: guards of every tile; en[t][h] live in registers -------------------------
-            u32 en[KMC_ST_K][NH];
-#pragma unroll
-            for (int t = 0; t < KMC_ST_K; ++t)
-#pragma unroll
-                for (int h = 0; h < NH; ++h) en[t][h] = 0;
-            const u32 errv = __hip_atomic_load(&a.ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma clang loop unroll(disable)
-            for (int t = 0; t < KMC_ST_K; ++t) {
-                const u64 j = super_base + (u64)t * 64 + lane;
-                const bool valid = j < seg_n;
-                u64 s[W];
-#pragma unroll
-                for (int k = 0; k < W; ++k) s[k] = valid ? a.fin[(u64)k * a.fin_stride + seg_base + j] : 0ull;
-                typename M::Pre pre = M::extract(s);
-                if (a.inv_mask && a.mode != KMC_MODE_ENUM && !(a.flags & KMC_FLAG_X_NOINV)) {
-                    const u32 bad = valid ? M::violated_pre(pre, a.inv_mask) : 0u;
-                    if (__ballot(bad != 0)) {
-                        if (bad) KmcSink<M>::report_violation(a, bad, kmc_fingerprint<W>(s, a.seed));
-                    }
-                }
-                u32 e32[NH];
-#pragma unroll
-                for (int h = 0; h < NH; ++h) e32[h] = 0;
-                const u32 valid01 = valid ? 1u : 0u;
-                kmc_static_for<0, M::NINST>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    u64 tt[W];
-                    int kd;
-                    u32 ex;
-                    const u32 g01 = M::template inst<i>(pre, s, tt, kd, ex) & valid01;
-                    e32[i >> 5] |= g01 << (i & 31);
-                    kmc_launder(e32[i >> 5]);
-                });
-                u32 nsucc = 0;
-#pragma unroll
-                for (int h = 0; h < NH; ++h) nsucc += __popc(e32[h]);
-                const u64 dm = __ballot(valid && nsucc == 0);
-                if (dm) {
-                    deadlocks += __popcll(dm);
-                    if (valid && nsucc == 0) atomicMax(&a.ctl->deadlock_fp_inv, ~kmc_fingerprint<W>(s, a.seed));
-                }
-                // park this tile's words in their registers (t is a loop variable: select, do not index)
-#pragma unroll
-                for (int tt2 = 0; tt2 < KMC_ST_K; ++tt2)
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) en[tt2][h] = (t == tt2) ? e32[h] : en[tt2][h];
-            }
-            table_full = __builtin_amdgcn_readfirstlane(errv) & KMC_ERR_TABLE_FULL;
-
-            // ---- phase B: per instance, the enabled states of all tiles on full lanes --------------
-            u32 cur[KMC_ST_K];
-#pragma clang loop unroll(disable)
-            for (int i = 0; i < M::NINST; ++i) {
-                if ((i & 31) == 0) {
-#pragma unroll
-                    for (int t = 0; t < KMC_ST_K; ++t) {
-                        cur[t] = en[t][0];
-#pragma unroll
-                        for (int h = 1; h < NH; ++h)
-                            if ((i >> 5) == h) cur[t] = en[t][h];
-                    }
-                }
-                u32 total = 0;
-#pragma unroll
-                for (int t = 0; t < KMC_ST_K; ++t) {
-                    const bool e = cur[t] & 1u;
-                    cur[t] >>= 1;
-                    const u64 m = __ballot(e);
-                    if (e) ids[total + kmc_rank_in(m)] = (kmc_stid_t)((t << 6) | lane);
-                    total += __popcll(m);
-                }
-                if (total == 0) continue;
-#pragma clang loop unroll(disable)
-                for (u32 c0 = 0; c0 < total; c0 += 64) {
-                    const bool active = c0 + lane < total;
-                    const u32 id = active ? ids[c0 + lane] : 0u;
-                    const u64 j = super_base + id;  // id = tile * 64 + source lane
-                    u64 s[W];
-#pragma unroll
-                    for (int k = 0; k < W; ++k) s[k] = active ? a.fin[(u64)k * a.fin_stride + seg_base + j] : 0ull;
-                    const u64 parent =
-                        (a.flags & (KMC_FLAG_TRACE | KMC_FLAG_ENUM_MATCH)) ? kmc_fingerprint<W>(s, a.seed) : 0ull;
-                    typename M::Pre pre = M::effect_view(s);
-                    M::launder(pre);
-#pragma unroll
-                    for (int k = 0; k < W; ++k) kmc_launder(s[k]);
-                    int kind = 0;
-                    u32 extra = 0;
-                    u64 t[W];
-                    kmc_dispatch<0, M::NINST>(i, [&](auto I) {
-                        (void)M::template inst<decltype(I)::value>(pre, s, t, kind, extra);
-                    });
-                    const u64 m = __ballot(active);
-                    const u32 n = __popcll(m);
-                    u32 weight = n;
-                    if constexpr (M::HAS_EXTRA) {
-                        u32 x = active ? extra : 0u;
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-                        weight += __builtin_amdgcn_readfirstlane(x);
-                    }
-                    gen_lane += (lane == (u32)kind) ? weight : 0u;
-                    bool keep = active;
-                    u64 mk = m;
-                    if constexpr (M::HAS_CONSTRAINT) {
-                        if (a.mode == KMC_MODE_LOCAL || a.mode == KMC_MODE_SHARDED) {
-                            const bool outside = active && !M::in_model(t);
-                            if (__ballot(outside)) {
-                                if (outside && a.inv_mask) {
-                                    const u32 bad = M::violated(t, a.inv_mask);
-                                    if (bad) KmcSink<M>::report_outside_violation(a, bad, kmc_fingerprint<W>(t, a.seed));
-                                }
-                                keep = active && !outside;
-                                mk = __ballot(keep);
-                            }
-                        }
-                    }
-                    if (keep) {
-                        const u32 pos = (head + count + kmc_rank_in(mk)) & (KMC_RING - 1);
-#pragma unroll
-                        for (int k = 0; k < W; ++k) q[k * KMC_RING + pos] = t[k];
-                        if (has_meta)
-                            q[W * KMC_RING + pos] =
-                                (a.mode == KMC_MODE_ENUM && !(a.flags & KMC_FLAG_ENUM_MATCH)) ? (u64)kind : parent;
-                    }
-                    count += __popcll(mk);
-                    if (count >= KMC_FLUSH_N) flush(KMC_FLUSH_N);
-                }
-            }
-        }
-    }
-    while (count) flush(count < KMC_FLUSH_N ? count : KMC_FLUSH_N);
-    out.finish(a);
-    if (lane < (u32)M::NKINDS && gen_lane) atomicAdd(&a.ctl->generated[lane], (u64)gen_lane);
-    if (lane == 0 && deadlocks) atomicAdd(&a.ctl->deadlock_count, (u64)deadlocks);
-}
-#endif  // KMC_SUPERTILE
-
 // dynamic LDS bytes k_expand needs for a state of W words
 KMC_HD inline unsigned kmc_expand_lds_bytes(int W, bool has_meta) {
     return (unsigned)(KMC_WAVES * ((W + (has_meta ? 1 : 0)) * KMC_RING + W * KMC_QCAP) * 8);
@@ -1648,14 +1517,9 @@ template <class M> KMC_DEV void kmc_find_body(const KmcArgs& a) {
 #ifndef KMC_MIN_WAVES
 #define KMC_MIN_WAVES 6   // __launch_bounds__ second argument for k_expand: minimum waves per SIMD (LDS admits 6 blocks/CU)
 #endif
-#if KMC_SUPERTILE
-#define KMC_EXPAND_BODY kmc_expand_body_st
-#else
-#define KMC_EXPAND_BODY kmc_expand_body
-#endif
 #define KMC_INSTANTIATE(NAME, ...)                                                                       \
     extern "C" __global__ __launch_bounds__(KMC_BLOCK, KMC_MIN_WAVES) void kmc_expand_##NAME(KmcArgs a) { \
-        KMC_EXPAND_BODY<__VA_ARGS__>(a);                                                                 \
+        kmc_expand_body<__VA_ARGS__>(a);                                                                 \
     }                                                                                                    \
     extern "C" __global__ __launch_bounds__(KMC_BLOCK) void kmc_insert_##NAME(KmcArgs a) {               \
         kmc_insert_body<__VA_ARGS__>(a);                                                                 \

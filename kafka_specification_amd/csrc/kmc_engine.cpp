@@ -7,6 +7,7 @@
 // device or compiler every entry point fails with KMC_E_DEVICE / KMC_E_COMPILE.
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is bound with dlopen when a communicator is created
 
 #include <dlfcn.h>
 #include <sys/stat.h>
@@ -23,6 +24,10 @@
 #include "../../include/kmc.h"
 #include "kmc_device.h"   // host-visible parts: KmcArgs, KmcLevelCtl, layout, fingerprint
 #include "kmc_sources.inc"  // generated: KMC_SRC_LAYOUT, KMC_SRC_DEVICE (the same two headers as text)
+
+// Levels kmc_run queues back to back before it waits (no progress callback): see run_levels.
+#define KMC_CHAIN 8
+#define KMC_CTL_SLOTS (3 + KMC_CHAIN)   // two alternating levels + one auxiliary + one per chained level
 
 namespace {
 
@@ -190,7 +195,8 @@ long expand_vgpr_spills(const std::vector<char>& code, const std::string& kernel
 }
 
 // Compile (or fetch from the cache) the code object specialised for cfg.
-int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<char>* code, std::string* kname) {
+int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<char>* code, std::string* kname,
+                    const char* extra_options = nullptr) {
     KmcLayout lay;
     std::string name, inst;
     if (!validate(cfg, &lay, &name, &inst))
@@ -201,7 +207,10 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
     // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_MIN_WAVES=5 -DKMC_PROFILE=1"
     std::vector<std::string> defines;
     std::string defines_key;
-    if (const char* d = getenv("KMC_JIT_DEFINES")) {
+    std::string all_defines = getenv("KMC_JIT_DEFINES") ? getenv("KMC_JIT_DEFINES") : "";
+    if (extra_options) all_defines += std::string(" ") + extra_options;
+    if (!all_defines.empty()) {
+        const char* d = all_defines.c_str();
         std::string tok;
         for (const char* q = d;; ++q) {
             if (*q == ' ' || *q == 0) {
@@ -262,7 +271,16 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
         hiprtcGetCode(prog, code->data());
         hiprtcDestroyProgram(&prog);
         const long spills = expand_vgpr_spills(*code, "kmc_expand_" + name);
-        if (waves_forced || spills < 0 || spills <= KMC_MAX_VGPR_SPILLS || waves == 1) break;
+        if (waves_forced) break;  // an explicit -DKMC_MIN_WAVES (tuning, bug hunts) is taken as given and never cached as default
+        // The guard must not pass by accident: an unreadable spill count, or a kernel that still spills at
+        // one wave per SIMD, is a failed specialisation — not a kernel to run and cache.
+        if (spills < 0)
+            return fail(KMC_E_COMPILE, "cannot read .vgpr_spill_count of kmc_expand_%s from the code object's metadata: "
+                                       "the register-budget rule cannot be checked", name.c_str());
+        if (spills <= KMC_MAX_VGPR_SPILLS) break;
+        if (waves == 1)
+            return fail(KMC_E_COMPILE, "kmc_expand_%s spills %ld vector registers even at one wave per SIMD: constants too "
+                                       "wide for this kernel shape", name.c_str(), spills);
         // (these kernels take up to minutes to compile: jump by the size of the overflow, do not crawl)
         const int next = spills > 64 ? 2 : spills > 24 ? 3 : 4;
         waves = next < waves ? next : waves - 1;
@@ -303,8 +321,12 @@ struct kmc_handle {
     std::string kname;
     hipModule_t mod = nullptr;
     hipFunction_t f_expand = nullptr, f_insert = nullptr, f_init = nullptr, f_find = nullptr;
+    hipModule_t mod_verify = nullptr;       // KMC_VERIFY=1: the same kernels from a second, differently compiled code object
+    hipFunction_t f_expand_verify = nullptr;
+    uint64_t verify_levels = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_chain[2 * KMC_CHAIN] = {nullptr};  // chained launches: one pair per level of a batch
     int rec_words = 0;  // exchange / insert record size: W, +1 when predecessor fingerprints are kept
     int n_cus = 256;
     int blocks_per_cu = 4;  // k_expand residency, from the occupancy query at open
@@ -327,6 +349,7 @@ struct kmc_handle {
     int cur = 0;                 // frontier[cur] holds the last completed level
     uint64_t n_cur = 0;          // its size on this shard
     uint64_t seg_n[KMC_SEGS] = {0};  // ... per segment
+    uint64_t prev_seg_n[KMC_SEGS] = {0};  // stepping: segments of the level kmc_step_finish just retired (in frontier[cur ^ 1])
     uint64_t seg_cap = 0;        // slots per segment
     uint64_t level = 0;          // number of completed levels
     bool stepping = false, step_expanded = false, restored = false;
@@ -339,6 +362,15 @@ struct kmc_handle {
     double t_start = 0;
     double dry_seconds = 0;
     uint64_t prof[8] = {0}, prof_dry[8] = {0};
+    // per-level exchange under the ABI (n_shards > 1): RCCL communicator, receive area, count/statistics rows
+    ncclComm_t comm = nullptr;
+    u64* recv = nullptr;             // device: everything this shard receives in one level, contiguous
+    uint64_t recv_cap = 0;           // records
+    int64_t* xrow_dev = nullptr;     // device: this rank's row, then the gathered rows of all ranks
+    int64_t* xrow_host = nullptr;    // pinned: the same
+    uint64_t last_send_counts[KMC_MAX_SHARDS * KMC_SEGS] = {0};  // of the last kmc_step_expand
+    std::vector<uint64_t> xcounts;   // [source][destination][sub-buffer] of the level being exchanged
+    bool xcounts_valid = false;
 };
 
 namespace {
@@ -346,7 +378,7 @@ namespace {
 int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid) {
     KmcArgs args = a;
     unsigned lds = 0;
-    if (f == h->f_expand) {  // k_expand carves its rings out of dynamic LDS
+    if (f == h->f_expand || f == h->f_expand_verify) {  // k_expand carves its rings out of dynamic LDS
         const bool meta = (args.flags & KMC_FLAG_TRACE) || args.mode == KMC_MODE_ENUM;
         if (meta) args.flags |= KMC_FLAG_META;
         lds = kmc_expand_lds_bytes(h->W, meta);
@@ -391,7 +423,10 @@ unsigned expand_grid(kmc_handle* h, uint64_t n) {
 }
 
 int read_ctl(kmc_handle* h, int slot) {
-    HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl + slot, sizeof(KmcLevelCtl), hipMemcpyDeviceToHost, h->stream));
+    // a single-GPU level reports through the head of the block; the per-destination send counters behind it are
+    // only written (and read back) in SHARDED mode
+    const size_t bytes = h->cfg.n_shards > 1 || h->stepping ? sizeof(KmcLevelCtl) : KMC_CTL_LOCAL_BYTES;
+    HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl + slot, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return KMC_OK;
 }
@@ -464,7 +499,7 @@ int reset_run(kmc_handle* h) {
     HIP_TRY(hipMemsetAsync(h->table, 0, h->table_cap * 8, h->stream));
     if (h->pred) HIP_TRY(hipMemsetAsync(h->pred, 0, h->table_cap * 8, h->stream));
     if (h->sent) HIP_TRY(hipMemsetAsync(h->sent, 0, h->sent_cap * 8, h->stream));
-    HIP_TRY(hipMemsetAsync(h->ctl, 0, 3 * sizeof(KmcLevelCtl), h->stream));
+    HIP_TRY(hipMemsetAsync(h->ctl, 0, KMC_CTL_SLOTS * sizeof(KmcLevelCtl), h->stream));
     h->levels.clear();
     h->witness.clear();
     h->have_witness = false;
@@ -626,6 +661,8 @@ int kmc_precompile(const kmc_config* cfg, const char* arch) {
     return get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname);
 }
 
+static void comm_release(kmc_handle* h);
+
 void kmc_close(kmc_handle* h) {
     if (!h) return;
     if (h->cfg.device < 0 || !h->stream) {  // host-only handle, or open failed before any device work
@@ -645,11 +682,18 @@ void kmc_close(kmc_handle* h) {
     if (h->scratch) hipFree(h->scratch);
     if (h->enum_out) hipFree(h->enum_out);
     if (h->send && h->send_owned) hipFree(h->send);
+    comm_release(h);
+    if (h->recv) hipFree(h->recv);
+    if (h->xrow_dev) hipFree(h->xrow_dev);
+    if (h->xrow_host) hipHostFree(h->xrow_host);
     if (h->ctl_host) hipHostFree(h->ctl_host);
     if (h->scratch_host) hipHostFree(h->scratch_host);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->ev_chain)
+        if (e) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
+    if (h->mod_verify) hipModuleUnload(h->mod_verify);
     if (h->mod) hipModuleUnload(h->mod);
     delete h;
 }
@@ -687,6 +731,18 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     HIP_TRY(hipModuleGetFunction(&h->f_insert, h->mod, ("kmc_insert_" + h->kname).c_str()));
     HIP_TRY(hipModuleGetFunction(&h->f_init, h->mod, ("kmc_init_" + h->kname).c_str()));
     HIP_TRY(hipModuleGetFunction(&h->f_find, h->mod, ("kmc_find_" + h->kname).c_str()));
+    if (getenv("KMC_VERIFY") && atoi(getenv("KMC_VERIFY"))) {
+        // Differential self-check for constants no oracle can reach (round 1 met a k_expand build that LOST successors
+        // under heavy register spilling): a second code object of the same source, compiled at -O1 with a quarter of
+        // the occupancy target, re-generates every level's successors (DRY mode: no table, no frontier) and the
+        // per-action counts, deadlock counts and violation counts of the two builds must agree.
+        std::vector<char> vcode;
+        std::string vname;
+        rc = get_code_object(h->cfg, arch, &vcode, &vname, "-O1 -DKMC_MIN_WAVES=2");
+        if (rc) return rc;
+        HIP_TRY(hipModuleLoadData(&h->mod_verify, vcode.data()));
+        HIP_TRY(hipModuleGetFunction(&h->f_expand_verify, h->mod_verify, ("kmc_expand_" + vname).c_str()));
+    }
     int occ = 0;
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->f_expand, KMC_BLOCK,
                                                            kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0)) == hipSuccess && occ > 0)
@@ -707,13 +763,14 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     const double budget = 0.85 * (double)free_b;
     const uint64_t slot_bytes = cfg->keep_trace ? 16 : 8;
     // auto-sizing: half of the budget for the table; a shard also keeps a sender-side filter of twice the table
-    const double table_share = h->cfg.n_shards > 1 ? 0.18 : 0.5;
+    // (0.15 + 0.30), two frontiers (2 x 0.09), a send area and a receive area (0.12 each)
+    const double table_share = h->cfg.n_shards > 1 ? 0.15 : 0.5;
     uint64_t tcap = cfg->table_capacity ? pow2_ceil(cfg->table_capacity)
                                         : pow2_floor((uint64_t)(budget * table_share) / slot_bytes);
     if (tcap < 1024) tcap = 1024;
     uint64_t fcap = cfg->frontier_capacity;
     if (!fcap) {
-        const double share = h->cfg.n_shards > 1 ? 0.12 : 0.20;
+        const double share = h->cfg.n_shards > 1 ? 0.09 : 0.20;
         fcap = (uint64_t)(budget * share) / (8ull * h->W);
         if (fcap > tcap) fcap = tcap;
     }
@@ -727,8 +784,8 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     for (int i = 0; i < 2; ++i)
         if (hipMalloc(&h->frontier[i], fcap * 8ull * h->W) != hipSuccess)
             return fail(KMC_E_NOMEM, "cannot allocate frontier of %llu states", (unsigned long long)fcap);
-    HIP_TRY(hipMalloc(&h->ctl, 3 * sizeof(KmcLevelCtl)));
-    HIP_TRY(hipHostMalloc(&h->ctl_host, sizeof(KmcLevelCtl)));
+    HIP_TRY(hipMalloc(&h->ctl, KMC_CTL_SLOTS * sizeof(KmcLevelCtl)));
+    HIP_TRY(hipHostMalloc(&h->ctl_host, KMC_CHAIN * sizeof(KmcLevelCtl)));
     HIP_TRY(hipMalloc(&h->scratch, 64 * 8));
     HIP_TRY(hipHostMalloc(&h->scratch_host, 64 * 8));
     HIP_TRY(hipMalloc(&h->enum_out, h->enum_cap * (h->W + 2) * 8ull));
@@ -740,7 +797,7 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     }
     if (h->cfg.n_shards > 1) {
         uint64_t scap = cfg->send_capacity;
-        if (!scap) scap = (uint64_t)(budget * 0.16) / (8ull * h->rec_words * h->cfg.n_shards * KMC_SEGS);
+        if (!scap) scap = (uint64_t)(budget * 0.12) / (8ull * h->rec_words * h->cfg.n_shards * KMC_SEGS);
         if (scap < 64) scap = 64;
         h->send_cap = scap;  // records per (destination, sub-buffer)
         if (hipMalloc(&h->send, scap * h->rec_words * 8ull * h->cfg.n_shards * KMC_SEGS) != hipSuccess)
@@ -971,6 +1028,78 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             r.queue_left = h->n_cur;
             break;
         }
+        static const int shadow = getenv("KMC_SHADOW") ? atoi(getenv("KMC_SHADOW")) : 0;
+        static const int dry_mode = getenv("KMC_DRYRUN") ? atoi(getenv("KMC_DRYRUN")) : 0;
+        static const int no_chain = getenv("KMC_NO_CHAIN") ? atoi(getenv("KMC_NO_CHAIN")) : 0;
+        if (!cb && !shadow && !dry_mode && !no_chain && !h->f_expand_verify) {
+            // ---- chained launches -------------------------------------------------------------------------
+            // Nobody watches the levels go by, so up to KMC_CHAIN of them are queued back to back and the host
+            // waits ONCE: a level launched behind another one takes its segment sizes from that level's control
+            // block on the device and does nothing if that level (or one before it) ended the search.  Per level
+            // this leaves a launch and two event records on the host instead of memset + launch + copy + wait
+            // (46 levels, 7 of them under 1024 states: 2.4 ms of a 38 ms check in round 1).
+            uint64_t B = max_levels - h->level;
+            if (B > KMC_CHAIN) B = KMC_CHAIN;
+            HIP_TRY(hipMemsetAsync(h->ctl + 3, 0, B * sizeof(KmcLevelCtl), h->stream));
+            for (uint64_t i = 0; i < B; ++i) {
+                if (!h->ev_chain[2 * i]) {
+                    HIP_TRY(hipEventCreate(&h->ev_chain[2 * i]));
+                    HIP_TRY(hipEventCreate(&h->ev_chain[2 * i + 1]));
+                }
+                KmcArgs a = base_args(h, 3 + (int)i);
+                const int ci = h->cur ^ (int)(i & 1);
+                a.fin = h->frontier[ci];
+                a.fout = h->frontier[ci ^ 1];
+                a.mode = KMC_MODE_LOCAL;
+                a.prev = i ? h->ctl + 3 + (i - 1) : nullptr;   // the first level of a batch always runs, on host-known sizes
+                a.stop_mask = h->cfg.continue_on_violation ? 0u : h->cfg.invariant_mask;
+                a.stop_deadlock = (h->cfg.check_deadlock && r.verdict == KMC_V_OK) ? 1u : 0u;
+                HIP_TRY(hipEventRecord(h->ev_chain[2 * i], h->stream));
+                // sizes behind the first level are unknown here: a resident grid, idle blocks leave at once
+                if ((rc = launch(h, h->f_expand, a, expand_grid(h, i ? h->fcap : h->n_cur)))) return rc;
+                HIP_TRY(hipEventRecord(h->ev_chain[2 * i + 1], h->stream));
+            }
+            HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl + 3, B * sizeof(KmcLevelCtl), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            bool done = false;
+            for (uint64_t i = 0; i < B && !done; ++i) {
+                const KmcLevelCtl c = h->ctl_host[i];
+                if (c.halt) break;   // the device ended the chain here; the host decides below whether the search goes on
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, h->ev_chain[2 * i], h->ev_chain[2 * i + 1]));
+                r.seconds_expand += 1e-3 * ms;
+                r.expand_launches++;
+                for (int k = 0; k < 8; ++k) h->prof[k] += c.prof[k];
+                uint64_t new_seg[KMC_SEGS];
+                const uint64_t produced = produced_segments(h, c, new_seg);
+                stop = absorb(h, c, h->frontier[h->cur], h->seg_n, &rc);
+                if (rc) return rc;
+                if (stop) {
+                    r.queue_left = h->n_cur;
+                    done = true;
+                    break;
+                }
+                if (produced == 0) {
+                    h->n_cur = 0;
+                    done = true;
+                    break;
+                }
+                h->cur ^= 1;
+                h->n_cur = produced;
+                for (int sg = 0; sg < KMC_SEGS; ++sg) h->seg_n[sg] = new_seg[sg];
+                h->level++;
+                r.depth = h->level;
+                r.distinct += produced;
+                h->levels.push_back(produced);
+                if ((double)r.distinct > 0.92 * (double)h->table_cap && r.verdict == KMC_V_OK) {
+                    r.verdict = KMC_V_TABLE_FULL;
+                    r.queue_left = h->n_cur;
+                    stop = done = true;
+                }
+            }
+            if (done) break;
+            continue;
+        }
         const int slot = (int)(h->level & 1);
         const int nxt = h->cur ^ 1;
         if ((rc = zero_ctl(h, slot))) return rc;
@@ -978,7 +1107,6 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
         a.fin = h->frontier[h->cur];
         a.fout = h->frontier[nxt];
         a.mode = KMC_MODE_LOCAL;
-        static const int shadow = getenv("KMC_SHADOW") ? atoi(getenv("KMC_SHADOW")) : 0;
         if (shadow) {  // tuning aid: the identical level first runs on a copy of the table, with KMC_XFLAGS applied
             if (!h->table2) HIP_TRY(hipMalloc(&h->table2, h->table_cap * 8));
             HIP_TRY(hipMemcpyAsync(h->table2, h->table, h->table_cap * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -1005,7 +1133,27 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
         r.expand_launches++;
         const KmcLevelCtl c = *h->ctl_host;
         for (int k = 0; k < 8; ++k) h->prof[k] += c.prof[k];
-        static const int dry = getenv("KMC_DRYRUN") ? atoi(getenv("KMC_DRYRUN")) : 0;
+        if (h->f_expand_verify) {  // KMC_VERIFY: the second build regenerates this level; the counts must agree
+            KmcArgs v = a;
+            v.mode = KMC_MODE_DRY;
+            v.ctl = h->ctl + 2;
+            if ((rc = zero_ctl(h, 2))) return rc;
+            if ((rc = launch(h, h->f_expand_verify, v, expand_grid(h, h->n_cur)))) return rc;
+            KmcLevelCtl vc;
+            HIP_TRY(hipMemcpyAsync(&vc, h->ctl + 2, KMC_CTL_LOCAL_BYTES, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            bool same = vc.deadlock_count == c.deadlock_count;
+            for (int k = 0; k < KMC_MAX_KINDS; ++k) same = same && vc.generated[k] == c.generated[k];
+            for (int k = 0; k < 4; ++k) same = same && vc.viol_count[k] == c.viol_count[k];
+            if (!same) {
+                r.verdict = KMC_V_ERROR;
+                return fail(KMC_E_DEVICE, "KMC_VERIFY: the two builds of kmc_expand_%s disagree at level %llu (generated / "
+                                          "deadlock / violation counts differ): one of them is miscompiled", h->kname.c_str(),
+                            (unsigned long long)h->level);
+            }
+            h->verify_levels++;
+        }
+        const int dry = dry_mode;
         if (dry) {  // tuning aid: time the same level again without table writes / frontier traffic
             KmcArgs d = a;  // 1: no table access at all, 2: + read-only probes, 3: + invariants on every successor
             d.mode = KMC_MODE_DRY;
@@ -1289,6 +1437,12 @@ int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     if (!h || !path) return fail(KMC_E_ARG, "null argument");
     if (!h->table || h->cfg.n_shards != 1) return fail(KMC_E_STATE, "checkpoints are for single-GPU device handles");
     if (h->levels.empty()) return fail(KMC_E_STATE, "nothing to checkpoint: run first");
+    // Only a level boundary is a consistent state: after a stop inside a level (invariant, deadlock, table / frontier
+    // full) the table already holds the fingerprints of the rolled-back or partial level while the frontier is still
+    // its parent — a search resumed from that would find every successor "seen" and end with states missing.
+    if (h->res.verdict != KMC_V_LEVEL_LIMIT)
+        return fail(KMC_E_STATE, "a checkpoint can only be taken at a level boundary: after a run that stopped at max_levels "
+                                 "(verdict level_limit); this run ended with verdict %d", h->res.verdict);
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     FILE* f = fopen(path, "wb");
@@ -1333,14 +1487,39 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
                 hd.has_pred != (uint64_t)(h->pred != nullptr)))
         rc = fail(KMC_E_ARG, "checkpoint capacities differ: open the handle with table_capacity=%llu frontier_capacity=%llu keep_trace=%d",
                   (unsigned long long)hd.table_cap, (unsigned long long)hd.fcap, (int)hd.has_pred);
+    // the file is not trusted: every size is checked against the handle before it sizes a buffer or a device copy
+    if (!rc && (hd.n_levels == 0 || hd.n_levels > 4096 || hd.level != hd.n_levels || hd.n_cur > hd.fcap))
+        rc = fail(KMC_E_ARG, "checkpoint header is inconsistent (levels %llu, level %llu, frontier %llu of %llu)",
+                  (unsigned long long)hd.n_levels, (unsigned long long)hd.level, (unsigned long long)hd.n_cur,
+                  (unsigned long long)hd.fcap);
     if (!rc) rc = reset_run(h);
     if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(KMC_E_DEVICE, "stream sync failed");
     if (!rc) {
-        h->levels.resize(hd.n_levels);
-        h->init_words.resize(h->W);
-        bool ok = rd(f, &h->res, sizeof h->res) && rd(f, h->levels.data(), hd.n_levels * 8) && rd(f, h->seg_n, sizeof h->seg_n) &&
-                  rd(f, h->init_words.data(), h->W * 8);
+        kmc_result saved{};
+        std::vector<uint64_t> lv(hd.n_levels);
+        uint64_t segs[KMC_SEGS];
+        std::vector<uint64_t> init(h->W);
+        bool ok = rd(f, &saved, sizeof saved) && rd(f, lv.data(), hd.n_levels * 8) && rd(f, segs, sizeof segs) &&
+                  rd(f, init.data(), h->W * 8);
         if (!ok) rc = fail(KMC_E_STATE, "checkpoint: short read");
+        uint64_t seg_sum = 0, lv_sum = 0;
+        for (int sg = 0; sg < KMC_SEGS && !rc; ++sg) {
+            if (segs[sg] > h->seg_cap) rc = fail(KMC_E_ARG, "checkpoint: segment %d holds %llu states, capacity %llu", sg,
+                                                 (unsigned long long)segs[sg], (unsigned long long)h->seg_cap);
+            seg_sum += segs[sg];
+        }
+        for (uint64_t x : lv) lv_sum += x;
+        if (!rc && (seg_sum != hd.n_cur || lv.back() != hd.n_cur || lv_sum != saved.distinct || saved.distinct > h->table_cap ||
+                    saved.verdict != KMC_V_LEVEL_LIMIT || saved.state_words != (uint64_t)h->W ||
+                    saved.table_capacity != h->table_cap || saved.frontier_capacity != h->fcap))
+            rc = fail(KMC_E_ARG, "checkpoint body is inconsistent with its header / this handle");
+        if (!rc && kmc_fingerprint_of(h, init.data()) == 0) rc = fail(KMC_E_ARG, "checkpoint: bad initial state");
+        if (!rc) {
+            h->res = saved;
+            h->levels = lv;
+            memcpy(h->seg_n, segs, sizeof segs);
+            h->init_words = init;
+        }
     }
     if (!rc) rc = file_to_dev(f, h->table, h->table_cap);
     if (!rc && h->pred) rc = file_to_dev(f, h->pred, h->table_cap);
@@ -1370,7 +1549,9 @@ int kmc_step_begin(kmc_handle* h) {
 
 int kmc_step_expand(kmc_handle* h, uint64_t* send_counts /* [KMC_MAX_SHARDS][KMC_SEND_SUBS] */) {
     if (!h || !h->stepping) return fail(KMC_E_STATE, "kmc_step_begin first");
-    if (!h->send) return fail(KMC_E_STATE, "no send area: open with n_shards > 1 or call kmc_step_set_send_buffer");
+    // (one shard buckets nothing: every successor is its own, so it may run without a send area)
+    if (!h->send && h->cfg.n_shards > 1)
+        return fail(KMC_E_STATE, "no send area: open with n_shards > 1 or call kmc_step_set_send_buffer");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const int slot = (int)(h->level & 1);
     int rc = zero_ctl(h, slot);
@@ -1394,8 +1575,10 @@ int kmc_step_expand(kmc_handle* h, uint64_t* send_counts /* [KMC_MAX_SHARDS][KMC
     for (int d = 0; d < KMC_MAX_SHARDS; ++d)
         for (int sb = 0; sb < KMC_SEGS; ++sb) {
             uint64_t c = h->ctl_host->send_count[d][sb].v;
-            send_counts[d * KMC_SEGS + sb] = c < h->send_cap ? c : h->send_cap;
+            h->last_send_counts[d * KMC_SEGS + sb] = c < h->send_cap ? c : h->send_cap;
+            if (send_counts) send_counts[d * KMC_SEGS + sb] = h->last_send_counts[d * KMC_SEGS + sb];
         }
+    h->xcounts_valid = false;
     h->step_expanded = true;
     return KMC_OK;
 }
@@ -1452,7 +1635,7 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
     r.deadlock_states += c.deadlock_count;
     h->cur = nxt;
     h->n_cur = produced;
-    for (int sg = 0; sg < KMC_SEGS; ++sg) h->seg_n[sg] = new_seg[sg];
+    for (int sg = 0; sg < KMC_SEGS; ++sg) { h->prev_seg_n[sg] = h->seg_n[sg]; h->seg_n[sg] = new_seg[sg]; }
     h->level++;
     if (produced) r.depth = h->level;
     r.distinct += produced;
@@ -1480,6 +1663,428 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
         info->error_flags = c.err;
     }
     return rc;
+}
+
+// ---- the per-level exchange under the ABI ---------------------------------------
+// After kmc_step_expand every shard holds, per (destination, sub-buffer), a dense run of records in its
+// send area.  One level's exchange is
+//   (1) an all-gather of one small row per rank: its KMC_SEGS send counts per destination and the caller's
+//       statistics vector (the statistics of the PREVIOUS expansion ride along: one collective decides
+//       termination and verdicts identically on every rank) — one stream synchronisation, because the host
+//       must know the counts to post the receives;
+//   (2) grouped ncclSend / ncclRecv of every non-empty (peer, sub-buffer) run, straight from the send area
+//       into one contiguous receive area, on the engine's stream; and
+//   (3) ONE k_insert over what arrived, queued behind the receives on the same stream — no host wait.
+// The plan (who sends how many words from which offset, where each run lands) is a pure function of the
+// count matrix, shared by the RCCL transport and by the in-process transport that moves the runs with
+// device-to-device copies between P logical shards on one GPU (RCCL refuses two ranks on one device).
+namespace {
+
+struct KmcRccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+// librccl is bound at run time: libkmc.so must load on a box without RCCL (single-GPU use, the CPU-side
+// ABI tests), and inside a PyTorch process the name resolves to the copy the wheel has already loaded
+// (same SONAME), so both sides of the process talk to one RCCL.
+KmcRccl* rccl() {
+    static KmcRccl r;
+    static bool tried = false;
+    if (tried) return r.lib ? &r : nullptr;
+    tried = true;
+    const char* names[] = {getenv("KMC_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    }
+    if (!r.lib) return nullptr;
+#define KMC_SYM(field, name)                                                     \
+    r.field = (decltype(r.field))dlsym(r.lib, name);                             \
+    if (!r.field) { r.lib = nullptr; return nullptr; }
+    KMC_SYM(GetUniqueId, "ncclGetUniqueId")
+    KMC_SYM(CommInitRank, "ncclCommInitRank")
+    KMC_SYM(CommDestroy, "ncclCommDestroy")
+    KMC_SYM(AllGather, "ncclAllGather")
+    KMC_SYM(Send, "ncclSend")
+    KMC_SYM(Recv, "ncclRecv")
+    KMC_SYM(GroupStart, "ncclGroupStart")
+    KMC_SYM(GroupEnd, "ncclGroupEnd")
+    KMC_SYM(GetErrorString, "ncclGetErrorString")
+#undef KMC_SYM
+    return &r;
+}
+
+#define NCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        ncclResult_t e_ = (expr);                                                                               \
+        if (e_ != ncclSuccess) return fail(KMC_E_DEVICE, "%s failed: %s", #expr, rccl()->GetErrorString(e_));  \
+    } while (0)
+
+// One message of a level's plan: `words` 64-bit words at `offset_words` of the send area (a send) or of the
+// receive area (a receive), exchanged with `peer`.
+struct KmcXfer {
+    uint64_t peer, offset_words, words;
+};
+// A single message stays below 1 GiB: this RCCL build corrupted all-to-all messages above 2 GiB
+// (tools/a2a_probe.py), so long runs are cut; both sides cut identically.
+constexpr uint64_t KMC_XFER_MAX_WORDS = 1ull << 27;
+
+// counts[(s * P + d) * KMC_SEGS + sub] = records shard s sends to shard d from its sub-buffer `sub`.
+// Sends of `me` in (destination, sub-buffer) order; receives in (source, sub-buffer) order — RCCL matches the
+// messages of a pair in posting order, and both lists enumerate a pair's runs in sub-buffer order.
+void plan_level(const uint64_t* counts, int P, int me, uint64_t send_cap, uint64_t rec_words,
+                std::vector<KmcXfer>* sends, std::vector<KmcXfer>* recvs, uint64_t* recv_records) {
+    sends->clear();
+    recvs->clear();
+    auto cut = [](std::vector<KmcXfer>* out, uint64_t peer, uint64_t off, uint64_t words) {
+        while (words) {
+            const uint64_t n = words < KMC_XFER_MAX_WORDS ? words : KMC_XFER_MAX_WORDS;
+            out->push_back(KmcXfer{peer, off, n});
+            off += n;
+            words -= n;
+        }
+    };
+    for (int d = 0; d < P; ++d) {
+        if (d == me) continue;
+        for (int sb = 0; sb < KMC_SEGS; ++sb) {
+            const uint64_t n = counts[((uint64_t)me * P + d) * KMC_SEGS + sb];
+            if (n) cut(sends, (uint64_t)d, ((uint64_t)d * KMC_SEGS + sb) * send_cap * rec_words, n * rec_words);
+        }
+    }
+    uint64_t at = 0;  // records received so far: the receive area is filled densely, source by source
+    for (int s2 = 0; s2 < P; ++s2) {
+        if (s2 == me) continue;
+        for (int sb = 0; sb < KMC_SEGS; ++sb) {
+            const uint64_t n = counts[((uint64_t)s2 * P + me) * KMC_SEGS + sb];
+            if (n) cut(recvs, (uint64_t)s2, at * rec_words, n * rec_words);
+            at += n;
+        }
+    }
+    *recv_records = at;
+}
+
+int ensure_exchange_buffers(kmc_handle* h) {
+    const int P = h->cfg.n_shards;
+    if (!h->send || !h->send_owned)
+        return fail(KMC_E_STATE, "the exchange under the ABI needs the engine-owned send area (n_shards > 1, no "
+                                 "kmc_step_set_send_buffer)");
+    if (!h->recv) {
+        // worst case: every other shard fills all its sub-buffers for this one
+        h->recv_cap = (uint64_t)(P - 1) * KMC_SEGS * h->send_cap;
+        if (hipMalloc(&h->recv, h->recv_cap * h->rec_words * 8ull) != hipSuccess) {
+            h->recv = nullptr;
+            return fail(KMC_E_NOMEM, "cannot allocate the receive area (%llu records)", (unsigned long long)h->recv_cap);
+        }
+    }
+    const size_t row = (size_t)P * KMC_SEGS + KMC_EXCHANGE_STATS;
+    if (!h->xrow_dev) HIP_TRY(hipMalloc(&h->xrow_dev, (size_t)(P + 1) * row * 8));
+    if (!h->xrow_host) HIP_TRY(hipHostMalloc(&h->xrow_host, (size_t)(P + 1) * row * 8));
+    return KMC_OK;
+}
+
+int insert_received(kmc_handle* h, uint64_t n_records) {
+    if (n_records == 0) return KMC_OK;
+    const int slot = (int)(h->level & 1);
+    KmcArgs a = base_args(h, slot);
+    a.recv = h->recv;
+    a.n_in = n_records;
+    a.fout = h->frontier[h->cur ^ 1];
+    a.mode = KMC_MODE_LOCAL;
+    uint64_t blocks = (n_records + KMC_BLOCK - 1) / KMC_BLOCK;
+    const uint64_t maxb = (uint64_t)h->n_cus * 8;
+    if (blocks > maxb) blocks = maxb;
+    return launch(h, h->f_insert, a, (unsigned)blocks);
+}
+
+}  // namespace
+
+static void comm_release(kmc_handle* h) {
+    if (h->comm && rccl()) rccl()->CommDestroy(h->comm);
+    h->comm = nullptr;
+}
+
+int kmc_comm_unique_id(uint8_t* id) {
+    if (!id) return fail(KMC_E_ARG, "null argument");
+    KmcRccl* r = rccl();
+    if (!r) return fail(KMC_E_DEVICE, "librccl not found (dlopen librccl.so.1): %s", dlerror() ? dlerror() : "?");
+    ncclUniqueId u;
+    NCCL_TRY(r->GetUniqueId(&u));
+    static_assert(sizeof u == KMC_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, &u, sizeof u);
+    return KMC_OK;
+}
+
+int kmc_comm_init(kmc_handle* h, const uint8_t* id) {
+    if (!h || !id) return fail(KMC_E_ARG, "null argument");
+    if (!h->table || h->cfg.n_shards < 1) return fail(KMC_E_STATE, "kmc_comm_init needs a device handle");
+    KmcRccl* r = rccl();
+    if (!r) return fail(KMC_E_DEVICE, "librccl not found (dlopen librccl.so.1)");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    comm_release(h);
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    NCCL_TRY(r->CommInitRank(&h->comm, h->cfg.n_shards, u, h->cfg.shard_id));
+    if (h->cfg.n_shards > 1) return ensure_exchange_buffers(h);
+    return KMC_OK;
+}
+
+// Exercises every RCCL entry point the exchange uses on this handle's communicator and stream: an all-gather of
+// one row per rank and a grouped send/receive ring (rank r sends a pattern to r+1 and receives from r-1; with one
+// rank that is a send to itself).  Verifies what arrived.  A world_size-1 run thereby covers the binding, the
+// argument conventions and the stream ordering although a one-shard search has no remote traffic.
+int kmc_comm_selftest(kmc_handle* h) {
+    if (!h || !h->comm) return fail(KMC_E_STATE, "kmc_comm_init first");
+    KmcRccl* r = rccl();
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int P = h->cfg.n_shards, me = h->cfg.shard_id;
+    const size_t n = 4096;
+    u64* buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, (size_t)(2 + P) * n * 8));
+    std::vector<uint64_t> host((size_t)(2 + P) * n);
+    for (size_t i = 0; i < n; ++i) host[i] = ((uint64_t)(me + 1) << 32) | i;
+    HIP_TRY(hipMemcpyAsync(buf, host.data(), n * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(buf + n, 0, (size_t)(1 + P) * n * 8, h->stream));
+    NCCL_TRY(r->GroupStart());
+    NCCL_TRY(r->Send(buf, n, ncclUint64, (me + 1) % P, h->comm, h->stream));
+    NCCL_TRY(r->Recv(buf + n, n, ncclUint64, (me + P - 1) % P, h->comm, h->stream));
+    NCCL_TRY(r->GroupEnd());
+    NCCL_TRY(r->AllGather(buf, buf + 2 * n, n, ncclUint64, h->comm, h->stream));
+    HIP_TRY(hipMemcpyAsync(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    hipFree(buf);
+    const uint64_t from = (uint64_t)((me + P - 1) % P + 1);
+    for (size_t i = 0; i < n; ++i) {
+        if (host[n + i] != ((from << 32) | i)) return fail(KMC_E_DEVICE, "selftest: send/recv word %zu is wrong", i);
+        for (int q = 0; q < P; ++q)
+            if (host[(2 + q) * n + i] != (((uint64_t)(q + 1) << 32) | i))
+                return fail(KMC_E_DEVICE, "selftest: all-gather word %zu of rank %d is wrong", i, q);
+    }
+    return KMC_OK;
+}
+
+int kmc_exchange_plan(const uint64_t* counts, int32_t n_shards, int32_t me, uint64_t send_cap, uint64_t rec_words,
+                      uint64_t* sends, uint64_t* recvs, uint64_t cap, uint64_t* n_sends, uint64_t* n_recvs,
+                      uint64_t* recv_records) {
+    if (!counts || n_shards < 1 || n_shards > KMC_MAX_SHARDS || me < 0 || me >= n_shards || !n_sends || !n_recvs ||
+        !recv_records)
+        return fail(KMC_E_ARG, "bad argument");
+    std::vector<KmcXfer> sv, rv;
+    plan_level(counts, n_shards, me, send_cap, rec_words, &sv, &rv, recv_records);
+    *n_sends = sv.size();
+    *n_recvs = rv.size();
+    for (uint64_t i = 0; i < sv.size() && i < cap && sends; ++i) {
+        sends[3 * i] = sv[i].peer; sends[3 * i + 1] = sv[i].offset_words; sends[3 * i + 2] = sv[i].words;
+    }
+    for (uint64_t i = 0; i < rv.size() && i < cap && recvs; ++i) {
+        recvs[3 * i] = rv[i].peer; recvs[3 * i + 1] = rv[i].offset_words; recvs[3 * i + 2] = rv[i].words;
+    }
+    return KMC_OK;
+}
+
+int kmc_step_exchange_counts(kmc_handle* h, const int64_t* stats, int32_t n_stats, int64_t* stats_sum,
+                             uint64_t* recv_records) {
+    if (!h || !h->stepping || !h->step_expanded) return fail(KMC_E_STATE, "kmc_step_expand first");
+    if (!h->comm) return fail(KMC_E_STATE, "kmc_comm_init first");
+    if (n_stats < 0 || n_stats > KMC_EXCHANGE_STATS || (n_stats && (!stats || !stats_sum)))
+        return fail(KMC_E_ARG, "bad statistics vector");
+    KmcRccl* r = rccl();
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const int P = h->cfg.n_shards, me = h->cfg.shard_id;
+    const size_t row = (size_t)P * KMC_SEGS + KMC_EXCHANGE_STATS;
+    int rc = P > 1 ? ensure_exchange_buffers(h) : KMC_OK;
+    if (rc) return rc;
+    h->xcounts.assign((size_t)P * P * KMC_SEGS, 0);
+    if (P == 1) {  // nothing to gather
+        for (int k = 0; k < n_stats; ++k) stats_sum[k] = stats[k];
+        if (recv_records) *recv_records = 0;
+        h->xcounts_valid = true;
+        return KMC_OK;
+    }
+    int64_t* mine = h->xrow_host;
+    for (int d = 0; d < P; ++d)
+        for (int sb = 0; sb < KMC_SEGS; ++sb)
+            mine[d * KMC_SEGS + sb] = d == me ? 0 : (int64_t)h->last_send_counts[d * KMC_SEGS + sb];
+    for (int k = 0; k < KMC_EXCHANGE_STATS; ++k) mine[P * KMC_SEGS + k] = k < n_stats ? stats[k] : 0;
+    HIP_TRY(hipMemcpyAsync(h->xrow_dev, mine, row * 8, hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(r->AllGather(h->xrow_dev, h->xrow_dev + row, row, ncclInt64, h->comm, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->xrow_host + row, h->xrow_dev + row, (size_t)P * row * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < n_stats; ++k) stats_sum[k] = 0;
+    for (int s2 = 0; s2 < P; ++s2) {
+        const int64_t* g = h->xrow_host + (size_t)(1 + s2) * row;
+        for (int d = 0; d < P; ++d)
+            for (int sb = 0; sb < KMC_SEGS; ++sb) {
+                const int64_t c = g[d * KMC_SEGS + sb];
+                if (c < 0 || (uint64_t)c > h->send_cap)
+                    return fail(KMC_E_STATE, "exchange: rank %d announces %lld records for a sub-buffer of %llu", s2,
+                                (long long)c, (unsigned long long)h->send_cap);
+                h->xcounts[((size_t)s2 * P + d) * KMC_SEGS + sb] = (uint64_t)c;
+            }
+        for (int k = 0; k < n_stats; ++k) stats_sum[k] += g[P * KMC_SEGS + k];
+    }
+    std::vector<KmcXfer> sv, rv;
+    uint64_t nrec = 0;
+    plan_level(h->xcounts.data(), P, me, h->send_cap, (uint64_t)h->rec_words, &sv, &rv, &nrec);
+    if (recv_records) *recv_records = nrec;
+    h->xcounts_valid = true;
+    return KMC_OK;
+}
+
+int kmc_step_exchange_payload(kmc_handle* h) {
+    if (!h || !h->stepping || !h->step_expanded) return fail(KMC_E_STATE, "kmc_step_expand first");
+    if (!h->xcounts_valid) return fail(KMC_E_STATE, "kmc_step_exchange_counts first");
+    h->xcounts_valid = false;
+    const int P = h->cfg.n_shards, me = h->cfg.shard_id;
+    if (P == 1) return KMC_OK;
+    KmcRccl* r = rccl();
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    std::vector<KmcXfer> sv, rv;
+    uint64_t nrec = 0;
+    plan_level(h->xcounts.data(), P, me, h->send_cap, (uint64_t)h->rec_words, &sv, &rv, &nrec);
+    if (nrec > h->recv_cap) return fail(KMC_E_STATE, "exchange: %llu records exceed the receive area", (unsigned long long)nrec);
+    if (!sv.empty() || !rv.empty()) {
+        NCCL_TRY(r->GroupStart());
+        for (const KmcXfer& x : sv) NCCL_TRY(r->Send(h->send + x.offset_words, x.words, ncclUint64, (int)x.peer, h->comm, h->stream));
+        for (const KmcXfer& x : rv) NCCL_TRY(r->Recv(h->recv + x.offset_words, x.words, ncclUint64, (int)x.peer, h->comm, h->stream));
+        NCCL_TRY(r->GroupEnd());
+    }
+    return insert_received(h, nrec);  // queued behind the receives on the same stream
+}
+
+// The same level step for P logical shards living in ONE process on ONE device (tests, `tlc -gpus P` on a
+// single GPU): counts and statistics are combined on the host, the runs move with device-to-device copies,
+// every shard then inserts what it received.  stats: [n_shards][n_stats].
+int kmc_step_exchange_local(kmc_handle** hs, int32_t n_shards, const int64_t* stats, int32_t n_stats, int64_t* stats_sum) {
+    if (!hs || n_shards < 1 || n_shards > KMC_MAX_SHARDS) return fail(KMC_E_ARG, "bad shard list");
+    const int P = n_shards;
+    for (int s2 = 0; s2 < P; ++s2) {
+        kmc_handle* h = hs[s2];
+        if (!h || !h->stepping || !h->step_expanded) return fail(KMC_E_STATE, "kmc_step_expand first (shard %d)", s2);
+        if (h->cfg.n_shards != P || h->cfg.shard_id != s2) return fail(KMC_E_ARG, "handle %d is not shard %d of %d", s2, s2, P);
+        if (h->cfg.device != hs[0]->cfg.device || h->send_cap != hs[0]->send_cap || h->rec_words != hs[0]->rec_words)
+            return fail(KMC_E_ARG, "local exchange: shards must share the device and the send geometry");
+    }
+    HIP_TRY(hipSetDevice(hs[0]->cfg.device));
+    std::vector<uint64_t> counts((size_t)P * P * KMC_SEGS, 0);
+    for (int s2 = 0; s2 < P; ++s2)
+        for (int d = 0; d < P; ++d)
+            for (int sb = 0; sb < KMC_SEGS; ++sb)
+                counts[((size_t)s2 * P + d) * KMC_SEGS + sb] = d == s2 ? 0 : hs[s2]->last_send_counts[d * KMC_SEGS + sb];
+    for (int k = 0; k < n_stats; ++k) {
+        stats_sum[k] = 0;
+        for (int s2 = 0; s2 < P; ++s2) stats_sum[k] += stats[(size_t)s2 * n_stats + k];
+    }
+    for (int s2 = 0; s2 < P; ++s2) {
+        hs[s2]->xcounts = counts;
+        hs[s2]->xcounts_valid = true;
+        if (P > 1) {
+            int rc = ensure_exchange_buffers(hs[s2]);
+            if (rc) return rc;
+        }
+    }
+    return KMC_OK;
+}
+
+int kmc_step_deliver_local(kmc_handle** hs, int32_t n_shards) {
+    if (!hs || n_shards < 1 || n_shards > KMC_MAX_SHARDS) return fail(KMC_E_ARG, "bad shard list");
+    const int P = n_shards;
+    for (int s2 = 0; s2 < P; ++s2)
+        if (!hs[s2] || !hs[s2]->xcounts_valid) return fail(KMC_E_STATE, "kmc_step_exchange_local first");
+    HIP_TRY(hipSetDevice(hs[0]->cfg.device));
+    // every shard's k_expand has completed (kmc_step_expand waits for its control block), so the send areas are final
+    for (int me = 0; me < P; ++me) {
+        kmc_handle* h = hs[me];
+        h->xcounts_valid = false;
+        std::vector<KmcXfer> sv, rv;
+        uint64_t nrec = 0;
+        plan_level(h->xcounts.data(), P, me, h->send_cap, (uint64_t)h->rec_words, &sv, &rv, &nrec);
+        if (P > 1 && nrec > h->recv_cap) return fail(KMC_E_STATE, "exchange: receive area too small");
+        // a receive from `peer` is matched by that peer's sends to `me`, in posting order, cut identically
+        std::vector<size_t> cursor(P, 0);
+        std::vector<std::vector<KmcXfer>> peer_sends(P);
+        for (int q = 0; q < P; ++q) {
+            if (q == me) continue;
+            std::vector<KmcXfer> qs, qr;
+            uint64_t dummy = 0;
+            plan_level(h->xcounts.data(), P, q, h->send_cap, (uint64_t)h->rec_words, &qs, &qr, &dummy);
+            for (const KmcXfer& x : qs)
+                if ((int)x.peer == me) peer_sends[q].push_back(x);
+        }
+        for (const KmcXfer& x : rv) {
+            const int q = (int)x.peer;
+            if (cursor[q] >= peer_sends[q].size() || peer_sends[q][cursor[q]].words != x.words)
+                return fail(KMC_E_STATE, "exchange plan mismatch between shards %d and %d", q, me);
+            const KmcXfer& sx = peer_sends[q][cursor[q]++];
+            HIP_TRY(hipMemcpyAsync(h->recv + x.offset_words, hs[q]->send + sx.offset_words, x.words * 8,
+                                   hipMemcpyDeviceToDevice, h->stream));
+        }
+        for (int q = 0; q < P; ++q)
+            if (q != me && cursor[q] != peer_sends[q].size())
+                return fail(KMC_E_STATE, "exchange plan mismatch: unmatched sends from shard %d to %d", q, me);
+        int rc = insert_received(h, nrec);
+        if (rc) return rc;
+    }
+    return KMC_OK;
+}
+
+// The invariants of the CURRENT frontier without expanding it: what kmc_run does for the last level under
+// max_levels (every state is normally checked when it is expanded; an unexpanded last level would otherwise go
+// unchecked).  Fills violation_count / violation_fp only.
+int kmc_step_check_frontier(kmc_handle* h, kmc_level_info* info) {
+    if (!h || !h->stepping || !info) return fail(KMC_E_STATE, "kmc_step_begin first");
+    if (h->step_expanded) return fail(KMC_E_STATE, "kmc_step_check_frontier between kmc_step_expand and kmc_step_finish");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    memset(info, 0, sizeof *info);
+    info->depth = h->level;
+    info->new_states = h->n_cur;
+    if (h->n_cur == 0 || h->cfg.invariant_mask == 0) return KMC_OK;
+    int rc = zero_ctl(h, 2);
+    if (rc) return rc;
+    KmcArgs d = base_args(h, 2);
+    d.fin = h->frontier[h->cur];
+    d.mode = KMC_MODE_DRY;
+    if ((rc = launch(h, h->f_expand, d, expand_grid(h, h->n_cur)))) return rc;
+    if ((rc = read_ctl(h, 2))) return rc;
+    for (int k = 0; k < 4; ++k) {
+        info->violation_count[k] = h->ctl_host->viol_count[k];
+        info->violation_fp[k] = h->ctl_host->viol_count[k] ? ~h->ctl_host->viol_fp_inv[k] : 0;
+    }
+    return KMC_OK;
+}
+
+// A violating successor OUTSIDE the state constraint is in no shard's table and no frontier.  After the
+// kmc_step_finish of the expansion that generated it (and before the next kmc_step_expand overwrites that level),
+// this looks for it among the successors of the retired level: *found = 1 gives its packed words and the
+// fingerprint of the parent it was generated from (the smallest one).
+int kmc_step_find_outside(kmc_handle* h, uint64_t fp, uint64_t* words, uint64_t* parent_fp, int32_t* found) {
+    if (!h || !h->stepping || !words || !parent_fp || !found) return fail(KMC_E_ARG, "bad argument");
+    if (h->step_expanded) return fail(KMC_E_STATE, "the retired level has been overwritten by kmc_step_expand");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    *found = 0;
+    uint64_t n = 0;
+    for (int sg = 0; sg < KMC_SEGS; ++sg) n += h->prev_seg_n[sg];
+    if (n == 0) return KMC_OK;
+    const bool had = h->have_witness;
+    int rc = find_outside_witness(h, h->frontier[h->cur ^ 1], h->prev_seg_n, fp);
+    if (rc) {  // "not found among the successors" is an answer here, not an error
+        g_err.clear();
+        h->witness_outside = false;
+        h->have_witness = had;
+        return KMC_OK;
+    }
+    for (int k = 0; k < h->W; ++k) words[k] = h->witness[k];
+    *parent_fp = h->witness_parent_fp;
+    *found = 1;
+    return KMC_OK;
 }
 
 int kmc_step_set_verdict(kmc_handle* h, int32_t verdict) {

@@ -39,28 +39,38 @@ N_STATS = 32  # [new, generated[16], viol[4], deadlocks, err_table, err_frontier
 class HipShardEngine:
     """One shard on one GPU through the kmc_step_* C ABI."""
 
-    def __init__(self, cfg: CheckerConfig, shard_id: int, n_shards: int, device: int):
-        import torch
-        self.torch = torch
-        self.cfg = replace(cfg, n_shards=n_shards, shard_id=shard_id, device=device)
+    def __init__(self, cfg: CheckerConfig, shard_id: int, n_shards: int, device: int, native: bool = True):
+        """native=True (the product): the send and receive areas belong to the engine and the per-level
+        exchange runs under the C ABI (RcclExchange / NativeLoopbackExchange) — no torch object is involved.
+        native=False: the send area is a torch tensor whose filled slices are handed to a torch.distributed
+        collective (DistExchange) or routed in process (LoopbackExchange)."""
+        native = native and os.environ.get("KMC_EXCHANGE", "rccl") != "torch"
+        self.native = native
+        subs = nat.KMC_SEND_SUBS
+        scap = cfg.send_capacity or max(1 << 13, (cfg.frontier_capacity or (1 << 22)) * 4 // (n_shards * subs))
+        self.send_cap = scap
+        self.cfg = replace(cfg, n_shards=n_shards, shard_id=shard_id, device=device, send_capacity=scap)
         self.shard_id, self.n_shards = shard_id, n_shards
-        self.device = torch.device("cuda", device)
         self.mc = ModelChecker(self.cfg)
         self.lib = nat.lib()
         self.W = self.mc.state_words
         self.record_words = self.W + (1 if cfg.keep_trace else 0)  # the predecessor fingerprint travels only for traces
-        # the send area belongs to torch so that slices of it can be handed to the collective:
-        # [destination][sub-buffer][record]; block b of k_expand fills sub-buffer b % KMC_SEND_SUBS
-        subs = nat.KMC_SEND_SUBS
-        scap = cfg.send_capacity or max(1 << 13, (cfg.frontier_capacity or (1 << 22)) * 4 // (n_shards * subs))
-        self.send_cap = scap
-        self.send = torch.zeros((n_shards, subs, scap, self.record_words), dtype=torch.int64, device=self.device)
-        nat.check(self.lib.kmc_step_set_send_buffer(self.mc.handle, C.c_void_p(self.send.data_ptr()), scap))
+        self.torch = None
+        if not native:
+            import torch
+            self.torch = torch
+            self.device = torch.device("cuda", device)
+            # the send area belongs to torch so that slices of it can be handed to the collective:
+            # [destination][sub-buffer][record]; block b of k_expand fills sub-buffer b % KMC_SEND_SUBS
+            self.send = torch.zeros((n_shards, subs, scap, self.record_words), dtype=torch.int64, device=self.device)
+            nat.check(self.lib.kmc_step_set_send_buffer(self.mc.handle, C.c_void_p(self.send.data_ptr()), scap))
         self._last = None
         self._viol_fp = [0, 0, 0, 0]
+        self._oviol_fp = [0, 0, 0, 0]
 
     def close(self):
-        self.torch.cuda.synchronize(self.device)
+        if self.torch is not None:
+            self.torch.cuda.synchronize()
         self.mc.close()
 
     def begin(self):
@@ -76,6 +86,8 @@ class HipShardEngine:
         subs = nat.KMC_SEND_SUBS
         counts = (C.c_uint64 * (nat.KMC_MAX_SHARDS * subs))()
         nat.check(self.lib.kmc_step_expand(self.mc.handle, counts))
+        if self.native:
+            return None          # the engine keeps the counts; the exchange under the ABI moves the runs
         return [[self.send[d, sb, :int(counts[d * subs + sb])] for sb in range(subs) if counts[d * subs + sb]]
                 for d in range(self.n_shards)]
 
@@ -104,7 +116,31 @@ class HipShardEngine:
         st[22] = 1 if info.error_flags & 2 else 0
         st[23] = 1 if info.error_flags & (1 | 4) else 0
         self._viol_fp = [int(info.violation_fp[k]) for k in range(4)]
+        self._oviol_fp = [int(info.outside_violation_fp[k]) for k in range(4)]
         return st
+
+    def check_frontier(self):
+        """Invariant-only pass over the current, unexpanded frontier (the last level under max_levels):
+        st[17..20] = violations among its states."""
+        info = nat.KmcLevelInfo()
+        nat.check(self.lib.kmc_step_check_frontier(self.mc.handle, C.byref(info)))
+        st = np.zeros(N_STATS, dtype=np.int64)
+        for k in range(4):
+            st[17 + k] = info.violation_count[k]
+        self._viol_fp = [int(info.violation_fp[k]) for k in range(4)]
+        return st
+
+    def outside_violation_fp(self, inv_index: int) -> int:
+        """Smallest fingerprint of the violating successors OUTSIDE the state constraint this shard generated in
+        the last finished expansion (0 = none)."""
+        return self._oviol_fp[inv_index]
+
+    def find_outside(self, fp: int):
+        """(packed words, parent fingerprint) of the outside-the-constraint successor fp if this shard's retired
+        level generates it, else None.  Valid between finish() and the next expand()."""
+        words, parent, found = (C.c_uint64 * self.W)(), C.c_uint64(), C.c_int32()
+        nat.check(self.lib.kmc_step_find_outside(self.mc.handle, C.c_uint64(fp), words, C.byref(parent), C.byref(found)))
+        return ([int(x) for x in words], int(parent.value)) if found.value else None
 
     def result(self) -> CheckResult:
         return self.mc.result()
@@ -162,6 +198,92 @@ class LoopbackExchange:
 
     def barrier(self):
         pass
+
+
+class NativeLoopbackExchange:
+    """P native HipShardEngines in one process on one GPU: kmc_step_exchange_local / kmc_step_deliver_local move
+    every run with a device-to-device copy, following the same plan (kmc_exchange_plan) the RCCL transport
+    executes, and each shard inserts what it received with one k_insert."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        self.n = len(self.engines)
+        self.lib = nat.lib()
+        self.handles = (C.c_void_p * self.n)(*[e.mc.handle for e in self.engines])
+
+    def exchange(self, sends, stats):
+        flat = np.ascontiguousarray(np.stack(stats), dtype=np.int64)
+        out = np.zeros(N_STATS, dtype=np.int64)
+        nat.check(self.lib.kmc_step_exchange_local(self.handles, self.n, flat.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                   N_STATS, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out, self._deliver
+
+    def _deliver(self):
+        nat.check(self.lib.kmc_step_deliver_local(self.handles, self.n))
+        return [[] for _ in self.engines]     # already inserted under the ABI
+
+    def all_reduce_sum(self, stats):
+        return np.sum(np.stack(stats), axis=0)
+
+    def all_reduce_max(self, x: float) -> float:
+        return x
+
+    def barrier(self):
+        pass
+
+
+class RcclExchange:
+    """One native HipShardEngine per process, one process per GPU: the per-level exchange under the C ABI
+    (kmc_step_exchange_counts / kmc_step_exchange_payload: an RCCL all-gather of counts + statistics, grouped
+    ncclSend/ncclRecv from the send area into the receive area, one k_insert, all on the engine's stream).
+    torch.distributed is used for the bootstrap only (the unique id travels through the default process
+    group) and for the rare small reductions of trace reconstruction and bench timing."""
+
+    def __init__(self, engine, device):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.engine, self.device = engine, device
+        self.lib = nat.lib()
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        uid = (C.c_uint8 * nat.KMC_COMM_ID_BYTES)()
+        if self.rank == 0:
+            nat.check(self.lib.kmc_comm_unique_id(uid))
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0)
+        uid = (C.c_uint8 * nat.KMC_COMM_ID_BYTES)(*box[0])
+        nat.check(self.lib.kmc_comm_init(engine.mc.handle, uid))
+
+    def selftest(self):
+        nat.check(self.lib.kmc_comm_selftest(self.engine.mc.handle))
+
+    def exchange(self, sends, stats):
+        (st,) = stats
+        st = np.ascontiguousarray(st, dtype=np.int64)
+        out = np.zeros(N_STATS, dtype=np.int64)
+        nrecv = C.c_uint64()
+        nat.check(self.lib.kmc_step_exchange_counts(self.engine.mc.handle, st.ctypes.data_as(C.POINTER(C.c_int64)), N_STATS,
+                                                    out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nrecv)))
+        return out, self._deliver
+
+    def _deliver(self):
+        nat.check(self.lib.kmc_step_exchange_payload(self.engine.mc.handle))
+        return [[]]
+
+    def all_reduce_sum(self, stats):
+        torch, dist = self.torch, self.dist
+        t = torch.from_numpy(np.sum(np.stack(stats), axis=0)).to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def all_reduce_max(self, x: float) -> float:
+        torch, dist = self.torch, self.dist
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        self.dist.barrier()
 
 
 class DistExchange:
@@ -314,6 +436,12 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
     # so expansion k+1 has already run locally when its predecessor's verdict becomes known: after
     # a stop, or once the global frontier is empty, that speculative expansion is simply not
     # counted (on an empty frontier it did nothing at all).
+    # Exception: a model with a state constraint whose traces are wanted.  A violating successor OUTSIDE the
+    # constraint is in no table; its words and its parent can only be recovered from the level that generated
+    # it, which the speculative expansion would already have overwritten.  Those runs reduce the statistics
+    # first and expand afterwards (one small collective more per level).
+    pipelined = not (cfg.keep_trace and cfg.model == "AsyncIsr")
+    zeros = [np.zeros(N_STATS, dtype=np.int64) for _ in engines]
     pending = [e.begin() for e in engines]   # per-engine statistics not yet reduced ...
     pending_depth = 0                        # ... of the expansion of this level (0: Init's insertion)
     depth = 0                                # levels recorded so far
@@ -322,7 +450,7 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
     while True:
         # the engines hold level depth+1 (complete); like kmc_run, level l is expanded iff l < max_levels
         can_expand = depth + 1 < max_levels
-        if can_expand:
+        if can_expand and pipelined:
             sends = [e.expand() for e in engines]
             st, deliver = exchange.exchange(sends, pending)
         else:
@@ -339,18 +467,28 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
             progress(dict(depth=depth, new_states=new, generated=generated, distinct=sum(levels)))
         if not can_expand:
             break
+        if not pipelined:
+            sends = [e.expand() for e in engines]
+            _, deliver = exchange.exchange(sends, zeros)
         recvs = deliver()
         for e, rs in zip(engines, recvs):
             for r in rs:
                 e.insert(r)
         pending = [e.finish() for e in engines]
         pending_depth = depth
+    if depth >= max_levels and new > 0 and verdict in ("ok", "invariant") and viol_inv is None:
+        # like kmc_run: the last frontier is not expanded, so its states get their invariant check now
+        st = exchange.all_reduce_sum([e.check_frontier() for e in engines])
+        counts = {n: int(st[17 + k]) for k, n in enumerate(inv_names)}
+        hit = [n for n in inv_names if n in cfg.invariants and counts[n]]
+        if hit:
+            viol_inv, viol_depth, viol_count, verdict = hit[0], depth, counts, "invariant"
     if depth >= max_levels and new > 0 and verdict == "ok":
-        verdict = "level_limit"  # (the unexpanded last frontier is not invariant-checked in sharded mode)
+        verdict = "level_limit"
     trace = []
-    if verdict == "invariant" and cfg.keep_trace and viol_depth <= len(levels):
-        # (a witness outside the state constraint, viol_depth = len(levels) + 1, is in no shard's table)
-        trace = _sharded_trace(engines, exchange, inv_names.index(viol_inv), action_names)
+    if verdict == "invariant" and cfg.keep_trace:
+        outside = viol_depth > len(levels)   # a witness outside the state constraint: in no shard's table
+        trace = _sharded_trace(engines, exchange, inv_names.index(viol_inv), action_names, outside)
     local = [e.result() for e in engines]
     run_sharded.last_send_filtered = filtered  # observability for tests / bench
     return CheckResult(
@@ -368,7 +506,19 @@ def _split64(x):
     return [x & 0xFFFFFFFF, x >> 32]
 
 
-def _sharded_trace(engines, exchange, inv_index, action_names):
+def _min_fp_over_shards(engines, exchange, values):
+    """values: {shard_id: fingerprint or 0} of this process's engines -> the smallest non-zero one over all shards."""
+    P = engines[0].n_shards
+    v = np.zeros(2 * P, dtype=np.int64)
+    for sid, fp in values.items():
+        v[2 * sid:2 * sid + 2] = _split64(fp)
+    v = exchange.all_reduce_sum([v])
+    cands = [int(v[2 * i]) | (int(v[2 * i + 1]) << 32) for i in range(P)]
+    cands = [c for c in cands if c]
+    return min(cands) if cands else 0
+
+
+def _sharded_trace(engines, exchange, inv_index, action_names, outside=False):
     """Counterexample of a sharded run (keep_trace): [(action name or None, canonical bytes)] from Init to
     the witness.  Every rank executes the same steps: (1) the witness is the smallest violating
     fingerprint over all shards (one small reduction); (2) the predecessor chain is walked owner by
@@ -376,16 +526,26 @@ def _sharded_trace(engines, exchange, inv_index, action_names):
     step carries the answer to everybody; (3) the chain is replayed forward from Init with the device's
     own successor enumeration, locally, picking at each step the successor whose fingerprint is next —
     what TLC does with its trace file [TLC-recall]."""
-    P = engines[0].n_shards
-    v = np.zeros(2 * P, dtype=np.int64)
-    for e in engines:
-        v[2 * e.shard_id:2 * e.shard_id + 2] = _split64(e.violation_fp(inv_index))
-    v = exchange.all_reduce_sum([v])
-    cands = [int(v[2 * i]) | (int(v[2 * i + 1]) << 32) for i in range(P)]
-    cands = [c for c in cands if c]
-    if not cands:
-        return []
-    chain = [min(cands)]
+    tail = []     # an outside-the-constraint witness: [its fingerprint]; the chain proper starts at its parent
+    if outside:
+        # the witness is the smallest violating outside-fingerprint over all shards; every shard that generates
+        # it from its retired level offers a parent, the smallest parent fingerprint wins
+        wfp = _min_fp_over_shards(engines, exchange, {e.shard_id: e.outside_violation_fp(inv_index) for e in engines})
+        if not wfp:
+            return []
+        offers = {}
+        for e in engines:
+            hit = e.find_outside(wfp)
+            offers[e.shard_id] = hit[1] if hit else 0
+        start = _min_fp_over_shards(engines, exchange, offers)
+        if not start:
+            raise RuntimeError(f"trace: no shard generates the outside-constraint witness {wfp:016x}")
+        tail = [wfp]
+    else:
+        start = _min_fp_over_shards(engines, exchange, {e.shard_id: e.violation_fp(inv_index) for e in engines})
+        if not start:
+            return []
+    chain = [start]
     for _guard in range(1 << 16):
         fp = chain[-1]
         a = np.zeros(3, dtype=np.int64)
@@ -402,6 +562,7 @@ def _sharded_trace(engines, exchange, inv_index, action_names):
             break
         chain.append(pred)
     chain.reverse()
+    chain += tail
     e0 = engines[0]
     cur = e0.init_words()
     if e0.fingerprint(cur) != chain[0]:
@@ -421,17 +582,22 @@ def _sharded_trace(engines, exchange, inv_index, action_names):
 def check_loopback(cfg: CheckerConfig, n_shards: int, device: int = 0, progress=None) -> CheckResult:
     """P logical shards on ONE GPU with an in-process exchange (tests the bucket / insert kernels
     and the level logic without RCCL)."""
-    engines = [HipShardEngine(cfg, s, n_shards, device) for s in range(n_shards)]
+    native = os.environ.get("KMC_EXCHANGE", "rccl") != "torch"
+    engines = [HipShardEngine(cfg, s, n_shards, device, native=native) for s in range(n_shards)]
     try:
-        return run_sharded(engines, LoopbackExchange(n_shards), cfg, engines[0].mc.action_names(), progress)
+        ex = NativeLoopbackExchange(engines) if native else LoopbackExchange(n_shards)
+        return run_sharded(engines, ex, cfg, engines[0].mc.action_names(), progress)
     finally:
         for e in engines:
             e.close()
 
 
 def make_exchange(eng, device):
-    """The per-level exchange of a one-shard-per-rank job: torch.distributed's all-gather + all-to-all
-    ("nccl" = RCCL on GPUs, "gloo" on CPU)."""
+    """The per-level exchange of a one-shard-per-rank job.  A native HipShardEngine on a GPU gets the exchange
+    under the C ABI (RcclExchange); KMC_EXCHANGE=torch selects torch.distributed's all-gather + all-to-all
+    instead (also what a stand-in engine on gloo gets)."""
+    if getattr(eng, "native", False) and device.type == "cuda" and os.environ.get("KMC_EXCHANGE", "rccl") != "torch":
+        return RcclExchange(eng, device)
     return DistExchange(device, eng.record_words)
 
 

@@ -1,13 +1,20 @@
 """`tlc2.TLC`-shaped command line [TLC-recall]:
 
     python -m kafka_specification_amd.tlc [-config X.cfg] [-deadlock] [-continue] [-workers N]
-                                          [-fp SEED] [-gpus P] [-table SLOTS] [-frontier STATES] Spec.tla
+                                          [-fp SEED] [-fpcheck] [-verify] [-force] [-gpus P] [-table SLOTS]
+                                          [-frontier STATES] Spec.tla
 
 Maps the root module's name to its lowered GPU model, reads constants / invariants from the
 .cfg (default: Spec.cfg next to the module), runs the exhaustive search on the GPU and prints
 TLC-style progress and summary lines.  -workers is accepted for command-line compatibility
 and ignored (the GPU's waves are the workers).  No TLA+ is parsed: only the modules of
-hachikuji/kafka-specification that have a Next are known.
+hachikuji/kafka-specification that have a Next are known — so the spec file given on the command line (and
+every module it EXTENDS / INSTANCEs, when found beside it) is hashed against the revision the kernels were
+lowered from (spec_revision.py); an edited spec is refused unless -force.
+
+The seen-set holds 64-bit fingerprints, like TLC's FPSet: two distinct states with one fingerprint lose a state
+silently.  Like TLC, the summary prints the estimated probability of that; -fpcheck runs the search a second
+time with another fingerprint seed and compares the counts (a collision moves with the seed).
 """
 from __future__ import annotations
 
@@ -25,6 +32,17 @@ def _now():
     return time.strftime("%Y-%m-%d %H:%M:%S")
 
 
+def collision_report(distinct: int, generated: int):
+    """TLC's closing estimate [TLC-recall: "calculated (optimistic)" = distinct x (generated - distinct) / 2^64], plus
+    the birthday bound n^2 / 2^65 for the fingerprints that were stored."""
+    opt = distinct * max(generated - distinct, 0) / 2.0 ** 64
+    birthday = distinct * distinct / 2.0 ** 65
+    return ["The seen-set stores 64-bit fingerprints; estimates of the probability that not all reachable states were "
+            "checked because two distinct states had the same fingerprint:",
+            f"  calculated (optimistic):  val = {opt:.2E}",
+            f"  birthday bound on the stored fingerprints:  val = {birthday:.2E}"]
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="tlc", add_help=True, prefix_chars="-")
     ap.add_argument("spec")
@@ -39,6 +57,12 @@ def main(argv=None) -> int:
     ap.add_argument("-frontier", type=int, default=0)
     ap.add_argument("-device", type=int, default=0)
     ap.add_argument("-notrace", action="store_true", help="do not keep predecessor links (no counterexample trace)")
+    ap.add_argument("-fpcheck", action="store_true",
+                    help="run the search again with a second fingerprint seed and compare the counts")
+    ap.add_argument("-verify", action="store_true",
+                    help="differential self-check: a second, differently compiled build of the kernels regenerates every "
+                         "level and the per-action / deadlock / violation counts must agree (for constants no oracle reaches)")
+    ap.add_argument("-force", action="store_true", help="check the built-in lowering although the spec text differs from it")
     a = ap.parse_args(argv)
 
     module = os.path.splitext(os.path.basename(a.spec))[0]
@@ -57,6 +81,19 @@ def main(argv=None) -> int:
         print(f"Error: {e}", file=sys.stderr)
         return 2
 
+    if a.verify:
+        os.environ["KMC_VERIFY"] = "1"
+    from .spec_revision import check_spec
+    status, msgs = check_spec(a.spec)
+    for m in msgs:
+        print(("Warning: " if status != "mismatch" else "Error: ") + m, file=sys.stderr)
+    if status == "mismatch":
+        if not a.force:
+            print("Error: the spec differs from the revision the GPU kernels were lowered from; nothing was checked "
+                  "(-force checks the built-in lowering anyway)", file=sys.stderr)
+            return 2
+        print("Warning: -force: checking the BUILT-IN lowering, not the text of the spec given", file=sys.stderr)
+
     print(f"kafka_specification_amd model checker (MI355X) — module {module}, config {os.path.basename(cfg_path)}")
     print(f"Running breadth-first search Model-Checking with fp seed {a.fp} on GPU {a.device}.")
     print("Computing initial states...")
@@ -69,19 +106,29 @@ def main(argv=None) -> int:
                   f"{i['distinct']} distinct states found, {i['new_states']} states left on queue.")
 
     from ._native import KmcError
-    try:
+    from dataclasses import replace
+
+    def search(conf, progress):
         if a.gpus > 1:
             from .sharded import check_loopback
-            res = check_loopback(cc, a.gpus, a.device, progress)
-            trace = res.trace   # walked owner by owner through the shards' predecessor tables
-        else:
-            with ModelChecker(cc) as mc:
-                res = mc.run(progress)
-                trace = []
-                if res.verdict in ("invariant",) and cc.keep_trace:
-                    trace = mc.trace()
-                elif res.verdict == "deadlock":
-                    trace = [(None, mc.unpack(mc.witness()))]
+            res = check_loopback(conf, a.gpus, a.device, progress)
+            return res, res.trace   # walked owner by owner through the shards' predecessor tables
+        with ModelChecker(conf) as mc:
+            res = mc.run(progress)
+            trace = []
+            if res.verdict in ("invariant",) and conf.keep_trace:
+                trace = mc.trace()
+            elif res.verdict == "deadlock":
+                trace = [(None, mc.unpack(mc.witness()))]
+            return res, trace
+
+    second = None
+    try:
+        res, trace = search(cc, progress)
+        if a.fpcheck:
+            seed2 = (a.fp * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
+            second, _ = search(replace(cc, hash_seed=seed2, keep_trace=False), None)
+            second = (seed2, second)
     except KmcError as e:
         print(f"Error: {e}", file=sys.stderr)
         return 3
@@ -110,6 +157,16 @@ def main(argv=None) -> int:
     print(f"{res.generated} states generated, {res.distinct} distinct states found, "
           f"{res.queue_left} states left on queue.")
     print(f"The depth of the complete state graph search is {res.depth}.")
+    for line in collision_report(res.distinct, res.generated):
+        print(line)
+    if second is not None:
+        seed2, r2 = second
+        same = (r2.verdict, r2.distinct, r2.generated, r2.depth) == (res.verdict, res.distinct, res.generated, res.depth)
+        print(f"Fingerprint check: second run with fp seed {seed2}: {r2.generated} states generated, {r2.distinct} distinct "
+              f"states found, depth {r2.depth} - " + ("identical to the first run." if same else
+              "DIFFERENT from the first run: a fingerprint collision dropped states in at least one of them."))
+        if not same and rc == 0:
+            rc = 13
     print(f"Finished in {res.seconds_total:.3f}s ({res.distinct / max(res.seconds_total, 1e-9):,.0f} distinct states/s; "
           f"{res.seconds_expand:.3f}s in the expand kernel) at ({_now()})")
     return rc

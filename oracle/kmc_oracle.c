@@ -24,6 +24,7 @@
  */
 #define _GNU_SOURCE
 #include <pthread.h>
+#include <sys/mman.h>
 #include <stdatomic.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -868,25 +869,95 @@ static int engine_insert(Engine *e, const uint8_t *st, uint64_t parent, int acti
     }
 }
 
-static void engine_grow(Engine *e, uint64_t want) {
-    uint64_t cap = e->cap ? e->cap : 1024;
-    while (cap < want) cap <<= 1;
-    if (cap == e->cap) return;
-    free((void *)e->table);
-    e->table = calloc(cap, sizeof(uint64_t));
-    if (!e->table) {
-        fprintf(stderr, "kmc_oracle: out of memory (table)\n");
-        abort();
+/* Static slices of an index range on T threads (the level-start phases: invariants, re-hashing).  The BFS used to run
+ * both on the calling thread alone, which capped the whole search near the single-thread rate whatever `threads` was
+ * (8 threads: 1.4x; the expansion itself scales). */
+typedef struct {
+    Engine *e;
+    void (*fn)(void *job, uint64_t lo, uint64_t hi);
+    void *arg;
+    uint64_t lo, hi;
+} Slice;
+static void *slice_main(void *a) {
+    Slice *sl = a;
+    sl->fn(sl->arg, sl->lo, sl->hi);
+    return NULL;
+}
+/* args: T contiguous per-thread argument records of `stride` bytes */
+static void run_slices(int T, uint64_t lo, uint64_t hi, void (*fn)(void *, uint64_t, uint64_t), void *args, size_t stride) {
+    if (T <= 1 || hi - lo < 4096) {
+        fn(args, lo, hi);
+        return;
     }
-    e->cap = cap;
-    uint64_t n = atomic_load(&e->nstates);
-    for (uint64_t idx = 0; idx < n; idx++) {
+    pthread_t th[256];
+    Slice sl[256];
+    if (T > 256) T = 256;
+    for (int t = 0; t < T; t++) {
+        sl[t].fn = fn;
+        sl[t].arg = (char *)args + (size_t)t * stride;
+        sl[t].lo = lo + (hi - lo) * (uint64_t)t / (uint64_t)T;
+        sl[t].hi = lo + (hi - lo) * (uint64_t)(t + 1) / (uint64_t)T;
+        pthread_create(&th[t], NULL, slice_main, &sl[t]);
+    }
+    for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+}
+
+typedef struct {
+    Engine *e;
+    uint64_t cap;
+} RehashJob;
+static void rehash_slice(void *a, uint64_t lo, uint64_t hi) {
+    RehashJob *j = a;
+    Engine *e = j->e;
+    const uint64_t cap = j->cap;
+    for (uint64_t idx = lo; idx < hi; idx++) {
         const uint8_t *st = rec_ptr(e, idx);
         uint64_t h = hash_bytes(st, e->p.sb);
         uint64_t tag = (h >> 40) << 40, i = h & (cap - 1);
-        while (atomic_load_explicit(&e->table[i], memory_order_relaxed)) i = (i + 1) & (cap - 1);
-        atomic_store_explicit(&e->table[i], tag | (idx + 2), memory_order_relaxed);
+        for (;;) {
+            uint64_t exp = 0;
+            if (atomic_load_explicit(&e->table[i], memory_order_relaxed) == 0 &&
+                atomic_compare_exchange_strong(&e->table[i], &exp, tag | (idx + 2)))
+                break;
+            i = (i + 1) & (cap - 1);
+        }
     }
+}
+static void engine_grow(Engine *e, uint64_t want, int T) {
+    uint64_t cap = e->cap ? e->cap : 1024;
+    while (cap < want) cap <<= 1;
+    if (cap == e->cap) return;
+    if (e->cap && cap < 4 * e->cap && cap < (1ull << 30)) cap = 4 * e->cap; /* below 8 GiB: grow by 4, re-hash half as often */
+    /* a fresh anonymous mapping is zero-filled; ask for huge pages (512x fewer first-touch faults — they, not the
+     * re-hashing, were most of the "table growth" time) and let the re-hashing threads do the first touch */
+    if (e->table) munmap((void *)e->table, e->cap * sizeof(uint64_t));
+    void *m = mmap(NULL, cap * sizeof(uint64_t), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) {
+        fprintf(stderr, "kmc_oracle: out of memory (table)\n");
+        abort();
+    }
+#ifdef MADV_HUGEPAGE
+    madvise(m, cap * sizeof(uint64_t), MADV_HUGEPAGE);
+#endif
+    e->table = m;
+    e->cap = cap;
+    uint64_t n = atomic_load(&e->nstates);
+    RehashJob jobs[256];
+    for (int t = 0; t < 256; t++) { jobs[t].e = e; jobs[t].cap = cap; }
+    run_slices(T, 0, n, rehash_slice, jobs, sizeof(RehashJob));
+}
+
+typedef struct {
+    Engine *e;
+    uint32_t inv_mask;
+    uint64_t cnt[4], first[4];
+} InvJob;
+static void invariant_slice(void *a, uint64_t lo, uint64_t hi) {
+    InvJob *j = a;
+    for (uint64_t idx = lo; idx < hi; idx++)
+        for (int inv = 0; inv < 4; inv++)
+            if ((j->inv_mask >> inv & 1) && !model_invariant(&j->e->p, inv, rec_ptr(j->e, idx)))
+                if (j->cnt[inv]++ == 0) j->first[inv] = idx;
 }
 
 static void worker_emit(void *ctx, int action, const uint8_t *succ) {
@@ -976,7 +1047,7 @@ void *kmo_run(const kmo_config *cfg, kmo_result *res) {
     e->rs = e->p.sb + 5;
     pthread_mutex_init(&e->chunk_mu, NULL);
     int T = cfg->threads > 0 ? cfg->threads : 1;
-    engine_grow(e, 1 << 16);
+    engine_grow(e, 1 << 16, 1);
 
     uint8_t init[KMO_MAXSB];
     if (e->p.model == M_IDSEQ || e->p.model == M_FRL)
@@ -990,6 +1061,15 @@ void *kmo_run(const kmo_config *cfg, kmo_result *res) {
     res->viol_inv = -1;
 
     uint64_t lo = 0, hi = 1;
+    double t_inv = 0, t_grow = 0, t_exp = 0; /* KMO_TIMING=1: where a run's time goes */
+    struct timespec ta, tb;
+#define KMO_TICK(acc)                                                             \
+    do {                                                                          \
+        clock_gettime(CLOCK_MONOTONIC, &tb);                                      \
+        acc += (tb.tv_sec - ta.tv_sec) + 1e-9 * (tb.tv_nsec - ta.tv_nsec);        \
+        ta = tb;                                                                  \
+    } while (0)
+    clock_gettime(CLOCK_MONOTONIC, &ta);
     Worker *ws = calloc(T, sizeof(Worker));
     pthread_t *th = calloc(T, sizeof(pthread_t));
     for (;;) {
@@ -998,11 +1078,20 @@ void *kmo_run(const kmo_config *cfg, kmo_result *res) {
         res->nlevels++;
         res->depth = res->nlevels;
         if (cfg->inv_mask && res->viol_inv < 0) {
+            /* slices are ordered, so the first violator of the lowest slice is the smallest index: the result is
+             * the serial loop's, whatever T is */
             uint64_t cnt[4] = {0, 0, 0, 0}, first[4] = {0, 0, 0, 0};
-            for (uint64_t idx = lo; idx < hi; idx++)
+            InvJob *ij = calloc(256, sizeof(InvJob));
+            for (int t = 0; t < 256; t++) { ij[t].e = e; ij[t].inv_mask = cfg->inv_mask; }
+            run_slices(T, lo, hi, invariant_slice, ij, sizeof(InvJob));
+            for (int t = 0; t < 256; t++)
                 for (int inv = 0; inv < 4; inv++)
-                    if ((cfg->inv_mask >> inv & 1) && !model_invariant(&e->p, inv, rec_ptr(e, idx)))
-                        if (cnt[inv]++ == 0) first[inv] = idx;
+                    if (ij[t].cnt[inv]) {
+                        if (cnt[inv] == 0) first[inv] = ij[t].first[inv];
+                        cnt[inv] += ij[t].cnt[inv];
+                    }
+            free(ij);
+            KMO_TICK(t_inv);
             for (int inv = 0; inv < 4; inv++)
                 if (cnt[inv]) {
                     res->viol_inv = inv;
@@ -1021,7 +1110,9 @@ void *kmo_run(const kmo_config *cfg, kmo_result *res) {
             break;
         }
         /* keep the table sparse enough to absorb this level's growth */
-        engine_grow(e, 4 * (hi + 6 * (hi - lo)));
+        clock_gettime(CLOCK_MONOTONIC, &ta);
+        engine_grow(e, 4 * (hi + 6 * (hi - lo)), T);
+        KMO_TICK(t_grow);
         e->lo = lo; e->hi = hi;
         atomic_store(&e->cursor, lo);
         for (int t = 0; t < T; t++) {
@@ -1035,6 +1126,7 @@ void *kmo_run(const kmo_config *cfg, kmo_result *res) {
         uint64_t dl = 0;
         for (int t = 0; t < T; t++)
             if (T > 1) pthread_join(th[t], NULL);
+        KMO_TICK(t_exp);
         if (cfg->inv_mask && res->viol_inv < 0) { /* violating successors outside the constraint: depth nlevels+1 */
             uint64_t cnt[4] = {0, 0, 0, 0};
             int best[4] = {-1, -1, -1, -1};
@@ -1088,6 +1180,9 @@ void *kmo_run(const kmo_config *cfg, kmo_result *res) {
     free(th);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     res->seconds = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    if (getenv("KMO_TIMING"))
+        fprintf(stderr, "kmc_oracle: %d threads, %.2f s: invariants %.2f, table growth %.2f, expansion %.2f\n", T,
+                res->seconds, t_inv, t_grow, t_exp);
     return e;
 }
 
@@ -1135,7 +1230,7 @@ void kmo_free(void *h) {
     Engine *e = h;
     if (!e) return;
     for (uint32_t c = 0; c < MAX_CHUNKS; c++) free(e->chunks[c]);
-    free((void *)e->table);
+    if (e->table) munmap((void *)e->table, e->cap * sizeof(uint64_t));
     free(e);
 }
 

@@ -75,6 +75,61 @@ const Entry TABLE[] = {
     FRL(2, 4, 2), FRL(3, 2, 2),
 };
 
+// A literal, loop-per-slot evaluation of the Kafka invariants on the packed fields, straight from the
+// definitions (KafkaReplication.tla:101-107, :320-326, :334-340, :345; FiniteReplicatedLog.tla:90-95) with the
+// run-time layout: the differential partner of KmcKafka::violated_pre on ARBITRARY bit patterns (TypeOk never
+// fails on a reachable state, so reachable states alone cannot tell a TypeOk that is always true from a right one).
+// Returns -1 for WeakIsr / StrongIsr when an endOffset or hw lies beyond LogSize (offsets past the log are not
+// representable, the comparison is undefined there).
+int kafka_reference(int model, int N, int L, int R, int E, const u64* w, unsigned mask) {
+    const KmcLayout y = kmc_make_layout(model, N, L, R, E, 0);
+    auto rec = [&](int r, int o) { return (unsigned)kmc_getbits(w, y.log_off[r] + o * y.BR, y.BR); };
+    auto end = [&](int r) { return (unsigned)kmc_getbits(w, y.end_off[r], y.BO); };
+    auto hw = [&](int r) { return (unsigned)kmc_getbits(w, y.hw_off[r], y.BO); };
+    auto ldr1 = [&](int r) { return (unsigned)kmc_getbits(w, y.ldr_off[r], y.BL); };
+    unsigned bad = 0;
+    if (mask & 1u) {
+        bool ok = kmc_getbits(w, y.nextep_off, y.BE) <= (unsigned)E + 1 && kmc_getbits(w, y.nextrec_off, y.BNR) <= (unsigned)R &&
+                  kmc_getbits(w, y.qep_off, y.BE) <= (unsigned)E + 1 && kmc_getbits(w, y.qldr_off, y.BL) <= (unsigned)N;
+        for (int r = 0; r < N; ++r) {
+            ok = ok && end(r) <= (unsigned)L && hw(r) <= (unsigned)L && kmc_getbits(w, y.ep_off[r], y.BE) <= (unsigned)E + 1 &&
+                 ldr1(r) <= (unsigned)N;
+            for (int o = 0; o < L; ++o) {
+                const unsigned c = rec(r, o), id1 = c >> y.BEr, ep = c & ((1u << y.BEr) - 1);
+                if ((unsigned)o < end(r)) ok = ok && id1 >= 1 && id1 <= (unsigned)R && ep <= (unsigned)E;
+                else ok = ok && c == 0;
+            }
+        }
+        const unsigned nextep = (unsigned)kmc_getbits(w, y.nextep_off, y.BE);
+        for (int e = 0; e <= E; ++e)
+            if ((unsigned)e < nextep) ok = ok && kmc_getbits(w, y.reqldr_off[e], y.BL) <= (unsigned)N;
+        if (!ok) bad |= 1u;
+    }
+    if (mask & 6u) {
+        for (int r = 0; r < N; ++r)
+            if (end(r) > (unsigned)L || hw(r) > (unsigned)L) return -1;
+        const unsigned qisr = (unsigned)kmc_getbits(w, y.qisr_off, y.BI);
+        bool weak = true, strong = true;
+        for (int r1 = 0; r1 < N; ++r1) {
+            if (ldr1(r1) != (unsigned)r1 + 1) continue;  // ReplicaPresumesLeadership
+            const unsigned isr = (unsigned)kmc_getbits(w, y.isr_off[r1], y.BI);
+            for (int r2 = 0; r2 < N; ++r2)
+                for (unsigned o = 0; o < hw(r1); ++o) {
+                    const bool same = o < end(r1) && o < end(r2) && rec(r1, (int)o) == rec(r2, (int)o);
+                    if (isr >> r2 & 1u) weak = weak && same;
+                    if (qisr >> r2 & 1u) strong = strong && same;
+                }
+        }
+        if ((mask & 2u) && !weak) bad |= 2u;
+        if ((mask & 4u) && !strong) bad |= 4u;
+    }
+    if (mask & 8u) {
+        const unsigned l1 = (unsigned)kmc_getbits(w, y.qldr_off, y.BL), qisr = (unsigned)kmc_getbits(w, y.qisr_off, y.BI);
+        if (!(l1 != 0 && (qisr >> (l1 - 1) & 1u))) bad |= 8u;
+    }
+    return (int)bad;
+}
+
 const Entry* find(int model, int N, int L, int R, int E, int K) {
     for (const Entry& e : TABLE)
         if (e.model == model && e.N == N && e.L == L && e.R == R && e.E == E && e.K == K) return &e;
@@ -106,6 +161,11 @@ int emu_violated(int model, int N, int L, int R, int E, int K, const u64* state,
     const Entry* e = find(model, N, L, R, E, K);
     return e ? (int)e->violated(state, mask) : -1;
 }
+// the literal reference above (Kafka family only)
+int emu_kafka_reference(int model, int N, int L, int R, int E, const u64* state, unsigned mask) {
+    return kafka_reference(model, N, L, R, E, state, mask);
+}
+int emu_state_bits(int model, int N, int L, int R, int E, int K) { return kmc_make_layout(model, N, L, R, E, K).bits; }
 int emu_init(int model, int N, int L, int R, int E, int K, u64* words) {
     const Entry* e = find(model, N, L, R, E, K);
     if (!e) return -1;

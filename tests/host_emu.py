@@ -29,6 +29,8 @@ def lib():
         l.emu_successors.argtypes = six + [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
         l.emu_violated.argtypes = six + [C.POINTER(C.c_uint64), C.c_uint]
         l.emu_init.argtypes = six + [C.POINTER(C.c_uint64)]
+        l.emu_kafka_reference.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_uint64), C.c_uint]
+        l.emu_state_bits.argtypes = six
         l.emu_in_model.argtypes = six + [C.POINTER(C.c_uint64)]
         _lib = l
     return _lib
@@ -68,3 +70,13 @@ def init(cfg6):
 def in_model(cfg6, words):
     W = lib().emu_words(*cfg6)
     return bool(lib().emu_in_model(*cfg6, (C.c_uint64 * W)(*words)))
+
+
+def kafka_reference(cfg6, words, mask):
+    """Literal loop-per-slot evaluation of the Kafka invariants on packed words (tests/host_emu.cpp); -1 = undefined."""
+    W = lib().emu_words(*cfg6)
+    return lib().emu_kafka_reference(*cfg6[:5], (C.c_uint64 * W)(*words), mask)
+
+
+def state_bits(cfg6):
+    return lib().emu_state_bits(*cfg6)

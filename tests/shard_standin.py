@@ -40,6 +40,8 @@ class OracleShardEngine:
         self.seen, self.frontier, self.next = {}, [], []             # seen: state -> predecessor fingerprint
         self.level = 0
         self._viol_fp = [0, 0, 0, 0]
+        self._oviol_fp = [0, 0, 0, 0]
+        self.retired = []                                             # the level the last finish() retired
         self.reset_level()
 
     def reset_level(self):
@@ -88,6 +90,7 @@ class OracleShardEngine:
     def expand(self):
         self.reset_level()
         viol = [0, 0, 0, 0]
+        oviol = [0, 0, 0, 0]
         buckets = [[] for _ in range(self.world)]
         for s in self.frontier:
             fps = self.fp(s)
@@ -105,10 +108,14 @@ class OracleShardEngine:
                     # outside the state constraint: invariant-checked, neither kept nor shipped
                     for name in self.cfg.invariants:
                         if not kmo.check_invariant(self.kcfg, INV_INDEX[name], t):
-                            self.st[25 + INV_INDEX[name]] += 1
+                            k = INV_INDEX[name]
+                            self.st[25 + k] += 1
+                            oviol[k] = self.fp(t) if oviol[k] == 0 else min(oviol[k], self.fp(t))
                     continue
                 buckets[self.owner(self.fp(t))].append((t, fps))
         self._viol_next = viol
+        self._oviol_next = oviol
+        self._expanding = list(self.frontier)
         if not self.hip_shaped:
             return [self._enc(b) for b in buckets]
         subs = nat.KMC_SEND_SUBS
@@ -122,7 +129,33 @@ class OracleShardEngine:
 
     def finish(self):
         self._viol_fp = self._viol_next
+        self._oviol_fp = self._oviol_next
+        self.retired = self._expanding
         return self._close_level()
+
+    def check_frontier(self):
+        """Invariant-only pass over the current, unexpanded frontier (the last level under max_levels)."""
+        st = np.zeros(N_STATS, dtype=np.int64)
+        viol = [0, 0, 0, 0]
+        for s in self.frontier:
+            for name in self.cfg.invariants:
+                if not kmo.check_invariant(self.kcfg, INV_INDEX[name], s):
+                    k = INV_INDEX[name]
+                    st[17 + k] += 1
+                    viol[k] = self.fp(s) if viol[k] == 0 else min(viol[k], self.fp(s))
+        self._viol_fp = viol
+        return st
+
+    def outside_violation_fp(self, k):
+        return self._oviol_fp[k]
+
+    def find_outside(self, fp):
+        best = None
+        for s in self.retired:
+            for _a, t in kmo.successors(self.kcfg, s, self.sb):
+                if self.fp(t) == fp and (best is None or self.fp(s) < best[1]):
+                    best = (self._pack(t), self.fp(s))
+        return best
 
     def _close_level(self):
         self.frontier, self.next = self.next, []

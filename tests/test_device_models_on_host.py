@@ -75,3 +75,46 @@ def test_device_model_matches_oracle_along_random_walks(cfg6):
                 if not nxt:
                     break
                 s = rng.choice(nxt)
+
+
+@pytest.mark.parametrize("cfg6", [c for c in CONFIGS if 2 <= c[0] <= 6], ids=_ids)
+def test_invariants_on_arbitrary_bit_patterns(cfg6):
+    """TypeOk holds in every reachable state, so the checks above cannot tell a right TypeOk from `return true`.
+    Here the device's integer-domain invariants (whole-log folds, membership map) meet a literal loop-per-slot
+    evaluation of the definitions on random packed words and on reachable states with a few flipped bits."""
+    import random
+    model, N, L, R, E, K = cfg6
+    name = MODEL_NAMES[model]
+    W, bits = host_emu.lib().emu_words(*cfg6), host_emu.state_bits(cfg6)
+    rng = random.Random(99 + model * 1000 + N * 100 + L * 10 + E)
+    ocfg = kmo.make_config(name, N=N, L=L, R=max(R, 1), E=E, invariants=(), max_states=3000, threads=1)
+    o = kmo.Run(ocfg)
+    seen_bad = {1: 0, 2: 0, 4: 0, 8: 0}
+    seen_ok = dict(seen_bad)
+    with ModelChecker(CheckerConfig(model=name, device=-1, n_replicas=N, log_size=L, max_records=max(R, 1),
+                                    max_leader_epoch=E)) as mc:
+        reach = [mc.pack(o.state(i)) for i in range(0, min(o.distinct, 3000), 7)]
+
+    def words_of(x):
+        return [(x >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(W)]
+
+    cases = []
+    for _ in range(1500):
+        cases.append(rng.getrandbits(bits))
+    for w in reach:
+        x = sum(v << (64 * k) for k, v in enumerate(w))
+        for _ in range(4):
+            y = x
+            for _f in range(rng.randint(1, 3)):
+                y ^= 1 << rng.randrange(bits)
+            cases.append(y)
+    for x in cases:
+        w = words_of(x)
+        for m in (1, 2, 4, 8):
+            want = host_emu.kafka_reference(cfg6, w, m)
+            if want < 0:
+                continue
+            got = host_emu.violated(cfg6, w, m)
+            assert got == want, f"invariant mask {m} on words {[hex(v) for v in w]}: device {got}, reference {want}"
+            (seen_bad if want else seen_ok)[m] += 1
+    assert all(seen_bad[m] > 0 and seen_ok[m] > 0 for m in (1, 2, 4, 8)), (seen_bad, seen_ok)

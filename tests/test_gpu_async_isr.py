@@ -164,3 +164,25 @@ def test_both_command_lines(capsys):
     assert tlc.main([os.path.join(ROOT, "models", "AsyncIsr.tla")] + small) == 2
     capsys.readouterr()
     assert subprocess.run([exe, os.path.join(ROOT, "models", "AsyncIsr.tla")] + small, capture_output=True).returncode == 2
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_sharded_trace_of_a_witness_outside_the_constraint(P):
+    """P shards on one GPU, exchange under the C ABI: the violating successor outside the constraint is in no
+    shard's table; the shard that generated it recovers it with kmc_step_find_outside from the level it has just
+    expanded, the rest of the chain comes from the owners' predecessor tables."""
+    N, M, V = 3, 2, 2
+    ocfg = kmo.make_config("AsyncIsr", N=N, L=M, E=V, invariants=OUT)
+    o = kmo.Run(ocfg)
+    r = check_loopback(cfg_of(N, M, V, inv=OUT, keep_trace=True, table_capacity=1 << 20, frontier_capacity=1 << 18,
+                              send_capacity=1 << 18), P)
+    assert (r.verdict, r.violated_invariant, r.violation_depth) == ("invariant", "LeaderOffsetInRange", o.viol_depth)
+    assert r.violation_count == o.viol_count and r.levels == o.levels and r.generated == o.generated
+    trace = r.trace
+    assert len(trace) == o.viol_depth and trace[0] == (None, o.state(0))
+    with ModelChecker(cfg_of(N, M, V, device=-1)) as mc:
+        names = mc.action_names()
+    for (_, prev), (act, cur) in zip(trace, trace[1:]):
+        assert (names.index(act), cur) in kmo.successors(ocfg, prev, o.sb)
+    w = trace[-1][1]
+    assert trace[-1][0] == "LeaderWrite" and w[6] == M + 1 and not kmo.check_invariant(ocfg, 2, w)

@@ -118,3 +118,91 @@ def test_wider_replica_sets(model, N, L, R, E):
     assert list(res.action_generated.values()) == o.action_generated[:len(res.action_generated)]
     if o.viol_inv:
         assert res.violation_depth == o.viol_depth and res.violation_count == o.viol_count
+
+
+VIOLATING = ("KafkaTruncateToHighWatermark", "Kip101", "Kip279", "Kip320FirstTry")
+
+
+@pytest.mark.parametrize("model,N,L,R,E", [(m, 3, 2, 2, 2) for m in VIOLATING] + [
+    ("KafkaTruncateToHighWatermark", 2, 3, 3, 2), ("KafkaTruncateToHighWatermark", 3, 3, 2, 1), ("Kip101", 2, 3, 3, 2),
+    ("Kip101", 3, 3, 2, 1), ("Kip279", 3, 3, 2, 1), ("Kip320FirstTry", 3, 2, 3, 2)])   # constants the oracle finds a violation for
+def test_continue_on_violation_matches_oracle(model, N, L, R, E):
+    """TLC -continue on the four models the reference describes as losing committed data
+    (KafkaTruncateToHighWatermark.tla:23-27, Kip101.tla / Kip279.tla:20-23, Kip320FirstTry.tla:27-33): the search
+    does not stop at the violation, so it exhausts the model — every count of the complete run and the depth /
+    per-invariant counts of the FIRST violating level against Oracle-B with stop_on_violation = 0."""
+    inv = ("TypeOk", "WeakIsr", "StrongIsr")
+    o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv, stop_on_violation=False, threads=8))
+    plain = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=("TypeOk",), threads=8))
+    res, _ = gpu_run(model, invariants=inv, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E,
+                     continue_on_violation=True, table_capacity=1 << 24, frontier_capacity=1 << 21)
+    assert o.verdict == "invariant", "these constants must reach a violation"
+    assert (res.verdict, res.violated_invariant) == ("invariant", o.viol_inv)
+    assert (res.violation_depth, res.violation_count) == (o.viol_depth, o.viol_count)
+    # ... and the numbers of the complete state graph, as if no invariant had been given
+    assert (res.distinct, res.generated, res.depth, res.levels) == (o.distinct, o.generated, o.depth, o.levels)
+    assert (res.distinct, res.generated, res.levels) == (plain.distinct, plain.generated, plain.levels)
+    assert list(res.action_generated.values()) == o.action_generated[:len(res.action_generated)]
+    assert res.deadlock_states == o.deadlock_states and res.queue_left == 0
+
+
+@pytest.mark.parametrize("model,N,L,R,E", [("Kip320", 2, 2, 2, 1), ("Kip279", 3, 2, 2, 1), ("Kip320FirstTry", 2, 3, 3, 2),
+                                           ("KafkaTruncateToHighWatermark", 3, 1, 1, 2)])
+def test_deadlock_checking_matches_oracle(model, N, L, R, E):
+    """CHECK_DEADLOCK TRUE (TLC's default): the bounded models have terminal states; verdict, the depth of the first
+    deadlocked level and every count up to it against Oracle-B; the witness really has no successor."""
+    ocfg = kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=("TypeOk",), check_deadlock=True, threads=4)
+    o = kmo.Run(ocfg)
+    cfg = CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, invariants=("TypeOk",),
+                        check_deadlock=True, table_capacity=1 << 22, frontier_capacity=1 << 20)
+    with ModelChecker(cfg) as mc:
+        res = mc.run()
+        witness = mc.unpack(mc.witness()) if res.verdict == "deadlock" else None
+    assert o.verdict == "deadlock" and res.verdict == "deadlock"
+    assert res.levels == o.levels and res.violation_depth == len(o.levels)
+    assert res.generated == o.generated and res.deadlock_states == o.deadlock_states
+    assert kmo.successors(ocfg, witness, o.sb) == []
+
+
+@pytest.mark.parametrize("name,model,N,L,R,E,levels", [
+    ("config 4's larger twin: Kip279, 5 brokers, MaxLeaderEpoch 2", "Kip279", 5, 2, 2, 2, 10),
+    ("config 5: Kip320, 7 brokers, LogSize 8", "Kip320", 7, 8, 8, 3, 7)])
+def test_baseline_multi_gpu_configs_match_oracle_prefix(name, model, N, L, R, E, levels):
+    """BASELINE.json config 5 at its own constants (models/Kip320_7brokers.cfg) and config 4 with MaxLeaderEpoch 2 (the
+    exhaustible binding, MaxLeaderEpoch 1, has its golden-fixture test in test_gpu_sharded_and_traces.py).
+    Neither is exhaustible here (6.5e9 states after 22 levels / 8.8e8 after 11), so the pin is the oracle's BFS prefix:
+    level sizes, generated (total and per action) and the exact state sets of the first levels (this
+    check lived in tools/run_ladder.py only)."""
+    inv = ("TypeOk",)
+    o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv, threads=8, max_states=1_500_000))
+    k = min(levels, len(o.levels) - 1)      # the oracle stops after the level that crosses max_states: compare complete levels
+    sets = []
+    cfg = CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, invariants=inv,
+                        max_levels=k, table_capacity=1 << 26, frontier_capacity=1 << 23)
+    with ModelChecker(cfg) as mc:
+        res = mc.run(progress=lambda info: sets.append({mc.unpack(r) for r in mc.frontier_states()}
+                                                       if info["new_states"] <= 50_000 else None))
+    assert res.verdict == "level_limit" and res.levels == o.levels[:k]
+    for d, s in enumerate(sets):
+        if s is not None:
+            assert s == o.level_states(d), f"{name}: level {d} state sets differ"
+    # generated up to (not including) the expansion of the last kept level: compare through a second oracle run
+    o2 = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv, threads=8,
+                                 max_states=sum(o.levels[:k - 1]) + 1))
+    if len(o2.levels) == k:   # it stopped right after producing level k
+        assert res.generated == o2.generated
+        assert list(res.action_generated.values()) == o2.action_generated[:len(res.action_generated)]
+
+
+def test_verify_mode_regenerates_every_level_with_a_second_build(monkeypatch):
+    """KMC_VERIFY=1 (CLI: -verify): a second code object of the same source (-O1, a quarter of the occupancy target)
+    re-generates every level's successors; the per-action, deadlock and violation counts of the two builds must agree.
+    The self-check for constants beyond any oracle, after round 1 met a build that lost successors under register
+    spilling.  Here both builds are right, so the run must simply equal the oracle's."""
+    monkeypatch.setenv("KMC_VERIFY", "1")
+    for model, N, L, R, E in (("Kip320", 3, 2, 2, 1), ("Kip279", 5, 1, 1, 1)):
+        inv = ("TypeOk", "WeakIsr", "StrongIsr")
+        o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv, threads=8))
+        res, _ = gpu_run(model, invariants=inv, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E,
+                         table_capacity=1 << 24, frontier_capacity=1 << 21)
+        assert (res.verdict, res.distinct, res.generated, res.levels) == (o.verdict, o.distinct, o.generated, o.levels)

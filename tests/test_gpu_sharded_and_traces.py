@@ -16,11 +16,13 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 INV_INDEX = {"TypeOk": 0, "WeakIsr": 1, "StrongIsr": 2, "LeaderInIsr": 3}
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "torch"])   # under the C ABI (device-to-device runs + one k_insert) / torch slices
 @pytest.mark.parametrize("P", [2, 3, 4])
 @pytest.mark.parametrize("model,N,L,R,E,inv", [("Kip320", 3, 2, 2, 1, ("TypeOk", "WeakIsr", "StrongIsr")),
                                                ("Kip279", 3, 2, 2, 2, ("TypeOk", "StrongIsr")),
                                                ("Kip320FirstTry", 2, 3, 3, 2, ("TypeOk",))])
-def test_loopback_shards_match_oracle(P, model, N, L, R, E, inv):
+def test_loopback_shards_match_oracle(P, model, N, L, R, E, inv, exchange, monkeypatch):
+    monkeypatch.setenv("KMC_EXCHANGE", exchange)
     o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv))
     cfg = CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, invariants=inv,
                         table_capacity=1 << 20, frontier_capacity=1 << 18, send_capacity=1 << 18)
@@ -150,10 +152,13 @@ def test_cli_prints_tlc_shaped_output(capsys):
     assert "1 states generated, 1 distinct states found" in out
 
 
-def test_rccl_single_rank_process_group_matches_oracle():
-    """The real torch.distributed/RCCL exchange (world_size 1 is all one GPU allows): exercises
-    DistExchange, the stream hand-over between RCCL and libkmc, and kmc_step_* at a size where
-    levels span many send-buffer tiles."""
+@pytest.mark.parametrize("exchange", ["rccl", "torch"])
+def test_rccl_single_rank_process_group_matches_oracle(exchange, monkeypatch):
+    """A real RCCL communicator (world_size 1 is all one GPU allows).  "rccl": the exchange under the C ABI —
+    kmc_comm_init on a unique id that travelled through the process group, kmc_comm_selftest (an all-gather and a
+    grouped send/receive to itself on the engine's stream, verified: with one rank the search itself has no remote
+    traffic), then the level loop through kmc_step_exchange_counts / _payload.  "torch": DistExchange."""
+    monkeypatch.setenv("KMC_EXCHANGE", exchange)
     import torch
     import torch.distributed as dist
     from kafka_specification_amd.sharded import check_distributed
@@ -171,6 +176,15 @@ def test_rccl_single_rank_process_group_matches_oracle():
         r = check_distributed(cfg)
         assert (r.verdict, r.distinct, r.generated, r.depth) == (o.verdict, o.distinct, o.generated, o.depth)
         assert r.levels == o.levels
+        if exchange == "rccl":
+            from kafka_specification_amd.sharded import HipShardEngine, RcclExchange
+            small = CheckerConfig(model="Kip320", n_replicas=2, log_size=2, max_records=2, max_leader_epoch=1,
+                                  table_capacity=1 << 16, frontier_capacity=1 << 12)
+            eng = HipShardEngine(small, 0, 1, 0)
+            try:
+                RcclExchange(eng, torch.device("cuda", 0)).selftest()
+            finally:
+                eng.close()
     finally:
         if created:
             dist.destroy_process_group()
@@ -244,6 +258,38 @@ def test_checkpoint_and_recover(tmp_path):
     with ModelChecker(CheckerConfig(**{**base, "table_capacity": 1 << 21})) as mc:
         with pytest.raises(KmcError):
             mc.load_checkpoint(path)
+    # the file is not trusted: a segment size beyond the capacity, a level count that would size a huge
+    # vector, or a truncated body are refused before anything is copied to the device
+    import struct
+    raw = bytearray(open(path, "rb").read())
+    hdr = 8 + 112 + 8 * 8                       # magic + kmc_config + 8 header words
+    res_bytes = len(raw)                        # (located below through the known tail layout)
+    nlev = struct.unpack_from("<Q", raw, 8 + 112 + 5 * 8)[0]
+    assert nlev == 11
+    from kafka_specification_amd import _native as nat
+    import ctypes as C
+    seg_off = hdr + C.sizeof(nat.KmcResult) + 8 * nlev
+    bad = bytearray(raw)
+    struct.pack_into("<Q", bad, seg_off, 1 << 40)          # seg_n[0]: far beyond seg_cap
+    (tmp_path / "bad_seg.ckpt").write_bytes(bad)
+    bad = bytearray(raw)
+    struct.pack_into("<Q", bad, 8 + 112 + 5 * 8, 1 << 50)  # n_levels
+    (tmp_path / "bad_levels.ckpt").write_bytes(bad)
+    (tmp_path / "short.ckpt").write_bytes(raw[:len(raw) // 2])
+    for name in ("bad_seg.ckpt", "bad_levels.ckpt", "short.ckpt"):
+        with ModelChecker(CheckerConfig(**base)) as mc:
+            with pytest.raises(KmcError):
+                mc.load_checkpoint(str(tmp_path / name))
+    # ... and a checkpoint is only taken at a level boundary: after a stop inside a level the table already holds the
+    # rolled-back level's fingerprints, a resume from there would silently lose states
+    with ModelChecker(CheckerConfig(**{**base, "table_capacity": 4096})) as mc:
+        assert mc.run().verdict == "table_full"
+        with pytest.raises(KmcError):
+            mc.save_checkpoint(str(tmp_path / "nope.ckpt"))
+    with ModelChecker(CheckerConfig(**base)) as mc:
+        assert mc.run().verdict == "ok"
+        with pytest.raises(KmcError):
+            mc.save_checkpoint(str(tmp_path / "nope.ckpt"))
 
 
 def test_level_limit_still_checks_the_last_frontier():
@@ -307,3 +353,53 @@ def test_counterexample_trace_across_shards(P, model):
         assert (names.index(act), cur) in kmo.successors(ocfg, prev, o.sb)
         assert all(kmo.check_invariant(ocfg, INV_INDEX[i], prev) for i in inv)
     assert not kmo.check_invariant(ocfg, INV_INDEX[o.viol_inv], trace[-1][1])
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_sharded_level_limit_checks_the_last_frontier(P):
+    """Sharded and single-GPU runs must agree at max_levels: the unexpanded last level gets its invariant pass
+    (kmc_step_check_frontier), so a violation that first appears there is reported — with its trace — instead of
+    "level_limit" (VERDICT r1 2c)."""
+    model, inv = "KafkaTruncateToHighWatermark", ("TypeOk", "StrongIsr")
+    ocfg = kmo.make_config(model, N=3, L=2, R=2, E=1, invariants=inv)
+    o = kmo.Run(ocfg)
+    assert o.verdict == "invariant"
+    base = dict(model=model, n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1, invariants=inv, keep_trace=True,
+                table_capacity=1 << 20, frontier_capacity=1 << 18, send_capacity=1 << 18)
+    with ModelChecker(CheckerConfig(**base, max_levels=o.viol_depth)) as mc:
+        one = mc.run()
+    r = check_loopback(CheckerConfig(**base, max_levels=o.viol_depth), P)
+    assert (r.verdict, r.violated_invariant, r.violation_depth, r.violation_count) == \
+        (one.verdict, one.violated_invariant, one.violation_depth, one.violation_count) == \
+        ("invariant", o.viol_inv, o.viol_depth, o.viol_count)
+    assert r.levels == one.levels == o.levels[:o.viol_depth]
+    assert len(r.trace) == o.viol_depth and not kmo.check_invariant(ocfg, INV_INDEX[o.viol_inv], r.trace[-1][1])
+    r = check_loopback(CheckerConfig(**base, max_levels=o.viol_depth - 1), P)
+    assert (r.verdict, r.violated_invariant, r.levels) == ("level_limit", None, o.levels[:o.viol_depth - 1])
+
+
+def test_baseline_config4_kip279_five_brokers_exhaustive_and_four_shards():
+    """BASELINE.json config 4 — "Kip279.tla leader-epoch truncation, 5 brokers, 4 x MI355X frontier-sharded" — at the
+    constants of models/Kip279_5brokers.cfg (LogSize 2, MaxRecords 2, MaxLeaderEpoch 1: the largest of the ladder
+    that can be exhausted).  One GPU and four fingerprint-sharded logical GPUs (exchange under the C ABI; one gpurun box
+    has one device) both reproduce the golden fixture of the C oracle, level by level: 112,549,196 distinct states.
+    With StrongIsr in the invariants the search stops at the violation Kip279.tla:20-23 describes, depth 14."""
+    g = json.load(open(os.path.join(GOLDEN, "oracle_kip279_5_2_2_1.json")))
+    base = dict(model="Kip279", n_replicas=g["N"], log_size=g["L"], max_records=g["R"], max_leader_epoch=g["E"],
+                invariants=("TypeOk",))
+    with ModelChecker(CheckerConfig(**base, table_capacity=1 << 29, frontier_capacity=1 << 25)) as mc:
+        r = mc.run()
+    assert r.verdict == "ok" and r.queue_left == 0
+    assert (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
+    assert list(r.action_generated.values()) == g["action_generated"][:9]   # Kip279's coinciding disjuncts counted twice
+    assert r.deadlock_states == g["deadlock_states"]
+    s = check_loopback(CheckerConfig(**base, table_capacity=1 << 27, frontier_capacity=1 << 23, send_capacity=1 << 21), 4)
+    assert (s.verdict, s.distinct, s.generated, s.depth, s.levels) == ("ok", g["distinct"], g["generated"], g["depth"], g["levels"])
+    assert list(s.action_generated.values()) == g["action_generated"][:9]
+    inv = ("TypeOk", "WeakIsr", "StrongIsr")
+    o = kmo.Run(kmo.make_config("Kip279", N=g["N"], L=g["L"], R=g["R"], E=g["E"], invariants=inv, threads=8))
+    with ModelChecker(CheckerConfig(**{**base, "invariants": inv}, table_capacity=1 << 25, frontier_capacity=1 << 22)) as mc:
+        v = mc.run()
+    assert (v.verdict, v.violated_invariant, v.violation_depth, v.violation_count) == \
+        ("invariant", "StrongIsr", 14, o.viol_count) == (o.verdict, o.viol_inv, o.viol_depth, o.viol_count)
+    assert v.levels == o.levels

@@ -154,3 +154,49 @@ def test_counterexample_trace_across_two_ranks(model):
         assert (names.index(act), cur) in kmo.successors(ocfg, prev, o.sb)
         assert all(kmo.check_invariant(ocfg, INV_INDEX[i], prev) for i in inv)
     assert not kmo.check_invariant(ocfg, INV_INDEX[o.viol_inv], trace[-1][1])
+
+
+def test_level_limit_checks_the_invariants_of_the_last_frontier():
+    """Every state is checked when it is EXPANDED; under max_levels the last level is not expanded, so it gets an
+    invariant-only pass (kmc_step_check_frontier) — like kmc_run on one GPU.  With max_levels = the depth of the
+    first violation the verdict must be that violation, not "level_limit" (ADVICE r1 / VERDICT r1 2c)."""
+    model, inv = "KafkaTruncateToHighWatermark", ("TypeOk", "StrongIsr")
+    o = kmo.Run(kmo.make_config(model, N=3, L=2, R=2, E=1, invariants=inv))
+    assert o.verdict == "invariant" and o.viol_depth > 2
+    kw = dict(model=model, n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1, invariants=inv, keep_trace=True)
+    out = _run_world(dict(kw, max_levels=o.viol_depth))
+    r = out[0]
+    assert out[1]["verdict"] == r["verdict"] == "invariant"
+    assert (r["viol"], r["viol_depth"], r["viol_count"]) == (o.viol_inv, o.viol_depth, o.viol_count)
+    assert r["levels"] == o.levels[:o.viol_depth]
+    assert len(r["trace"]) == o.viol_depth and out[1]["trace"] == r["trace"]
+    ocfg = kmo.make_config(model, N=3, L=2, R=2, E=1, invariants=inv)
+    assert not kmo.check_invariant(ocfg, INV_INDEX[o.viol_inv], r["trace"][-1][1])
+    # one level earlier nothing is wrong yet: a plain level limit
+    r = _run_world(dict(kw, max_levels=o.viol_depth - 1))[0]
+    assert (r["verdict"], r["viol"], r["levels"]) == ("level_limit", None, o.levels[:o.viol_depth - 1])
+
+
+def test_trace_of_a_witness_outside_the_state_constraint_across_two_ranks():
+    """AsyncIsr: a successor outside the constraint that violates an invariant is in no shard's table.  The shard
+    that generated it recovers it (and a parent) from the level it has just expanded; the chain continues through
+    the owners' predecessor tables."""
+    inv = ("ValidHighWatermark", "LeaderOffsetInRange")
+    kw = dict(model="AsyncIsr", n_replicas=3, log_size=2, max_leader_epoch=2, invariants=inv, keep_trace=True)
+    ocfg = kmo.make_config("AsyncIsr", N=3, L=2, E=2, invariants=inv)
+    o = kmo.Run(ocfg)
+    assert o.verdict == "invariant" and o.viol_inv == "LeaderOffsetInRange"
+    out = _run_world(kw)
+    r = out[0]
+    assert out[1]["trace"] == r["trace"]
+    assert (r["verdict"], r["viol"], r["viol_depth"], r["viol_count"]) == ("invariant", o.viol_inv, o.viol_depth, o.viol_count)
+    assert r["levels"] == o.levels and r["generated"] == o.generated
+    trace = r["trace"]
+    assert len(trace) == o.viol_depth and trace[0] == (None, o.state(0))
+    names = _names(CheckerConfig(**kw))
+    for (_, prev), (act, cur) in zip(trace, trace[1:]):
+        assert (names.index(act), cur) in kmo.successors(ocfg, prev, o.sb)
+    w = trace[-1][1]
+    assert w[6] > 2                                          # offsets[Leader] > MaxOffset: outside the constraint
+    assert not kmo.check_invariant(ocfg, INV_INDEX["LeaderOffsetInRange"], w)
+    assert all(kmo.check_invariant(ocfg, INV_INDEX[i], s) for _a, s in trace[:-1] for i in inv)

@@ -3,7 +3,7 @@
 #   1. --kernel-trace --stats                  -> per-kernel durations
 #   2..n. --pmc <set> (one set per pass)       -> HBM bytes, L2 hit rate, SQ stall breakdown
 # Output: gpurun_out/prof_<tag>/...csv ; summarise with tools/summarize_profile.py
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
@@ -22,3 +22,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_A
 done
 grep -h '"metric"' "$OUT"/*.log | head -1 | cut -c1-400
 find "$OUT" -name "*.csv" | head -30
+python3 "$REPO/tools/summarize_profile.py" "$OUT" "$OUT/summary.json" "$OUT/pmc_summary.json" > /dev/null && echo summarised
+cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv" 2>/dev/null

@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
 """Summarise tools/profile.sh output (rocprofv3 CSVs) for the dominant kernel kmc_expand_*:
 kernel-trace stats + PMC counters summed over the run's launches.
-usage: tools/summarize_profile.py gpurun_out/prof_<tag> [out.json]"""
-import csv, glob, json, os, sys
+usage: tools/summarize_profile.py gpurun_out/prof_<tag> [out.json [pmc_summary.json]]
+The summaries carry the sha256 of the device sources they were measured on: bench.py quotes `roofline.traffic` only
+from a PMC summary that belongs to the code it is running."""
+import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 d = sys.argv[1]
 out = {}
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _f in ("kmc_layout.h", "kmc_device.h"):
+    _h.update(open(os.path.join(_root, "kafka_specification_amd", "csrc", _f), "rb").read())
+out["device_source_sha256"] = _h.hexdigest()
 # kernel trace
-rows = list(csv.DictReader(open(os.path.join(d, "trace", "trace_kernel_trace.csv"))))
+_tr = glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True)
+rows = list(csv.DictReader(open(_tr[0])))
 per = defaultdict(list)
 for r in rows:
     per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -20,7 +28,7 @@ ex = [r for r in rows if r["Kernel_Name"] == exp]
 out["dominant_launch_cfg"] = {k: ex[-1].get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in ex[-1]}
 # counters
 ctr = defaultdict(float)
-for f in sorted(glob.glob(os.path.join(d, "pmc*", "pmc_counter_collection.csv"))):
+for f in sorted(glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
         if r["Kernel_Name"] == exp:
             ctr[r["Counter_Name"]] += float(r["Counter_Value"])
@@ -54,3 +62,12 @@ js = json.dumps(out, indent=1)
 print(js)
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(js)
+
+if len(sys.argv) > 3 and "hbm_bytes_raw" in der:
+    pm = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the run's {n} k_expand launches "
+                    "(tools/profile.sh); raw counter bytes — see the calibration file beside this one for what the counters "
+                    "report per random 8-byte access",
+          "device_source_sha256": out["device_source_sha256"],
+          "fetch_bytes": der["fetch_bytes_raw"], "write_bytes": der["write_bytes_raw"], "hbm_bytes": der["hbm_bytes_raw"],
+          "launches": n, "hbm_bytes_per_launch": der["hbm_bytes_per_launch_raw"]}
+    open(sys.argv[3], "w").write(json.dumps(pm, indent=1) + "\n")
