@@ -1031,7 +1031,11 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
         static const int shadow = getenv("KMC_SHADOW") ? atoi(getenv("KMC_SHADOW")) : 0;
         static const int dry_mode = getenv("KMC_DRYRUN") ? atoi(getenv("KMC_DRYRUN")) : 0;
         static const int no_chain = getenv("KMC_NO_CHAIN") ? atoi(getenv("KMC_NO_CHAIN")) : 0;
-        if (!cb && !shadow && !dry_mode && !no_chain && !h->f_expand_verify) {
+        // Under -continue a violation does not end the search, so levels queued behind the violating one would run and
+        // overwrite its parent frontier before the host could fetch the witness (find_state / find_outside_witness):
+        // such runs go level by level until the first violation has been recorded, and chain from there on.
+        const bool witness_pending = h->cfg.continue_on_violation && h->cfg.invariant_mask && r.violated_invariant < 0;
+        if (!cb && !shadow && !dry_mode && !no_chain && !h->f_expand_verify && !witness_pending) {
             // ---- chained launches -------------------------------------------------------------------------
             // Nobody watches the levels go by, so up to KMC_CHAIN of them are queued back to back and the host
             // waits ONCE: a level launched behind another one takes its segment sizes from that level's control
@@ -1061,14 +1065,18 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             }
             HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl + 3, B * sizeof(KmcLevelCtl), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            bool done = false;
-            for (uint64_t i = 0; i < B && !done; ++i) {
-                const KmcLevelCtl c = h->ctl_host[i];
-                if (c.halt) break;   // the device ended the chain here; the host decides below whether the search goes on
+            // every launch of the batch is accounted (also the ones behind the end of the search, which find nothing to
+            // do and return in microseconds): the per-launch average then is what rocprofv3 --kernel-trace reports
+            for (uint64_t i = 0; i < B; ++i) {
                 float ms = 0;
                 HIP_TRY(hipEventElapsedTime(&ms, h->ev_chain[2 * i], h->ev_chain[2 * i + 1]));
                 r.seconds_expand += 1e-3 * ms;
                 r.expand_launches++;
+            }
+            bool done = false;
+            for (uint64_t i = 0; i < B && !done; ++i) {
+                const KmcLevelCtl c = h->ctl_host[i];
+                if (c.halt) break;   // the device ended the chain here; the host decides below whether the search goes on
                 for (int k = 0; k < 8; ++k) h->prof[k] += c.prof[k];
                 uint64_t new_seg[KMC_SEGS];
                 const uint64_t produced = produced_segments(h, c, new_seg);
