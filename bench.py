@@ -128,9 +128,10 @@ def cpu_baseline(c, budget_states, total_states):
     on a bounded prefix of the same workload: it stops after the BFS level that crosses
     `budget_states` distinct states."""
     import kmo
-    # every host core (round 1 capped this at 32: the level-start phases — invariants, re-hashing — ran on one
-    # thread and the rest could not help; they are sliced over the threads now)
-    threads = min(os.cpu_count() or 1, int(os.environ.get("KMC_CPU_THREADS", 256)))
+    # 32 threads is where the oracle peaks on the 256-thread GPU boxes (profiles/r02_oracle_scaling.txt: 17.6 M states/s
+    # at 32, 14.5 at 64, 6.3 at 256 — first-touch page faults and the shared table then dominate).  Round 1 measured
+    # 1.5 M/s at 32: its level-start phases ran on one thread and every new state took a shared fetch-add.
+    threads = min(os.cpu_count() or 1, int(os.environ.get("KMC_CPU_THREADS", 32)))
     cfg = kmo.make_config(c["model"], N=c["n_replicas"], L=c["log_size"], R=c["max_records"],
                           E=c["max_leader_epoch"], invariants=c["invariants"], threads=threads,
                           max_states=budget_states)
@@ -184,7 +185,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-states", type=int, default=0,
-                    help="cpu_baseline sample size in distinct states (default: 10 %% of the workload's reachable set; the "
+                    help="cpu_baseline sample size in distinct states (default: 25 %% of the workload's reachable set; the "
                          "oracle stops after the BFS level that crosses it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: a small configuration instead of the headline")
@@ -276,7 +277,7 @@ def main():
         "device": device_info(),
     }
     if not a.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(c, a.cpu_states or max(1_000_000, distinct // 10), distinct)
+        out["cpu_baseline"] = cpu_baseline(c, a.cpu_states or max(1_000_000, distinct // 4), distinct)
     print(json.dumps(out))
 
 
