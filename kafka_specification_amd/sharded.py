@@ -247,10 +247,17 @@ class RcclExchange:
         self.lib = nat.lib()
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         uid = (C.c_uint8 * nat.KMC_COMM_ID_BYTES)()
+        box = [None]
         if self.rank == 0:
-            nat.check(self.lib.kmc_comm_unique_id(uid))
-        box = [bytes(uid)]
+            # a failure here (librccl cannot be loaded) must still reach the other ranks' broadcast, or they wait forever
+            try:
+                nat.check(self.lib.kmc_comm_unique_id(uid))
+                box = [bytes(uid)]
+            except nat.KmcError as e:
+                box = [str(e)]
         dist.broadcast_object_list(box, src=0)
+        if not isinstance(box[0], bytes):
+            raise nat.KmcError(2, f"rank 0 could not create an RCCL unique id: {box[0]}")
         uid = (C.c_uint8 * nat.KMC_COMM_ID_BYTES)(*box[0])
         nat.check(self.lib.kmc_comm_init(engine.mc.handle, uid))
 
@@ -592,13 +599,42 @@ def check_loopback(cfg: CheckerConfig, n_shards: int, device: int = 0, progress=
             e.close()
 
 
-def make_exchange(eng, device):
-    """The per-level exchange of a one-shard-per-rank job.  A native HipShardEngine on a GPU gets the exchange
-    under the C ABI (RcclExchange); KMC_EXCHANGE=torch selects torch.distributed's all-gather + all-to-all
-    instead (also what a stand-in engine on gloo gets)."""
-    if getattr(eng, "native", False) and device.type == "cuda" and os.environ.get("KMC_EXCHANGE", "rccl") != "torch":
-        return RcclExchange(eng, device)
-    return DistExchange(device, eng.record_words)
+def make_engine_and_exchange(cfg: CheckerConfig, rank: int, world: int, local: int, device):
+    """The shard engine and per-level exchange of a one-shard-per-rank job.
+
+    On GPUs the product is a native HipShardEngine with the exchange under the C ABI (RcclExchange).  Before it is
+    used, every rank runs kmc_comm_selftest on the fresh communicator — an all-gather and a grouped send/receive ring
+    across ALL ranks on the engine's stream, verified — and the ranks agree (one small all-reduce) on whether it
+    worked everywhere.  If any rank could not bring it up (librccl not loadable, a failed RCCL call, a wrong
+    pattern), all of them fall back TOGETHER to the torch.distributed exchange (DistExchange, still RCCL, still the
+    GPU — there is no CPU path) and say so on stderr; a rank-local decision would desynchronise the collectives.
+    KMC_EXCHANGE=torch selects that exchange from the start; a stand-in engine on gloo always gets it."""
+    import sys
+    factory = _engine_factory()
+    want_native = device.type == "cuda" and factory is HipShardEngine and os.environ.get("KMC_EXCHANGE", "rccl") != "torch"
+    if not want_native:
+        eng = factory(cfg, rank, world, local)
+        return eng, DistExchange(device, eng.record_words)
+    import torch
+    import torch.distributed as dist
+    eng, ex, err = None, None, ""
+    try:
+        eng = HipShardEngine(cfg, rank, world, local, native=True)
+        ex = RcclExchange(eng, device)
+        ex.selftest()
+    except Exception as e:   # noqa: BLE001 — any failure here must reach the agreement below, not kill one rank
+        err = f"{type(e).__name__}: {e}"
+    flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return eng, ex
+    if rank == 0 or err:
+        print(f"[kmc] rank {rank}: the exchange under the C ABI is not usable on every rank"
+              f"{' (' + err + ')' if err else ''}; all ranks fall back to the torch.distributed exchange", file=sys.stderr)
+    if eng is not None:
+        eng.close()
+    eng = HipShardEngine(cfg, rank, world, local, native=False)
+    return eng, DistExchange(device, eng.record_words)
 
 
 def check_distributed(cfg: CheckerConfig, progress=None) -> CheckResult:
@@ -607,10 +643,10 @@ def check_distributed(cfg: CheckerConfig, progress=None) -> CheckResult:
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
     local = int(os.environ.get("LOCAL_RANK", rank))
-    eng = _engine_factory()(cfg, rank, world, local)
     device = torch.device("cuda", local) if dist.get_backend() == "nccl" else torch.device("cpu")
+    eng, ex = make_engine_and_exchange(cfg, rank, world, local, device)
     try:
-        return run_sharded([eng], make_exchange(eng, device), cfg, eng.action_names(), progress)
+        return run_sharded([eng], ex, cfg, eng.action_names(), progress)
     finally:
         eng.close()
 
@@ -653,8 +689,7 @@ def bench_sharded(c: dict, steps: int, warmup: int, backend: str = "nccl"):
     cfg = CheckerConfig(**c, table_capacity=int(os.environ.get("KMC_BENCH_TABLE", max(1 << 27, (1 << 30) // per))),
                         frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", max(1 << 23, (1 << 26) // per))),
                         send_capacity=int(os.environ.get("KMC_BENCH_SEND", max(1 << 18, (1 << 25) // (per * per)))))
-    eng = _engine_factory()(cfg, rank, world, local)
-    ex = make_exchange(eng, device)
+    eng, ex = make_engine_and_exchange(cfg, rank, world, local, device)
     names = eng.action_names()
     results = []
 
