@@ -51,8 +51,9 @@ def main(argv=None) -> int:
     ap.add_argument("-continue", dest="cont", action="store_true")
     ap.add_argument("-workers", default="1")
     ap.add_argument("-fp", type=int, default=0)
-    ap.add_argument("-gpus", type=int, default=1, help="P > 1: P logical shards on this process's GPU (loopback); "
-                                                       "real multi-GPU runs go through torch.distributed.run")
+    ap.add_argument("-gpus", type=int, default=1, help="P > 1: P logical shards on this process's GPU (loopback).  Real "
+                    "multi-GPU runs: `python -m torch.distributed.run --nproc-per-node P -m kafka_specification_amd.tlc ...` "
+                    "— one rank per GPU, the fingerprint space sharded over the ranks, rank 0 prints")
     ap.add_argument("-table", type=int, default=0)
     ap.add_argument("-frontier", type=int, default=0)
     ap.add_argument("-device", type=int, default=0)
@@ -80,6 +81,21 @@ def main(argv=None) -> int:
     except CfgError as e:
         print(f"Error: {e}", file=sys.stderr)
         return 2
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        # launched by torch.distributed.run: one shard per rank (RCCL over xGMI, the exchange under the C ABI);
+        # every rank computes the same global result, rank 0 reports it
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if not dist.is_initialized():
+            dist.init_process_group(backend=os.environ.get("KMC_BACKEND", "nccl"))
+        if dist.get_backend() == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        if rank != 0:
+            sys.stdout = open(os.devnull, "w")
 
     if a.verify:
         os.environ["KMC_VERIFY"] = "1"
@@ -109,6 +125,10 @@ def main(argv=None) -> int:
     from dataclasses import replace
 
     def search(conf, progress):
+        if world > 1:
+            from .sharded import check_distributed
+            res = check_distributed(conf, progress)
+            return res, res.trace
         if a.gpus > 1:
             from .sharded import check_loopback
             res = check_loopback(conf, a.gpus, a.device, progress)

@@ -46,3 +46,27 @@ def test_bench_gpus2_without_gpus_fails_loudly():
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
     assert "no CPU fallback" in p.stderr or "HIP" in p.stderr or "nccl" in p.stderr.lower()
+
+
+def test_tlc_front_end_under_torchrun_shards_over_the_ranks():
+    """`python -m torch.distributed.run --nproc-per-node P -m kafka_specification_amd.tlc Spec.tla` — how BASELINE
+    configs 4 and 5 are meant to run on P GPUs: one shard per rank, every rank computes the same global result, rank 0
+    alone prints it (here: gloo + the stand-in engine)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, KMC_SHARD_ENGINE="shard_standin:make_engine", KMC_BACKEND="gloo",
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "kafka_specification_amd.tlc",
+                        os.path.join(ROOT, "models", "Kip320FirstTry.tla"), "-deadlock"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    out = p.stdout
+    o = kmo.Run(kmo.make_config("Kip320FirstTry", N=3, L=2, R=2, E=2, invariants=("TypeOk", "WeakIsr", "StrongIsr")))
+    assert out.count("Computing initial states...") == 1                      # rank 0 only
+    assert f"Error: Invariant {o.viol_inv} is violated." in out
+    assert f"State {o.viol_depth}: <" in out and f"State {o.viol_depth + 1}: <" not in out
+    assert f"{o.generated} states generated, {o.distinct} distinct states found" in out
+    assert p.returncode != 0                                                   # TLC's exit code 12 travels through the launcher
