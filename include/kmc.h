@@ -228,6 +228,11 @@ int kmc_step_set_send_buffer(kmc_handle* h, void* dev_ptr, uint64_t records_per_
 int kmc_step_insert(kmc_handle* h, const void* dev_records, uint64_t n_records);
 int kmc_step_finish(kmc_handle* h, kmc_level_info* info); /* info->new_states: this shard's next frontier */
 int kmc_step_set_verdict(kmc_handle* h, int32_t verdict); /* driver-decided global stop reason */
+/* Multi-GPU checkpoints: between kmc_step_finish and the next kmc_step_expand every shard may save its own table /
+ * frontier with kmc_checkpoint_save (after kmc_step_set_verdict(h, KMC_V_LEVEL_LIMIT)); the driver keeps the global
+ * counters.  kmc_checkpoint_load into a handle with the same constants, capacities and shard id, then kmc_step_resume
+ * puts it back at that level boundary. */
+int kmc_step_resume(kmc_handle* h);
 /* Invariant-only pass over the CURRENT (unexpanded) frontier — the last level under max_levels; fills
  * info->violation_count / violation_fp. */
 int kmc_step_check_frontier(kmc_handle* h, kmc_level_info* info);

@@ -112,6 +112,7 @@ SYMBOLS = [
     ("kmc_step_insert", C.c_int, [_H, C.c_void_p, C.c_uint64]),
     ("kmc_step_finish", C.c_int, [_H, C.POINTER(KmcLevelInfo)]),
     ("kmc_step_set_verdict", C.c_int, [_H, C.c_int32]),
+    ("kmc_step_resume", C.c_int, [_H]),
     ("kmc_step_check_frontier", C.c_int, [_H, C.POINTER(KmcLevelInfo)]),
     ("kmc_step_find_outside", C.c_int, [_H, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     ("kmc_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),

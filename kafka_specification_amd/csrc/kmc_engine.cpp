@@ -1443,7 +1443,11 @@ int file_to_dev(FILE* f, u64* dev, uint64_t words) {
 
 int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     if (!h || !path) return fail(KMC_E_ARG, "null argument");
-    if (!h->table || h->cfg.n_shards != 1) return fail(KMC_E_STATE, "checkpoints are for single-GPU device handles");
+    if (!h->table) return fail(KMC_E_STATE, "checkpoints are for device handles");
+    // a shard of a multi-GPU search (level-step interface) saves its own table / frontier between kmc_step_finish and
+    // the next kmc_step_expand; the driver keeps the global counters (sharded.py) and sets the verdict first
+    if (h->cfg.n_shards != 1 && (!h->stepping || h->step_expanded))
+        return fail(KMC_E_STATE, "a shard is checkpointed between kmc_step_finish and the next kmc_step_expand");
     if (h->levels.empty()) return fail(KMC_E_STATE, "nothing to checkpoint: run first");
     // Only a level boundary is a consistent state: after a stop inside a level (invariant, deadlock, table / frontier
     // full) the table already holds the fingerprints of the rolled-back or partial level while the frontier is still
@@ -1477,7 +1481,7 @@ int kmc_checkpoint_save(kmc_handle* h, const char* path) {
 
 int kmc_checkpoint_load(kmc_handle* h, const char* path) {
     if (!h || !path) return fail(KMC_E_ARG, "null argument");
-    if (!h->table || h->cfg.n_shards != 1) return fail(KMC_E_STATE, "checkpoints are for single-GPU device handles");
+    if (!h->table) return fail(KMC_E_STATE, "checkpoints are for device handles");
     HIP_TRY(hipSetDevice(h->cfg.device));
     FILE* f = fopen(path, "rb");
     if (!f) return fail(KMC_E_ARG, "cannot open %s", path);
@@ -1489,8 +1493,8 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
     if (!rc && (a.model != b.model || a.n_replicas != b.n_replicas || a.log_size != b.log_size ||
                 a.max_records != b.max_records || a.max_leader_epoch != b.max_leader_epoch ||
                 a.n_log_records != b.n_log_records || a.max_id != b.max_id || a.hash_seed != b.hash_seed ||
-                hd.w != (uint64_t)h->W))
-        rc = fail(KMC_E_ARG, "checkpoint was taken for a different model / constants / hash seed");
+                a.n_shards != b.n_shards || a.shard_id != b.shard_id || hd.w != (uint64_t)h->W))
+        rc = fail(KMC_E_ARG, "checkpoint was taken for a different model / constants / hash seed / shard");
     if (!rc && (hd.table_cap != h->table_cap || hd.fcap != h->fcap || hd.seg_cap != h->seg_cap ||
                 hd.has_pred != (uint64_t)(h->pred != nullptr)))
         rc = fail(KMC_E_ARG, "checkpoint capacities differ: open the handle with table_capacity=%llu frontier_capacity=%llu keep_trace=%d",
@@ -2092,6 +2096,21 @@ int kmc_step_find_outside(kmc_handle* h, uint64_t fp, uint64_t* words, uint64_t*
     for (int k = 0; k < h->W; ++k) words[k] = h->witness[k];
     *parent_fp = h->witness_parent_fp;
     *found = 1;
+    return KMC_OK;
+}
+
+// Continue a sharded search from a shard checkpoint: after kmc_checkpoint_load the handle is back at the level
+// boundary it was saved at; the next call is kmc_step_expand.
+int kmc_step_resume(kmc_handle* h) {
+    if (!h) return fail(KMC_E_ARG, "null handle");
+    if (!h->table || !h->restored) return fail(KMC_E_STATE, "kmc_step_resume needs a handle restored by kmc_checkpoint_load");
+    h->restored = false;
+    h->stepping = true;
+    h->step_expanded = false;
+    h->xcounts_valid = false;
+    h->t_start = now_s() - h->res.seconds_total;
+    if (h->res.verdict == KMC_V_LEVEL_LIMIT) h->res.verdict = KMC_V_OK;
+    h->res.queue_left = 0;
     return KMC_OK;
 }
 

@@ -119,6 +119,18 @@ class HipShardEngine:
         self._oviol_fp = [int(info.outside_violation_fp[k]) for k in range(4)]
         return st
 
+    def save_checkpoint(self, path: str):
+        """This shard's table / frontier at the level boundary it stands on (between finish() and expand())."""
+        nat.check(self.lib.kmc_step_set_verdict(self.mc.handle, nat.VERDICTS.index("level_limit")))
+        nat.check(self.lib.kmc_checkpoint_save(self.mc.handle, path.encode()))
+
+    def load_checkpoint(self, path: str) -> int:
+        """-> the size of the level this shard holds after the load (its share of the last recorded level)."""
+        nat.check(self.lib.kmc_checkpoint_load(self.mc.handle, path.encode()))
+        nat.check(self.lib.kmc_step_resume(self.mc.handle))
+        lv = self.mc.result().levels
+        return lv[-1] if lv else 0
+
     def check_frontier(self):
         """Invariant-only pass over the current, unexpanded frontier (the last level under max_levels):
         st[17..20] = violations among its states."""
@@ -391,9 +403,15 @@ def _chunks(x):
 
 
 def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: List[str],
-                progress=None) -> CheckResult:
+                progress=None, checkpoint_dir: Optional[str] = None, resume_dir: Optional[str] = None) -> CheckResult:
     """Level-synchronous BFS over all shards.  Returns the global result (identical on every
-    rank).  `engines` are this process's shards."""
+    rank).  `engines` are this process's shards.
+
+    checkpoint_dir: when the run stops at max_levels (verdict level_limit) every shard saves its table / frontier
+    there (shard<i>of<P>.ckpt, kmc_checkpoint_save) and the global counters go to driver.json — TLC's -checkpoint for a
+    sharded search.  resume_dir: load such a checkpoint into shards opened with the same constants, capacities and
+    shard ids and continue as if the search had never stopped (-recover); cfg.max_levels of this run applies."""
+    import json
     t0 = time.perf_counter()
     inv_names = tuple(n for n in nat.invariant_names(cfg.model) if n != "?")
     levels, generated, deadlocks = [], 0, 0
@@ -449,9 +467,27 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
     # first and expand afterwards (one small collective more per level).
     pipelined = not (cfg.keep_trace and cfg.model == "AsyncIsr")
     zeros = [np.zeros(N_STATS, dtype=np.int64) for _ in engines]
-    pending = [e.begin() for e in engines]   # per-engine statistics not yet reduced ...
-    pending_depth = 0                        # ... of the expansion of this level (0: Init's insertion)
-    depth = 0                                # levels recorded so far
+    P = engines[0].n_shards
+    if resume_dir:
+        drv = json.load(open(os.path.join(resume_dir, "driver.json")))
+        if drv["n_shards"] != P or drv["model"] != cfg.model:
+            raise ValueError(f"checkpoint in {resume_dir} is for {drv['model']} on {drv['n_shards']} shards")
+        # the shards come back holding the last recorded level, complete and unexpanded: it is recorded again from
+        # the sizes they report, everything before it comes from the driver file
+        pending = []
+        for e in engines:
+            st = np.zeros(N_STATS, dtype=np.int64)
+            st[0] = e.load_checkpoint(os.path.join(resume_dir, f"shard{e.shard_id}of{P}.ckpt"))
+            pending.append(st)
+        levels = list(drv["levels"][:-1])
+        generated, deadlocks, filtered = drv["generated"], drv["deadlocks"], drv["filtered"]
+        action_generated = list(drv["action_generated"])
+        depth = len(levels)
+        pending_depth = depth
+    else:
+        pending = [e.begin() for e in engines]   # per-engine statistics not yet reduced ...
+        pending_depth = 0                        # ... of the expansion of this level (0: Init's insertion)
+        depth = 0                                # levels recorded so far
     max_levels = cfg.max_levels or (1 << 62)
     new = 0
     while True:
@@ -492,6 +528,15 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
             viol_inv, viol_depth, viol_count, verdict = hit[0], depth, counts, "invariant"
     if depth >= max_levels and new > 0 and verdict == "ok":
         verdict = "level_limit"
+        if checkpoint_dir:
+            os.makedirs(checkpoint_dir, exist_ok=True)
+            for e in engines:
+                e.save_checkpoint(os.path.join(checkpoint_dir, f"shard{e.shard_id}of{P}.ckpt"))
+            if any(e.shard_id == 0 for e in engines):
+                with open(os.path.join(checkpoint_dir, "driver.json"), "w") as f:
+                    json.dump(dict(model=cfg.model, n_shards=P, levels=levels, generated=generated, deadlocks=deadlocks,
+                                   filtered=filtered, action_generated=action_generated), f)
+            exchange.barrier()
     trace = []
     if verdict == "invariant" and cfg.keep_trace:
         outside = viol_depth > len(levels)   # a witness outside the state constraint: in no shard's table
@@ -586,14 +631,15 @@ def _sharded_trace(engines, exchange, inv_index, action_names, outside=False):
     return out
 
 
-def check_loopback(cfg: CheckerConfig, n_shards: int, device: int = 0, progress=None) -> CheckResult:
+def check_loopback(cfg: CheckerConfig, n_shards: int, device: int = 0, progress=None, checkpoint_dir=None,
+                   resume_dir=None) -> CheckResult:
     """P logical shards on ONE GPU with an in-process exchange (tests the bucket / insert kernels
     and the level logic without RCCL)."""
     native = os.environ.get("KMC_EXCHANGE", "rccl") != "torch"
     engines = [HipShardEngine(cfg, s, n_shards, device, native=native) for s in range(n_shards)]
     try:
         ex = NativeLoopbackExchange(engines) if native else LoopbackExchange(n_shards)
-        return run_sharded(engines, ex, cfg, engines[0].mc.action_names(), progress)
+        return run_sharded(engines, ex, cfg, engines[0].mc.action_names(), progress, checkpoint_dir, resume_dir)
     finally:
         for e in engines:
             e.close()
@@ -637,7 +683,7 @@ def make_engine_and_exchange(cfg: CheckerConfig, rank: int, world: int, local: i
     return eng, DistExchange(device, eng.record_words)
 
 
-def check_distributed(cfg: CheckerConfig, progress=None) -> CheckResult:
+def check_distributed(cfg: CheckerConfig, progress=None, checkpoint_dir=None, resume_dir=None) -> CheckResult:
     """One shard per rank of the default process group (launch with torch.distributed.run)."""
     import torch
     import torch.distributed as dist
@@ -646,7 +692,7 @@ def check_distributed(cfg: CheckerConfig, progress=None) -> CheckResult:
     device = torch.device("cuda", local) if dist.get_backend() == "nccl" else torch.device("cpu")
     eng, ex = make_engine_and_exchange(cfg, rank, world, local, device)
     try:
-        return run_sharded([eng], ex, cfg, eng.action_names(), progress)
+        return run_sharded([eng], ex, cfg, eng.action_names(), progress, checkpoint_dir, resume_dir)
     finally:
         eng.close()
 

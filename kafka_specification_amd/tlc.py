@@ -60,6 +60,11 @@ def main(argv=None) -> int:
     ap.add_argument("-notrace", action="store_true", help="do not keep predecessor links (no counterexample trace)")
     ap.add_argument("-fpcheck", action="store_true",
                     help="run the search again with a second fingerprint seed and compare the counts")
+    ap.add_argument("-maxlevels", type=int, default=0, help="stop after this many BFS levels (verdict level_limit)")
+    ap.add_argument("-checkpoint", default=None, metavar="DIR",
+                    help="with -gpus P / torch.distributed.run and -maxlevels: every shard saves its table and frontier "
+                         "there when the level limit is reached (TLC -checkpoint for a sharded search)")
+    ap.add_argument("-recover", default=None, metavar="DIR", help="continue a sharded search from such a directory")
     ap.add_argument("-verify", action="store_true",
                     help="differential self-check: a second, differently compiled build of the kernels regenerates every "
                          "level and the per-action / deadlock / violation counts must agree (for constants no oracle reaches)")
@@ -74,7 +79,7 @@ def main(argv=None) -> int:
     try:
         mcfg = parse_cfg(open(cfg_path).read())
         over = dict(hash_seed=a.fp, device=a.device, continue_on_violation=a.cont, keep_trace=not a.notrace,
-                    table_capacity=a.table, frontier_capacity=a.frontier)
+                    table_capacity=a.table, frontier_capacity=a.frontier, max_levels=a.maxlevels)
         if a.deadlock:
             over["check_deadlock"] = False
         cc = to_checker_config(module, mcfg, **over)
@@ -127,11 +132,11 @@ def main(argv=None) -> int:
     def search(conf, progress):
         if world > 1:
             from .sharded import check_distributed
-            res = check_distributed(conf, progress)
+            res = check_distributed(conf, progress, a.checkpoint, a.recover)
             return res, res.trace
         if a.gpus > 1:
             from .sharded import check_loopback
-            res = check_loopback(conf, a.gpus, a.device, progress)
+            res = check_loopback(conf, a.gpus, a.device, progress, a.checkpoint, a.recover)
             return res, res.trace   # walked owner by owner through the shards' predecessor tables
         with ModelChecker(conf) as mc:
             res = mc.run(progress)

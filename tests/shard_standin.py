@@ -133,6 +133,18 @@ class OracleShardEngine:
         self.retired = self._expanding
         return self._close_level()
 
+    def save_checkpoint(self, path):
+        import pickle
+        with open(path, "wb") as f:
+            pickle.dump(dict(seen=self.seen, frontier=self.frontier), f)
+
+    def load_checkpoint(self, path):
+        import pickle
+        d = pickle.load(open(path, "rb"))
+        self.seen, self.frontier, self.next = d["seen"], d["frontier"], []
+        self.reset_level()
+        return len(self.frontier)
+
     def check_frontier(self):
         """Invariant-only pass over the current, unexpanded frontier (the last level under max_levels)."""
         st = np.zeros(N_STATS, dtype=np.int64)
