@@ -15,8 +15,11 @@ RUNS = {
     "config2_headline": dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=2,
                              invariants=("TypeOk", "WeakIsr", "StrongIsr"), table_capacity=1 << 30,
                              frontier_capacity=1 << 26),
-    "config3_kip279_5brokers_levels": dict(model="Kip279", n_replicas=5, log_size=2, max_records=2, max_leader_epoch=2,
-                                           invariants=("TypeOk",), max_levels=16),
+    # BASELINE config 4 at its exhaustible constants (models/Kip279_5brokers.cfg; golden: 112,549,196 states)
+    "config3_kip279_5brokers": dict(model="Kip279", n_replicas=5, log_size=2, max_records=2, max_leader_epoch=1,
+                                    invariants=("TypeOk",), table_capacity=1 << 29, frontier_capacity=1 << 25),
+    "config3_kip279_5brokers_epoch2_levels": dict(model="Kip279", n_replicas=5, log_size=2, max_records=2, max_leader_epoch=2,
+                                                  invariants=("TypeOk",), max_levels=16),
     "config4_kip320_7brokers_log8_levels": dict(model="Kip320", n_replicas=7, log_size=8, max_records=8,
                                                 max_leader_epoch=3, invariants=("TypeOk",), max_levels=13),
     "stretch_kip279_5brokers_exhaustive": dict(model="Kip279", n_replicas=5, log_size=2, max_records=2,
@@ -34,7 +37,7 @@ RUNS = {
 # level sizes of the first BFS levels from the C oracle (oracle/kmc_oracle --max-states 30000000, 8 threads):
 # the configurations that cannot be exhausted are at least checked on the prefix the CPU can reach
 ORACLE_PREFIX = {
-    "config3_kip279_5brokers_levels": [1, 10, 110, 1220, 9000, 46140, 173465, 537555, 1489900, 3772630, 8765995, 18824715],
+    "config3_kip279_5brokers_epoch2_levels": [1, 10, 110, 1220, 9000, 46140, 173465, 537555, 1489900, 3772630, 8765995, 18824715],
     "stretch_kip279_5brokers_exhaustive": [1, 10, 110, 1220, 9000, 46140, 173465, 537555, 1489900, 3772630, 8765995, 18824715],
     "config4_kip320_7brokers_log8_levels": [1, 14, 182, 2282, 27650, 130095, 1112202, 6530965, 33198956],
 }
@@ -56,6 +59,10 @@ def child(name):
                state_bits=r.state_bits, table_capacity=r.table_capacity, frontier_capacity=r.frontier_capacity,
                widest_level=max(r.levels) if r.levels else 0, trace_len=trace_len, levels_tail=r.levels[-5:],
                levels_head=r.levels[:12])
+    golden = os.path.join(ROOT, "tests", "golden", "oracle_kip279_5_2_2_1.json")
+    if name == "config3_kip279_5brokers" and os.path.exists(golden):
+        g = json.load(open(golden))
+        out["matches_oracle_golden"] = (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
     if name in ORACLE_PREFIX:
         k = min(len(ORACLE_PREFIX[name]), len(r.levels))
         out["oracle_prefix_levels"] = k
