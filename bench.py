@@ -70,6 +70,22 @@ def randbench_rates():
     return rates, (os.path.relpath(path, ROOT) if path else None)
 
 
+def calibrated_bytes_per_access(mode):
+    """(FETCH_SIZE + WRITE_SIZE bytes per random access of randbench `mode`, file) from the newest
+    profiles/rNN_fetch_calibration.txt (tools/calibrate_fetch.sh), or None."""
+    import re
+    path = newest_profile("fetch_calibration.txt")
+    if not path:
+        return None
+    tot, seen = 0.0, 0
+    for line in open(path):
+        m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+mode (\d+).*?([0-9.]+) B/access", line)
+        if m and int(m.group(2)) == mode:
+            tot += float(m.group(3))
+            seen += 1
+    return (tot, os.path.relpath(path, ROOT)) if seen == 2 else None
+
+
 def measured_traffic():
     """HBM bytes per k_expand launch from the newest committed PMC summary — only when it was measured on THIS
     device code (the summary carries the sha256 of the device sources); otherwise null, with the reason."""
@@ -253,6 +269,19 @@ def main():
             "claims_per_s": claims / max(kernel_s, 1e-12), "claims_per_s_ceiling": rates[3],
             "lower_bound_s": lb, "frac_of_lower_bound": min(1.0, lb / max(kernel_s, 1e-12)),
             "source": rates_file + " (modes 1 and 3)"}
+        # What actually bounds the kernel: 64-byte SECTOR traffic of random accesses.  The measured HBM bytes of the
+        # run (PMC, same device code) over the kernel time, against what the memory system sustains for the seen-set's
+        # own access mix — randbench mode 3 (a random load, then a CAS when the slot was empty) moves
+        # rate x (FETCH + WRITE bytes per access) as calibrated under the same counters.
+        per_access = calibrated_bytes_per_access(3)
+        if traffic and per_access:
+            sector_bps = traffic * launches / max(kernel_s, 1e-12)
+            ceiling = rates[3] * per_access[0]
+            random_access.update({
+                "sector_traffic_GBps": sector_bps / 1e9, "sector_traffic_ceiling_GBps": ceiling / 1e9,
+                "frac_of_sector_ceiling": sector_bps / ceiling,
+                "sector_ceiling_source": f"{rates_file} mode 3 = {rates[3] / 1e9:.1f} G accesses/s x {per_access[0]:.1f} B/access "
+                                         f"({per_access[1]})"})
     out = {
         "metric": "distinct states/sec + time-to-exhaustive, KafkaReplication 3-broker",
         "value": value, "unit": "distinct states/s", "n_gpus": max(a.gpus, world), "steps": a.steps,
@@ -272,8 +301,10 @@ def main():
                      "note": "achieved = algorithmic bytes (2*S + 8*g + 8 per distinct state) over the summed durations "
                              "of the step's per-level k_expand launches (HIP events on the engine stream); random 8-B "
                              "probes move >= one 64-B sector each, so 12.5 % useful bytes is the ceiling for the probe "
-                             "part.  The kernel is bound by integer ALU work, not by HBM (profiles/: ablation, "
-                             "instruction counts)"},
+                             "part.  What bounds the kernel is the RATE of 64-B sector operations of random accesses "
+                             "(random_access.frac_of_sector_ceiling): the run moves its sectors at the speed the "
+                             "load-then-CAS microbenchmark does; neither fewer ALU instructions nor more waves per "
+                             "SIMD shorten it (profiles/r02_ablation.txt, r02_occupancy_sweep.txt)"},
         "device": device_info(),
     }
     if not a.no_cpu_baseline and world == 1:

@@ -1217,6 +1217,9 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
                         "of which flush %.1f%%  tail %.1f%%  (total %.3g ticks)\n",
                 100 * h->prof[0] / tot, 100 * h->prof[1] / tot, 100 * h->prof[2] / tot, 100 * h->prof[3] / tot,
                 100 * h->prof[4] / tot, tot);
+        if (h->prof[6])
+            fprintf(stderr, "[kmc] effect leaves dispatched per 64-state tile: %.1f (%llu tiles)\n",
+                    (double)h->prof[5] / (double)h->prof[6], (unsigned long long)h->prof[6]);
         for (int k = 0; k < 8; ++k) h->prof[k] = 0;
     }
     if (h->prof_dry[7]) {
