@@ -17,3 +17,6 @@ for ctr in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA
   echo "$name rc=$?" >> "$OUT/passes.log"
 done
 python3 "$REPO/tools/calibrate_fetch.py" "$OUT"
+# ... and the rates themselves, without the profiler (G accesses/s per mode, 8 GiB table)
+timeout 200 "$BIN" 0 > "$OUT/randbench.txt" 2>&1
+cat "$OUT/randbench.txt"
