@@ -1864,6 +1864,7 @@ int kmc_comm_selftest(kmc_handle* h) {
     const size_t n = 4096;
     u64* buf = nullptr;
     HIP_TRY(hipMalloc(&buf, (size_t)(2 + P) * n * 8));
+    struct Free { u64* p; ~Free() { hipFree(p); } } free_buf{buf};   // also on the error returns below
     std::vector<uint64_t> host((size_t)(2 + P) * n);
     for (size_t i = 0; i < n; ++i) host[i] = ((uint64_t)(me + 1) << 32) | i;
     HIP_TRY(hipMemcpyAsync(buf, host.data(), n * 8, hipMemcpyHostToDevice, h->stream));
@@ -1875,7 +1876,6 @@ int kmc_comm_selftest(kmc_handle* h) {
     NCCL_TRY(r->AllGather(buf, buf + 2 * n, n, ncclUint64, h->comm, h->stream));
     HIP_TRY(hipMemcpyAsync(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    hipFree(buf);
     const uint64_t from = (uint64_t)((me + P - 1) % P + 1);
     for (size_t i = 0; i < n; ++i) {
         if (host[n + i] != ((from << 32) | i)) return fail(KMC_E_DEVICE, "selftest: send/recv word %zu is wrong", i);
