@@ -409,6 +409,21 @@ KmcArgs base_args(kmc_handle* h, int ctl_slot) {
     return a;
 }
 
+// Upper bound on the successors of one state = the number of action instances of the lowered Next (device header:
+// KmcKafka::NINST etc.).  Sizes the grids of chained launches, whose input sizes only the device knows.
+uint64_t max_fanout(const kmc_handle* h) {
+    const uint64_t N = (uint64_t)h->cfg.n_replicas, L = (uint64_t)h->cfg.log_size, E1 = (uint64_t)h->cfg.max_leader_epoch + 1;
+    switch (h->cfg.model) {
+    case KMC_IDSEQUENCE: return 1;
+    case KMC_FINITE_REPLICATED_LOG: return N * (uint64_t)h->cfg.n_log_records + N * L + N * (N - 1);
+    case KMC_ASYNC_ISR: return (N - 1) + (1ull << N) + (N - 1) + N + 1 + (uint64_t)h->cfg.max_leader_epoch + (N - 1);
+    default: {
+        const uint64_t NP = N * (N - 1);
+        return N + N + E1 * N + N * N + NP + N + N + NP * E1 + NP + (h->cfg.model == KMC_KIP320_FIRST_TRY ? NP : 0);
+    }
+    }
+}
+
 unsigned expand_grid(kmc_handle* h, uint64_t n) {
     const uint64_t tiles = (n + 63) / 64;
     uint64_t blocks = (tiles + KMC_WAVES - 1) / KMC_WAVES;
@@ -1045,6 +1060,8 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             uint64_t B = max_levels - h->level;
             if (B > KMC_CHAIN) B = KMC_CHAIN;
             HIP_TRY(hipMemsetAsync(h->ctl + 3, 0, B * sizeof(KmcLevelCtl), h->stream));
+            const uint64_t fan = max_fanout(h) ? max_fanout(h) : 1;
+            uint64_t bound = h->n_cur;   // upper bound on the size of the level launch i expands
             for (uint64_t i = 0; i < B; ++i) {
                 if (!h->ev_chain[2 * i]) {
                     HIP_TRY(hipEventCreate(&h->ev_chain[2 * i]));
@@ -1059,8 +1076,11 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
                 a.stop_mask = h->cfg.continue_on_violation ? 0u : h->cfg.invariant_mask;
                 a.stop_deadlock = (h->cfg.check_deadlock && r.verdict == KMC_V_OK) ? 1u : 0u;
                 HIP_TRY(hipEventRecord(h->ev_chain[2 * i], h->stream));
-                // sizes behind the first level are unknown here: a resident grid, idle blocks leave at once
-                if ((rc = launch(h, h->f_expand, a, expand_grid(h, i ? h->fcap : h->n_cur)))) return rc;
+                // sizes behind the first level are only known on the device: the grid is sized for the most a level can
+                // grow (every state enabling every action instance), which saturates at a resident grid within two or
+                // three levels but keeps the chains of tiny levels (IdSequence: 1002 one-state levels) to one block
+                if ((rc = launch(h, h->f_expand, a, expand_grid(h, bound)))) return rc;
+                bound = bound > h->fcap / fan ? h->fcap : bound * fan;
                 HIP_TRY(hipEventRecord(h->ev_chain[2 * i + 1], h->stream));
             }
             HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl + 3, B * sizeof(KmcLevelCtl), hipMemcpyDeviceToHost, h->stream));
