@@ -1,7 +1,7 @@
 """Multi-GPU BFS: the fingerprint space is hash-partitioned across shards (one shard per GPU,
 one process per GPU) and every BFS level exchanges successor states with one all-to-all.
 
-    owner(state) = (fingerprint >> 40) % P            (csrc/kmc_device.h: kmc_owner)
+    owner(state) = (bits 40..63 of the fingerprint) * P >> 24      (csrc/kmc_device.h: kmc_owner)
 
 Per level, on every shard:  expand the local frontier, bucketing each successor into the send
 area of its owner (k_expand, mode SHARDED)  ->  all-to-all-v of packed states (W words, plus the
@@ -166,7 +166,7 @@ class HipShardEngine:
         return self._viol_fp[inv_index]
 
     def owner(self, fp: int) -> int:
-        return (fp >> 40) % self.n_shards          # kmc_owner (csrc/kmc_device.h)
+        return (((fp >> 40) & 0xFFFFFF) * self.n_shards) >> 24          # kmc_owner (csrc/kmc_device.h)
 
     def pred_of(self, fp: int):
         """Predecessor fingerprint recorded for fp in this shard's table, None when fp is not here."""

@@ -1,17 +1,32 @@
-"""The headline configuration through the sharded path with P = 2 and 4 logical shards on ONE GPU (in-process
-exchange): counts and level sizes against the committed golden fixture.  usage: python tools/loopback_headline.py"""
+"""The headline configuration through the sharded path with P = 2, 4 and 8 logical shards on ONE GPU: counts and level
+sizes against the committed golden fixture, once with the exchange under the C ABI (device-to-device runs + one k_insert
+per shard and level) and once with the torch path (slices of a torch-owned send area routed in Python).  One device does
+all shards' work one after the other, so the times say what the per-level machinery costs, not how P GPUs would scale.
+usage: python tools/loopback_headline.py [P ...]"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
+import torch  # noqa: F401  (first: one HIP runtime per process)
 from kafka_specification_amd import CheckerConfig
 from kafka_specification_amd.configs import HEADLINE
-from kafka_specification_amd.sharded import check_loopback
+from kafka_specification_amd import sharded
 g = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_kip320_3_6_6_2.json")))
-for P in (2, 4):
-    cfg = CheckerConfig(**HEADLINE, table_capacity=(1 << 30) // P, frontier_capacity=(1 << 26) // P,
-                        send_capacity=(1 << 25) // (P * P) * 2)
-    t = time.time()
-    r = check_loopback(cfg, P)
-    print(P, r.verdict, r.distinct, r.generated, r.depth, r.distinct == g["distinct"] and r.generated == g["generated"] and r.levels == g["levels"],
-          round(time.time() - t, 2), "s; expand", round(r.seconds_expand, 3))
+for P in ([int(x) for x in sys.argv[1:]] or [2, 4, 8]):
+    for exchange in ("rccl", "torch"):
+        os.environ["KMC_EXCHANGE"] = exchange
+        cfg = CheckerConfig(**HEADLINE, table_capacity=(1 << 30) // P, frontier_capacity=(1 << 26) // P,
+                            send_capacity=max(1 << 18, (1 << 25) // (P * P) * 2))
+        engines = [sharded.HipShardEngine(cfg, s, P, 0, native=exchange == "rccl") for s in range(P)]
+        ex = sharded.NativeLoopbackExchange(engines) if exchange == "rccl" else sharded.LoopbackExchange(P)
+        try:
+            sharded.run_sharded(engines, ex, cfg, engines[0].action_names())          # warm-up
+            t = time.time()
+            r = sharded.run_sharded(engines, ex, cfg, engines[0].action_names())
+            dt = time.time() - t
+        finally:
+            for e in engines:
+                e.close()
+        ok = r.distinct == g["distinct"] and r.generated == g["generated"] and r.levels == g["levels"]
+        print(json.dumps(dict(shards=P, exchange="under the C ABI" if exchange == "rccl" else "torch slices", verdict=r.verdict,
+                              distinct=r.distinct, matches_golden=ok, seconds=round(dt, 4),
+                              send_filtered=sharded.run_sharded.last_send_filtered)), flush=True)
