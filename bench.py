@@ -71,19 +71,21 @@ def randbench_rates():
 
 
 def calibrated_bytes_per_access(mode):
-    """(FETCH_SIZE + WRITE_SIZE bytes per random access of randbench `mode`, file) from the newest
-    profiles/rNN_fetch_calibration.txt (tools/calibrate_fetch.sh), or None."""
+    """(DRAM bytes per random access of randbench `mode`, file) from the newest profiles/rNN_dram_bytes_per_access.txt:
+    32 bytes x (TCC_EA0_RDREQ_DRAM_32B + TCC_EA0_WRREQ_WRITE_DRAM_32B + TCC_EA0_WRREQ_ATOMIC_DRAM_32B) per access, the
+    gfx950 counters that say how many bytes a request really moved (FETCH_SIZE tallies a 128-byte request as 64), or None."""
     import re
-    path = newest_profile("fetch_calibration.txt")
+    path = newest_profile("dram_bytes_per_access.txt")
     if not path:
         return None
-    tot, seen = 0.0, 0
+    tot, seen = 0.0, set()
     for line in open(path):
-        m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+mode (\d+).*?([0-9.]+) B/access", line)
+        m = re.match(r"(TCC_EA0_RDREQ_DRAM_32B_sum|TCC_EA0_WRREQ_WRITE_DRAM_32B_sum|TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum)\s+"
+                     r"mode (\d+).*?([0-9.]+) req/access", line)
         if m and int(m.group(2)) == mode:
-            tot += float(m.group(3))
-            seen += 1
-    return (tot, os.path.relpath(path, ROOT)) if seen == 2 else None
+            tot += 32.0 * float(m.group(3))
+            seen.add(m.group(1))
+    return (tot, os.path.relpath(path, ROOT)) if len(seen) == 3 else None
 
 
 def measured_traffic():
@@ -269,21 +271,22 @@ def main():
             "claims_per_s": claims / max(kernel_s, 1e-12), "claims_per_s_ceiling": rates[3],
             "lower_bound_s": lb, "frac_of_lower_bound": min(1.0, lb / max(kernel_s, 1e-12)),
             "source": rates_file + " (modes 1 and 3)"}
-        # What actually bounds the kernel: 64-byte SECTOR traffic of random accesses.  The measured HBM bytes of the
-        # run (PMC, same device code) over the kernel time, against what the memory system sustains for the seen-set's
-        # own access mix — randbench mode 7 (a random load, and a CAS on that slot for 35 % of the accesses; mode 3, a CAS
-        # whenever the slot was empty, when no mode-7 measurement is committed) moves rate x (FETCH + WRITE bytes per
-        # access) as calibrated under the same counters.
+        # What actually bounds the kernel: HBM traffic of random accesses.  Every random 8-byte probe fills a whole
+        # 128-byte line from DRAM (profiles/r02_request_size.txt).  The measured DRAM bytes of the run (PMC, same device
+        # code) over the kernel time, against what the memory system sustains for the seen-set's own access mix —
+        # randbench mode 7 (a random load, and a CAS on that slot for 35 % of the accesses; mode 3, a CAS whenever the slot
+        # was empty, when no mode-7 measurement is committed): rate x DRAM bytes per access under the same counters.
         mix = 7 if rates.get(7) and calibrated_bytes_per_access(7) else 3   # mode 7: a load + a CAS for 35 % = this kernel's mix
         per_access = calibrated_bytes_per_access(mix)
         if traffic and per_access:
-            sector_bps = traffic * launches / max(kernel_s, 1e-12)
+            dram_bps = traffic * launches / max(kernel_s, 1e-12)
             ceiling = rates[mix] * per_access[0]
             random_access.update({
-                "sector_traffic_GBps": sector_bps / 1e9, "randbench_same_mix_GBps": ceiling / 1e9,
-                "ratio_to_randbench_same_mix": sector_bps / ceiling,   # ~1: a microbenchmark of the same mix, not a hard bound
+                "dram_traffic_GBps": dram_bps / 1e9, "dram_traffic_frac_of_hbm_peak": dram_bps / HBM_PEAK_BPS,
+                "randbench_same_mix_GBps": ceiling / 1e9,
+                "ratio_to_randbench_same_mix": dram_bps / ceiling,   # ~1: a microbenchmark of the same mix, not a hard bound
                 "randbench_source": f"{rates_file} mode {mix} = {rates[mix] / 1e9:.1f} G accesses/s x {per_access[0]:.1f} "
-                                         f"B/access ({per_access[1]})"})
+                                         f"DRAM B/access ({per_access[1]})"})
     out = {
         "metric": "distinct states/sec + time-to-exhaustive, KafkaReplication 3-broker",
         "value": value, "unit": "distinct states/s", "n_gpus": max(a.gpus, world), "steps": a.steps,
@@ -301,12 +304,13 @@ def main():
                      "traffic_source": traffic_source, "random_access": random_access,
                      "device_source_sha256": device_source_sha256()[:16],
                      "note": "achieved = algorithmic bytes (2*S + 8*g + 8 per distinct state) over the summed durations "
-                             "of the step's per-level k_expand launches (HIP events on the engine stream); random 8-B "
-                             "probes move >= one 64-B sector each, so 12.5 % useful bytes is the ceiling for the probe "
-                             "part.  What bounds the kernel is the RATE of 64-B sector operations of random accesses "
-                             "(random_access.ratio_to_randbench_same_mix): the run moves its sectors at the speed a "
-                             "microbenchmark of the same load/CAS mix does; neither fewer ALU instructions nor more waves per "
-                             "SIMD shorten it (profiles/r02_ablation.txt, r02_occupancy_sweep.txt)"},
+                             "of the step's per-level k_expand launches (HIP events on the engine stream).  traffic = DRAM bytes "
+                             "per launch from the gfx950 request-size counters: every random 8-B probe fills one 128-B line "
+                             "(6.25 % useful bytes is the ceiling for the probe part), a claim adds a 64-B atomic request.  "
+                             "What bounds the kernel is the HBM traffic of these random accesses "
+                             "(random_access.dram_traffic_frac_of_hbm_peak; ratio_to_randbench_same_mix ~ 1: the run moves "
+                             "its lines as fast as a microbenchmark of the same load/CAS mix); neither fewer ALU instructions "
+                             "nor more waves per SIMD shorten it (profiles/r02_ablation.txt, r02_occupancy_sweep.txt)"},
         "device": device_info(),
     }
     if not a.no_cpu_baseline and world == 1:

@@ -79,6 +79,29 @@ typedef unsigned int u32;
 #ifndef KMC_SC1_PROBE
 #define KMC_SC1_PROBE 0   // 1: probe with agent-scope (L2-bypassing) loads: fewer stale "empty" reads -> fewer lost CASes
 #endif
+#ifndef KMC_NT_PROBE
+#define KMC_NT_PROBE 0    // 1: the seen-set probe is a non-temporal load (`global_load_dwordx2 ... nt`).  Every random 8-byte
+                          //    probe fills a whole 128-byte line (profiles/r02_request_size.txt) and the nt flavour alone
+                          //    sustains 54.8 G random loads/s against 49.5 G/s — but in the kernel it is SLOWER (42.8 ms
+                          //    against 35.5, profiles/r02_nt_sweep.txt): the claim's CAS wants the line the probe has just
+                          //    brought into L2 (randbench: load-then-CAS runs 21.7 G pairs/s, a cold CAS 17.3 G/s)
+#endif
+#if KMC_NT_PROBE
+#define KMC_PROBE_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define KMC_PROBE_LOAD(p) (*(p))
+#endif
+#ifndef KMC_NT_FRONTIER
+#define KMC_NT_FRONTIER 1 // 1: the frontier planes (read once, written once per level) stream past the caches: nt loads / stores
+                          //    (-0.5 ms on the headline, profiles/r02_nt_sweep.txt)
+#endif
+#if KMC_NT_FRONTIER
+#define KMC_FRONTIER_LOAD(p) __builtin_nontemporal_load(p)
+#define KMC_FRONTIER_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define KMC_FRONTIER_LOAD(p) (*(p))
+#define KMC_FRONTIER_STORE(p, v) (*(p) = (v))
+#endif
 #ifndef KMC_ERRCHK_TILE
 #define KMC_ERRCHK_TILE 1 // 1: the "table already full" early-out reads the error word once per tile (issued with the
                           //    frontier loads) instead of once per flush (a dependent L2 round trip in front of every
@@ -1014,7 +1037,7 @@ template <int W> struct KmcStager {
             if (base + lane < a.seg_cap) {
                 const u64 idx = (u64)seg * a.seg_cap + base + lane;
 #pragma unroll
-                for (int k = 0; k < W; ++k) a.fout[(u64)k * a.fout_stride + idx] = planes[k * KMC_QCAP + lane];
+                for (int k = 0; k < W; ++k) KMC_FRONTIER_STORE(&a.fout[(u64)k * a.fout_stride + idx], planes[k * KMC_QCAP + lane]);
             } else {
                 atomicOr(&a.ctl->err, KMC_ERR_FRONTIER_FULL);
             }
@@ -1074,7 +1097,7 @@ template <class M> struct KmcSink {
 #if KMC_SC1_PROBE
             u64 v = __hip_atomic_load(&a.table[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-            u64 v = a.table[i];
+            u64 v = KMC_PROBE_LOAD(&a.table[i]);
 #endif
             if (v == 0) {
                 if (a.flags & KMC_FLAG_X_PLAINSTORE) {
@@ -1101,7 +1124,7 @@ template <class M> struct KmcSink {
     static KMC_DEV bool first_time(u64* set, u64 mask, u64 fp) {
         u64 i = (fp >> 17) & mask;  // other bits than the owner's table index
         for (u32 probes = 0; probes < 64; ++probes) {
-            u64 v = set[i];
+            u64 v = KMC_PROBE_LOAD(&set[i]);
             if (v == 0) {
                 v = atomicCAS(&set[i], 0ull, fp);
                 if (v == 0) return true;
@@ -1338,7 +1361,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         const u32 errv = __hip_atomic_load(&a.ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 #pragma unroll
-        for (int k = 0; k < W; ++k) s[k] = valid ? a.fin[(u64)k * a.fin_stride + idx] : 0ull;
+        for (int k = 0; k < W; ++k) s[k] = valid ? KMC_FRONTIER_LOAD(&a.fin[(u64)k * a.fin_stride + idx]) : 0ull;
 #if KMC_ERRCHK_TILE
         table_full = __builtin_amdgcn_readfirstlane(errv) & KMC_ERR_TABLE_FULL;
 #endif

@@ -804,9 +804,16 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     HIP_TRY(hipMalloc(&h->scratch, 64 * 8));
     HIP_TRY(hipHostMalloc(&h->scratch_host, 64 * 8));
     HIP_TRY(hipMalloc(&h->enum_out, h->enum_cap * (h->W + 2) * 8ull));
-    if (h->cfg.n_shards > 1 && !(getenv("KMC_NO_SEND_FILTER") && atoi(getenv("KMC_NO_SEND_FILTER")))) {
-        // sender-side duplicate filter: a shard generates (and would ship) a remote state several
-        // times; it may meet up to ~2x as many distinct remote fingerprints as it owns
+    // Sender-side duplicate filter: a shard generates (and would ship) a remote state several times.  What it saves
+    // shrinks with P (each copy of a state is generated on a different shard: 49 % of the remote successors dropped at
+    // P = 2, 31 % at 4, 18 % at 8 on the headline) while every remote successor pays one more random probe for it, so it
+    // is on where the wire is the bottleneck (P <= 4: one to three xGMI links per GPU carry everything) and off beyond
+    // (profiles/r02_loopback_filter.jsonl: k_expand per shard 11.6 -> 8.1 ms at P = 8).  KMC_SEND_FILTER=1 / 0 forces it.
+    bool want_filter = h->cfg.n_shards > 1 && h->cfg.n_shards <= 4;
+    if (const char* e = getenv("KMC_SEND_FILTER")) want_filter = h->cfg.n_shards > 1 && atoi(e) != 0;
+    if (getenv("KMC_NO_SEND_FILTER") && atoi(getenv("KMC_NO_SEND_FILTER"))) want_filter = false;
+    if (want_filter) {
+        // it may meet up to ~2x as many distinct remote fingerprints as it owns
         h->sent_cap = tcap * 2;
         if (hipMalloc(&h->sent, h->sent_cap * 8) != hipSuccess) { h->sent = nullptr; h->sent_cap = 0; }  // optional
     }

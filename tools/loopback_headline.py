@@ -12,7 +12,7 @@ from kafka_specification_amd.configs import HEADLINE
 from kafka_specification_amd import sharded
 g = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_kip320_3_6_6_2.json")))
 for P in ([int(x) for x in sys.argv[1:]] or [2, 4, 8]):
-    for exchange in ("rccl", "torch"):
+    for exchange in os.environ.get("KMC_LOOPBACK_EXCHANGES", "rccl torch").split():
         os.environ["KMC_EXCHANGE"] = exchange
         cfg = CheckerConfig(**HEADLINE, table_capacity=(1 << 30) // P, frontier_capacity=(1 << 26) // P,
                             send_capacity=max(1 << 18, (1 << 25) // (P * P) * 2))
@@ -29,4 +29,6 @@ for P in ([int(x) for x in sys.argv[1:]] or [2, 4, 8]):
         ok = r.distinct == g["distinct"] and r.generated == g["generated"] and r.levels == g["levels"]
         print(json.dumps(dict(shards=P, exchange="under the C ABI" if exchange == "rccl" else "torch slices", verdict=r.verdict,
                               distinct=r.distinct, matches_golden=ok, seconds=round(dt, 4),
-                              send_filtered=sharded.run_sharded.last_send_filtered)), flush=True)
+                              send_filtered=sharded.run_sharded.last_send_filtered,
+                              sender_filter=not int(os.environ.get("KMC_NO_SEND_FILTER", "0") or 0),
+                              seconds_expand_max_shard=round(r.seconds_expand, 4))), flush=True)

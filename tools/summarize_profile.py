@@ -37,9 +37,8 @@ n = out["kernel_trace"][exp]["calls"]
 t = out["kernel_trace"][exp]["total_ns"] * 1e-9
 der = {}
 if "FETCH_SIZE" in ctr:
-    # rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; the guide's gfx950 correction (x2) applies
-    # to wide coalesced streaming reads only -- this kernel's reads are dominated by random 8-B
-    # probes, so both the raw and the doubled figure are given.
+    # rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE is RDREQ x 64 B while this kernel's read
+    # requests are 128-byte line fills (random probes and streamed planes alike), so the x2 of the guide applies.
     der["fetch_bytes_raw"] = ctr["FETCH_SIZE"] * 1024
     der["fetch_bytes_x2_streaming_correction"] = 2 * ctr["FETCH_SIZE"] * 1024
 if "WRITE_SIZE" in ctr:
@@ -48,6 +47,18 @@ if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
     der["hbm_bytes_raw"] = der["fetch_bytes_raw"] + der["write_bytes_raw"]
     der["hbm_bytes_per_launch_raw"] = der["hbm_bytes_raw"] / n
     der["hbm_GBps_raw_over_kernel_time"] = der["hbm_bytes_raw"] / t / 1e9
+# The HBM byte count proper: 32-byte units of DRAM traffic by request kind (gfx950-only counters).  FETCH_SIZE is
+# RDREQ x 64 B on this tool although the requests of this kernel (random probes, streamed frontier planes) are 128-byte
+# line fills: profiles/r02_request_size.txt.
+if "TCC_EA0_RDREQ_DRAM_32B_sum" in ctr:
+    der["dram_read_bytes"] = 32 * ctr["TCC_EA0_RDREQ_DRAM_32B_sum"]
+if "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum" in ctr and "TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum" in ctr:
+    der["dram_write_bytes"] = 32 * ctr["TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"]
+    der["dram_atomic_bytes"] = 32 * ctr["TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum"]
+if "dram_read_bytes" in der and "dram_write_bytes" in der:
+    der["dram_bytes"] = der["dram_read_bytes"] + der["dram_write_bytes"] + der["dram_atomic_bytes"]
+    der["dram_bytes_per_launch"] = der["dram_bytes"] / n
+    der["dram_GBps_over_kernel_time"] = der["dram_bytes"] / t / 1e9
 if ctr.get("TCC_HIT_sum") is not None and "TCC_MISS_sum" in ctr:
     der["l2_hit_rate"] = ctr["TCC_HIT_sum"] / max(ctr["TCC_HIT_sum"] + ctr["TCC_MISS_sum"], 1)
 if "SQ_WAVE_CYCLES" in ctr:
@@ -63,11 +74,25 @@ print(js)
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(js)
 
-if len(sys.argv) > 3 and "hbm_bytes_raw" in der:
-    pm = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the run's {n} k_expand launches "
-                    "(tools/profile.sh); raw counter bytes — see the calibration file beside this one for what the counters "
-                    "report per random 8-byte access",
-          "device_source_sha256": out["device_source_sha256"],
-          "fetch_bytes": der["fetch_bytes_raw"], "write_bytes": der["write_bytes_raw"], "hbm_bytes": der["hbm_bytes_raw"],
-          "launches": n, "hbm_bytes_per_launch": der["hbm_bytes_per_launch_raw"]}
+if len(sys.argv) > 3 and ("dram_bytes" in der or "hbm_bytes_raw" in der):
+    if "dram_bytes" in der:
+        pm = {"source": f"rocprofv3 --pmc TCC_EA0_RDREQ_DRAM_32B_sum / TCC_EA0_WRREQ_WRITE_DRAM_32B_sum / "
+                        f"TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum (32-byte units of DRAM traffic, gfx950), separate passes, summed over "
+                        f"the run's {n} k_expand launches (tools/profile.sh)",
+              "read_bytes": der["dram_read_bytes"], "write_bytes": der["dram_write_bytes"],
+              "atomic_bytes": der["dram_atomic_bytes"], "hbm_bytes": der["dram_bytes"],
+              "hbm_bytes_per_launch": der["dram_bytes_per_launch"]}
+    else:
+        # the guide's rule for this tool: FETCH_SIZE counts 128-byte requests as 64 -> double it; WRITE_SIZE as reported
+        hb = der["fetch_bytes_x2_streaming_correction"] + der["write_bytes_raw"]
+        pm = {"source": f"rocprofv3 --pmc FETCH_SIZE (x2: gfx950 tallies 128-byte requests at 64 B) + WRITE_SIZE, separate "
+                        f"passes, summed over the run's {n} k_expand launches (tools/profile.sh)",
+              "read_bytes": der["fetch_bytes_x2_streaming_correction"], "write_bytes": der["write_bytes_raw"],
+              "hbm_bytes": hb, "hbm_bytes_per_launch": hb / n}
+    if "fetch_bytes_raw" in der:
+        pm["FETCH_SIZE_bytes_as_reported"] = der["fetch_bytes_raw"]
+    if "write_bytes_raw" in der:
+        pm["WRITE_SIZE_bytes_as_reported"] = der["write_bytes_raw"]
+    pm["device_source_sha256"] = out["device_source_sha256"]
+    pm["launches"] = n
     open(sys.argv[3], "w").write(json.dumps(pm, indent=1) + "\n")
