@@ -301,6 +301,12 @@ def main():
                      "kernel": "kmc_expand_*", "kernel_seconds_per_step": kernel_s, "launches_per_step": launches,
                      "algorithmic_bytes_per_launch": alg_bytes_per_state * distinct / max(launches, 1),
                      "algorithmic_bytes_per_distinct_state": alg_bytes_per_state,
+                     # SURVEY §8d asks for the granular figure beside the algorithmic one: what the same accesses cost
+                     # at the memory's granularity — a 128-byte line fill per probe (not the 64-byte sector the survey
+                     # assumed: profiles/r02_request_size.txt), a 64-byte atomic request per claim attempt
+                     "line_granular_bytes_per_distinct_state": 2 * S + 128 * g + 64 * claims / max(distinct, 1),
+                     "line_granular_GBps": (2 * S + 128 * g + 64 * claims / max(distinct, 1)) * distinct / max(kernel_s, 1e-12) / 1e9,
+                     "useful_fraction_ceiling_of_a_probe": 8.0 / 128.0,
                      "traffic_source": traffic_source, "random_access": random_access,
                      "device_source_sha256": device_source_sha256()[:16],
                      "note": "achieved = algorithmic bytes (2*S + 8*g + 8 per distinct state) over the summed durations "

@@ -8,3 +8,6 @@ make -s -C oracle
 ./oracle/kmc_oracle --model Kip320 --N 3 --L 5 --R 5 --E 2 --threads 8 --inv 7 > tests/golden/oracle_kip320_3_5_5_2.json
 ./oracle/kmc_oracle --model Kip320 --N 3 --L 6 --R 6 --E 2 --threads 8 --inv 7 > tests/golden/oracle_kip320_3_6_6_2.json
 ./oracle/kmc_oracle --model Kip279 --N 5 --L 2 --R 2 --E 1 --threads 8 --inv 1 > tests/golden/oracle_kip279_5_2_2_1.json   # BASELINE config 4 (TypeOk: exhaustive)
+# SURVEY §8d names two bindings for the headline: Kip320, and KafkaTruncateToHighWatermark with TypeOk only (its Next is built
+# purely from KafkaReplication.tla actions).  At LogSize 6 the latter outgrows the oracle's RAM; LogSize 5 (221 M states) is pinned.
+./oracle/kmc_oracle --model KafkaTruncateToHighWatermark --N 3 --L 5 --R 5 --E 2 --threads 8 --inv 1 > tests/golden/oracle_thw_3_5_5_2.json

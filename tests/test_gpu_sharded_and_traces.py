@@ -116,6 +116,22 @@ def test_headline_size_against_golden_fixture(name):
     assert sum(r.levels) == r.distinct and sum(r.action_generated.values()) + 1 == r.generated
 
 
+def test_truncate_to_hw_binding_of_the_headline_against_golden_fixture():
+    """SURVEY §8d's second binding of "KafkaReplication, 3 brokers": KafkaTruncateToHighWatermark (Next built purely from
+    KafkaReplication.tla's actions, KafkaTruncateToHighWatermark.tla:33-42) with TypeOk, at the largest LogSize the exact
+    CPU oracle still holds in RAM: 221,065,990 distinct states, 933 M generated, 736,602 deadlocked states."""
+    g = json.load(open(os.path.join(GOLDEN, "oracle_thw_3_5_5_2.json")))
+    cfg = CheckerConfig(model="KafkaTruncateToHighWatermark", n_replicas=g["N"], log_size=g["L"], max_records=g["R"],
+                        max_leader_epoch=g["E"], invariants=("TypeOk",), table_capacity=1 << 30, frontier_capacity=1 << 26)
+    with ModelChecker(cfg) as mc:
+        r = mc.run()
+    assert r.verdict == "ok" and r.queue_left == 0
+    assert (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
+    assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
+    assert r.deadlock_states == g["deadlock_states"]
+    assert sum(r.levels) == r.distinct and sum(r.action_generated.values()) + 1 == r.generated
+
+
 def test_headline_seed_independence_at_medium_size():
     cfgs = [CheckerConfig(model="Kip320", n_replicas=3, log_size=4, max_records=4, max_leader_epoch=2,
                           table_capacity=1 << 27, frontier_capacity=1 << 23, hash_seed=s) for s in (0, 12345)]
@@ -326,6 +342,26 @@ def test_sender_side_filter_drops_duplicates_but_not_states():
         assert sharded.run_sharded.last_send_filtered == 0
     finally:
         del os.environ["KMC_NO_SEND_FILTER"]
+    assert (r2.distinct, r2.generated, r2.levels) == (r.distinct, r.generated, r.levels)
+
+
+def test_eight_logical_shards_default_filter_policy():
+    """KMC_MAX_SHARDS logical shards: the largest plan the exchange supports, and the side of the sender-filter policy
+    (on for P <= 4, off beyond: profiles/r02_loopback_filter.jsonl) that the other loopback tests do not reach."""
+    from kafka_specification_amd import sharded
+    cfg = CheckerConfig(model="Kip320", n_replicas=3, log_size=3, max_records=3, max_leader_epoch=1,
+                        invariants=("TypeOk", "WeakIsr", "StrongIsr"), table_capacity=1 << 19, frontier_capacity=1 << 17,
+                        send_capacity=1 << 15)
+    o = kmo.Run(kmo.make_config("Kip320", N=3, L=3, R=3, E=1, invariants=("TypeOk", "WeakIsr", "StrongIsr")))
+    r = check_loopback(cfg, 8)
+    assert (r.verdict, r.distinct, r.generated, r.levels) == (o.verdict, o.distinct, o.generated, o.levels)
+    assert sharded.run_sharded.last_send_filtered == 0      # P = 8: no sender-side filter by default
+    os.environ["KMC_SEND_FILTER"] = "1"
+    try:
+        r2 = check_loopback(cfg, 8)
+        assert sharded.run_sharded.last_send_filtered > 0
+    finally:
+        del os.environ["KMC_SEND_FILTER"]
     assert (r2.distinct, r2.generated, r2.levels) == (r.distinct, r.generated, r.levels)
 
 
