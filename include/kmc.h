@@ -207,6 +207,9 @@ int kmc_witness(kmc_handle* h, uint64_t* words);
  * with kmc_successors on any shard. */
 int kmc_pred_of(kmc_handle* h, uint64_t fp, uint64_t* pred, int32_t* found);
 int kmc_init_state(kmc_handle* h, uint64_t* words);
+/* The shard that owns a fingerprint among n_shards (the partition k_expand buckets by: bits 40..63 of the fingerprint
+ * scaled onto 0..n_shards-1).  Pure function, no handle; -1 for n_shards outside 1..KMC_MAX_SHARDS. */
+int32_t kmc_owner_of(uint64_t fp, int32_t n_shards);
 
 const char* kmc_model_name(int32_t model);
 const char* kmc_action_name(int32_t model, int32_t kind);

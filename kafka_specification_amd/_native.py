@@ -105,6 +105,7 @@ SYMBOLS = [
     ("kmc_model_invariant_name", C.c_char_p, [C.c_int32, C.c_int32]),
     ("kmc_pred_of", C.c_int, [_H, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     ("kmc_init_state", C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    ("kmc_owner_of", C.c_int32, [C.c_uint64, C.c_int32]),
     ("kmc_step_begin", C.c_int, [_H]),
     ("kmc_step_expand", C.c_int, [_H, C.POINTER(C.c_uint64)]),
     ("kmc_step_send_buffer", C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),

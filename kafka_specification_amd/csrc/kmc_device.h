@@ -1208,25 +1208,29 @@ template <class M> struct KmcSink {
             const bool remote = valid && dst != a.shard;
             const bool ship = remote && (a.sent == nullptr || first_time(a.sent, a.sent_mask, fp));
             out.filtered += (u32)__popcll(__ballot(remote && !ship));
-            for (u32 d = 0; d < a.nshards; ++d) {  // wave-uniform
-                if (d == a.shard) continue;
-                const bool mine = ship && dst == d;
-                const u64 m = __ballot(mine);
-                if (m == 0) continue;
-                const int leader = __builtin_ctzll(m);
-                u64 base = 0;
-                if ((int)kmc_lane() == leader) base = atomicAdd(&a.ctl->send_count[d][sub].v, (u64)__popcll(m));
-                base = kmc_bcast64(base, leader);
-                if (mine) {
-                    const u64 pos = base + kmc_rank_in(m);
-                    if (pos < a.send_cap) {
-                        u64* rec = a.send + (((u64)d * KMC_SEGS + sub) * a.send_cap + pos) * (u64)a.rec_words;
+            // One atomic round trip per batch, not one per destination: lane d reserves destination d's run.  (A loop of
+            // "ballot, leader's atomicAdd, broadcast" per destination put up to P-1 dependent device-scope round trips
+            // of ~2 us into every flush: k_expand per shard 8.1 ms at P = 8 for work that takes 4.3 ms locally.)
+            u32 my_rank = 0, want = 0;   // this lane's rank among the batch's records for ITS destination; lane d: their number
+            for (u32 d = 0; d < a.nshards; ++d) {  // wave-uniform; no memory traffic in here
+                const u64 m = __ballot(ship && dst == d);
+                if (ship && dst == d) my_rank = kmc_rank_in(m);
+                if (kmc_lane() == d) want = (u32)__popcll(m);
+            }
+            u64 base = 0;
+            if (want) base = atomicAdd(&a.ctl->send_count[kmc_lane()][sub].v, (u64)want);   // lanes 0..P-1, all at once
+            // every record lane fetches the base of its destination's run from lane `dst`
+            const u32 src = ship ? dst : 0u;
+            const u32 lo = (u32)__shfl((int)(u32)base, (int)src), hi = (u32)__shfl((int)(u32)(base >> 32), (int)src);
+            if (ship) {
+                const u64 pos = (((u64)hi << 32) | lo) + my_rank;
+                if (pos < a.send_cap) {
+                    u64* rec = a.send + (((u64)dst * KMC_SEGS + sub) * a.send_cap + pos) * (u64)a.rec_words;
 #pragma unroll
-                        for (int k = 0; k < W; ++k) rec[k] = t[k];
-                        if (a.rec_words > (u32)W) rec[W] = meta;
-                    } else {
-                        atomicOr(&a.ctl->err, KMC_ERR_SEND_FULL);
-                    }
+                    for (int k = 0; k < W; ++k) rec[k] = t[k];
+                    if (a.rec_words > (u32)W) rec[W] = meta;
+                } else {
+                    atomicOr(&a.ctl->err, KMC_ERR_SEND_FULL);
                 }
             }
         } else {  // KMC_MODE_ENUM

@@ -1375,6 +1375,11 @@ int kmc_pred_of(kmc_handle* h, uint64_t fp, uint64_t* pred, int32_t* found) {
     return KMC_OK;
 }
 
+int32_t kmc_owner_of(uint64_t fp, int32_t n_shards) {
+    if (n_shards < 1 || n_shards > KMC_MAX_SHARDS) return -1;
+    return (int32_t)kmc_owner(fp, (uint32_t)n_shards);
+}
+
 int kmc_init_state(kmc_handle* h, uint64_t* words) {
     if (!h || !words) return fail(KMC_E_ARG, "null argument");
     if (h->init_words.empty()) return fail(KMC_E_STATE, "no run has started on this handle");

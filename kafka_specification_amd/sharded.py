@@ -166,7 +166,7 @@ class HipShardEngine:
         return self._viol_fp[inv_index]
 
     def owner(self, fp: int) -> int:
-        return (((fp >> 40) & 0xFFFFFF) * self.n_shards) >> 24          # kmc_owner (csrc/kmc_device.h)
+        return int(self.lib.kmc_owner_of(C.c_uint64(fp), self.n_shards))   # the partition k_expand buckets by (kmc_owner)
 
     def pred_of(self, fp: int):
         """Predecessor fingerprint recorded for fp in this shard's table, None when fp is not here."""
