@@ -28,6 +28,14 @@ RUNS = {
                                    invariants=("TypeOk", "WeakIsr", "StrongIsr")),
     "stretch_kip320_3_6_6_3_seed2": dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3,
                                          invariants=("TypeOk", "WeakIsr", "StrongIsr"), hash_seed=0x5EED2),
+    # SURVEY §8d's second binding of the headline, at the headline's LogSize: beyond the exact CPU oracle's RAM, so it is
+    # checked on the oracle's 21-level prefix and by agreement of two hash seeds
+    "stretch_truncate_to_hw_3_6_6_2": dict(model="KafkaTruncateToHighWatermark", n_replicas=3, log_size=6, max_records=6,
+                                           max_leader_epoch=2, invariants=("TypeOk",)),
+    "stretch_truncate_to_hw_3_6_6_2_seed2": dict(model="KafkaTruncateToHighWatermark", n_replicas=3, log_size=6, max_records=6,
+                                                 max_leader_epoch=2, invariants=("TypeOk",), hash_seed=0x5EED2),
+    "stretch_kip320_3_6_6_3_seed3": dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3,
+                                         invariants=("TypeOk", "WeakIsr", "StrongIsr"), hash_seed=0xC0FFEE),
     "violation_kip279_3_4_4_2": dict(model="Kip279", n_replicas=3, log_size=4, max_records=4, max_leader_epoch=2,
                                      invariants=("TypeOk", "StrongIsr"), keep_trace=True, table_capacity=1 << 28,
                                      frontier_capacity=1 << 24),
@@ -39,6 +47,10 @@ RUNS = {
 ORACLE_PREFIX = {
     "config3_kip279_5brokers_epoch2_levels": [1, 10, 110, 1220, 9000, 46140, 173465, 537555, 1489900, 3772630, 8765995, 18824715],
     "stretch_kip279_5brokers_exhaustive": [1, 10, 110, 1220, 9000, 46140, 173465, 537555, 1489900, 3772630, 8765995, 18824715],
+    "stretch_truncate_to_hw_3_6_6_2": [1, 6, 36, 207, 837, 2247, 4605, 9411, 20322, 44157, 97341, 215223, 463995, 940002, 1767177,
+                                       3130248, 5285973, 8506092, 13058256, 19043907, 26414805],
+    "stretch_truncate_to_hw_3_6_6_2_seed2": [1, 6, 36, 207, 837, 2247, 4605, 9411, 20322, 44157, 97341, 215223, 463995, 940002,
+                                             1767177, 3130248, 5285973, 8506092, 13058256, 19043907, 26414805],
     "config4_kip320_7brokers_log8_levels": [1, 14, 182, 2282, 27650, 130095, 1112202, 6530965, 33198956],
 }
 
