@@ -36,6 +36,9 @@ RUNS = {
                                                  max_leader_epoch=2, invariants=("TypeOk",), hash_seed=0x5EED2),
     "stretch_kip320_3_6_6_3_seed3": dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3,
                                          invariants=("TypeOk", "WeakIsr", "StrongIsr"), hash_seed=0xC0FFEE),
+    **{f"stretch_kip320_3_6_6_3_seed{k}": dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3,
+                                                invariants=("TypeOk", "WeakIsr", "StrongIsr"), hash_seed=0x1234567 * k)
+       for k in (4, 5, 6, 7)},
     "violation_kip279_3_4_4_2": dict(model="Kip279", n_replicas=3, log_size=4, max_records=4, max_leader_epoch=2,
                                      invariants=("TypeOk", "StrongIsr"), keep_trace=True, table_capacity=1 << 28,
                                      frontier_capacity=1 << 24),
