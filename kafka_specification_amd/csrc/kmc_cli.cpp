@@ -558,7 +558,8 @@ int main(int argc, char** argv) {
         printf("Fingerprint check: second run with fp seed %llu: %llu states generated, %llu distinct states found, depth %llu - %s\n",
                (unsigned long long)c2.hash_seed, (unsigned long long)r2.generated, (unsigned long long)r2.distinct,
                (unsigned long long)r2.depth,
-               same ? "identical to the first run." : "DIFFERENT from the first run: a fingerprint collision dropped states in at least one of them.");
+               same ? "identical to the first run." : "DIFFERENT from the first run: a fingerprint collision dropped states in at least one of them "
+                      "(a collision can only lose states: the larger count is the better lower bound).");
         if (!same && rc == 0) rc = 13;
     }
     printf("Finished in %.3fs (%.0f distinct states/s; %.3fs in the expand kernel) at (%s)\n", r.seconds_total,

@@ -189,7 +189,8 @@ def main(argv=None) -> int:
         same = (r2.verdict, r2.distinct, r2.generated, r2.depth) == (res.verdict, res.distinct, res.generated, res.depth)
         print(f"Fingerprint check: second run with fp seed {seed2}: {r2.generated} states generated, {r2.distinct} distinct "
               f"states found, depth {r2.depth} - " + ("identical to the first run." if same else
-              "DIFFERENT from the first run: a fingerprint collision dropped states in at least one of them."))
+              "DIFFERENT from the first run: a fingerprint collision dropped states in at least one of them "
+              "(a collision can only lose states: the larger count is the better lower bound)."))
         if not same and rc == 0:
             rc = 13
     print(f"Finished in {res.seconds_total:.3f}s ({res.distinct / max(res.seconds_total, 1e-9):,.0f} distinct states/s; "

@@ -1,0 +1,115 @@
+"""The measurement tooling (bench.py's profile readers, tools/summarize_profile.py) and the committed evidence under
+profiles/: the bench line keeps its contract, its side numbers are derived from files that say what they say, and the
+rocprofv3 summary agrees with the line it stands behind.  No GPU, no oracle."""
+import csv
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def bench():
+    return importlib.import_module("bench")
+
+
+def test_dram_bytes_per_access_are_read_from_the_committed_calibration(bench):
+    b7, src = bench.calibrated_bytes_per_access(7)          # the kernel's own mix: a load + a CAS for 35 %
+    assert src.endswith("dram_bytes_per_access.txt")
+    assert 140.0 < b7 < 160.0                                # 128 B line fill + 0.35 x 64 B atomic request
+    b1, _ = bench.calibrated_bytes_per_access(1)             # loads only: one 128-byte request each
+    assert abs(b1 - 128.0) < 1.0
+    assert bench.calibrated_bytes_per_access(42) is None     # a mode the file does not hold
+
+
+def test_traffic_is_quoted_only_for_the_device_code_it_was_measured_on(bench, monkeypatch):
+    t, src = bench.measured_traffic()
+    pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+    if pm["device_source_sha256"] == bench.device_source_sha256():
+        assert t == pm["hbm_bytes_per_launch"] and src == "profiles/r02_pmc_summary.json"
+        # the DRAM-unit counters, not FETCH_SIZE: reads are twice what FETCH_SIZE reports on gfx950
+        assert abs(pm["read_bytes"] / pm["FETCH_SIZE_bytes_as_reported"] - 2.0) < 0.01
+        assert abs(pm["hbm_bytes"] - (pm["read_bytes"] + pm["write_bytes"] + pm["atomic_bytes"])) < 1.0
+    monkeypatch.setattr(bench, "device_source_sha256", lambda: "0" * 64)
+    t2, why = bench.measured_traffic()
+    assert t2 is None and "other device code" in why
+
+
+def test_committed_bench_line_keeps_the_contract_and_is_self_consistent():
+    j = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["higher_is_better"] is True and j["vs_baseline"] is None and j["dtype"] == "u64"
+    assert "workload" in j["config"] and "model" not in j["config"] and j["config"]["matches_oracle_golden"] is True
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # achieved = algorithmic bytes per distinct state x distinct states / summed k_expand time
+    distinct = j["config"]["distinct_states"]
+    assert abs(r["achieved"] * 1e9 - r["algorithmic_bytes_per_distinct_state"] * distinct / r["kernel_seconds_per_step"]) \
+        < 1e-6 * r["achieved"] * 1e9
+    assert abs(r["algorithmic_bytes_per_launch"] * r["launches_per_step"] - r["algorithmic_bytes_per_distinct_state"] * distinct) < 1.0
+    # value = distinct states of the timed steps / wall time; the kernel fits inside the step
+    assert abs(j["value"] - distinct / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+    assert r["kernel_seconds_per_step"] * 1e3 <= j["ms_per_step"]
+    # measured traffic is well above the algorithmic bytes (one 128-byte line per 8-byte probe) and below the HBM peak
+    assert r["traffic"] > 4 * r["algorithmic_bytes_per_launch"]
+    assert r["traffic"] * r["launches_per_step"] / r["kernel_seconds_per_step"] < 8.0e12
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["unit"] == j["unit"] and c["cores"] >= 1
+
+
+def test_rocprof_kernel_stats_agree_with_the_bench_line():
+    j = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv"))))
+    top = rows[0]
+    assert top["Name"].startswith("kmc_expand_") and float(top["Percentage"]) > 90.0        # the dominant kernel
+    assert int(top["Calls"]) == j["roofline"]["launches_per_step"]
+    avg_prof = float(top["AverageNs"]) * 1e-9
+    avg_bench = j["roofline"]["kernel_seconds_per_step"] / j["roofline"]["launches_per_step"]
+    assert abs(avg_prof - avg_bench) / avg_bench < 0.05      # rocprofv3's average launch duration vs bench.py's HIP events
+
+
+def test_summarize_profile_derives_dram_bytes_from_the_32_byte_unit_counters(tmp_path):
+    d = tmp_path / "prof"
+    (d / "trace").mkdir(parents=True)
+    with open(d / "trace" / "x_kernel_trace.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp", "VGPR_Count", "LDS_Block_Size", "Scratch_Size",
+                    "Workgroup_Size", "Grid_Size"])
+        w.writerow(["kmc_expand_T", 1000, 2001000, 40, 0, 16, 256, 1024])
+        w.writerow(["kmc_expand_T", 3000000, 5000000, 40, 0, 16, 256, 1024])
+        w.writerow(["other", 0, 10, 8, 0, 0, 64, 64])
+
+    def pmc(i, rows):
+        (d / f"pmc{i}").mkdir()
+        with open(d / f"pmc{i}" / "pmc_counter_collection.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value"])
+            for r in rows:
+                w.writerow(r)
+    pmc(1, [["kmc_expand_T", "TCC_EA0_RDREQ_DRAM_32B_sum", 400], ["kmc_expand_T", "TCC_EA0_RDREQ_DRAM_32B_sum", 600],
+            ["other", "TCC_EA0_RDREQ_DRAM_32B_sum", 999]])
+    pmc(2, [["kmc_expand_T", "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", 10], ["kmc_expand_T", "TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum", 20]])
+    pmc(3, [["kmc_expand_T", "FETCH_SIZE", 15.625]])     # KiB: 500 requests x 64 B = half of the 32 000 bytes really read
+    pmc(4, [["kmc_expand_T", "WRITE_SIZE", 0.9375]])
+    out, pm = tmp_path / "summary.json", tmp_path / "pmc_summary.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_profile.py"), str(d), str(out), str(pm)],
+                          stdout=subprocess.DEVNULL)
+    s, p = json.load(open(out)), json.load(open(pm))
+    assert s["dominant_kernel"] == "kmc_expand_T" and s["launches"] == 2
+    assert s["derived"]["dram_read_bytes"] == 32 * 1000 and s["derived"]["dram_bytes"] == 32 * 1030
+    assert p["hbm_bytes"] == 32 * 1030 and p["hbm_bytes_per_launch"] == 32 * 1030 / 2
+    assert p["read_bytes"] == 2 * p["FETCH_SIZE_bytes_as_reported"]
+    assert len(p["device_source_sha256"]) == 64
