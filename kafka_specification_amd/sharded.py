@@ -717,11 +717,16 @@ def bench_sharded(c: dict, steps: int, warmup: int, backend: str = "nccl"):
     import torch
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    on_gpu = backend == "nccl"
+    if on_gpu and not torch.cuda.is_available():
+        # said here, before the process group is created, so that the message names the cause
+        raise RuntimeError(f"bench.py --gpus {os.environ.get('WORLD_SIZE', '?')}: no HIP device is visible to rank "
+                           f"{os.environ.get('RANK', '?')}; the multi-GPU leg runs one shard per GPU over RCCL "
+                           "(there is no CPU fallback)")
     if not dist.is_initialized():
         dist.init_process_group(backend=backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     local = int(os.environ.get("LOCAL_RANK", rank))
-    on_gpu = backend == "nccl"
     if on_gpu:
         if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
             raise RuntimeError(f"bench.py --gpus {world}: rank {rank} needs HIP device {local}, "
