@@ -109,3 +109,20 @@ def test_self_traffic_is_never_planned():
     for me in range(P):
         sends, recvs, nrec = plan(counts, P, me, 64, 3)
         assert all(p != me for p, _o, _w in sends + recvs) and nrec == 2 * SUBS * 5
+
+
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_mock_rccl_moves_planned_runs_between_concurrent_ranks(P, tmp_path):
+    """tests/mock_rccl.cpp is what stands in for librccl when the exchange under the C ABI runs with several ranks on
+    one GPU (tests/test_gpu_native_exchange_threads.py).  Its matching logic is checked here on CPU (plain memory): P
+    threads execute kmc_exchange_plan's runs for random count matrices — empty sub-buffers, full ones, a rank with
+    nothing to send — and every receive area must hold exactly what the peers addressed to it; a mismatched pair fails."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "mock_rccl_selfcheck")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-w", "-o", exe,
+                           os.path.join(here, "mock_rccl_selfcheck.cpp"), "-ldl"])
+    lib = os.path.join(os.path.dirname(here), "kafka_specification_amd", "libkmc.so")
+    p = subprocess.run([exe, lib, str(P), "12"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "selfcheck ok" in p.stdout, (p.stdout, p.stderr[-800:])

