@@ -25,6 +25,7 @@ def test_every_shipped_cfg_parses_and_binds():
     for path in glob.glob(os.path.join(ROOT, "models", "*.cfg")):
         name = os.path.splitext(os.path.basename(path))[0]
         module = {"Kip279_5brokers": "Kip279", "Kip320_7brokers": "Kip320", "LeaderInIsr": "Kip320",
+                  "KafkaTruncateToHighWatermark_3brokers": "KafkaTruncateToHighWatermark",
                   "MCAsyncIsr_small": "MCAsyncIsr", "MCAsyncIsr_outside": "MCAsyncIsr"}.get(name, name)
         c = to_checker_config(module, parse_cfg(open(path).read()))
         c.to_native()

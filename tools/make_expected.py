@@ -25,10 +25,12 @@ from kafka_specification_amd.cfg import MODULE_TO_MODEL, parse_cfg, to_checker_c
 
 # .cfg -> root module (TLC takes the module from the command line; several twins share one module)
 MODULE_OF = {"Kip279_5brokers": "Kip279", "Kip320_7brokers": "Kip320", "LeaderInIsr": "Kip320",
+             "KafkaTruncateToHighWatermark_3brokers": "KafkaTruncateToHighWatermark",
              "MCAsyncIsr_outside": "MCAsyncIsr", "MCAsyncIsr_small": "MCAsyncIsr"}
 NOT_EXHAUSTIBLE = {"Kip320_7brokers": "8.8e8 states in the first 11 levels (profiles/r01_ladder.jsonl)"}
 GOLDEN = {"Kip320": os.path.join(ROOT, "tests", "golden", "oracle_kip320_3_6_6_2.json"),
-          "Kip279_5brokers": os.path.join(ROOT, "tests", "golden", "oracle_kip279_5_2_2_1.json")}
+          "Kip279_5brokers": os.path.join(ROOT, "tests", "golden", "oracle_kip279_5_2_2_1.json"),
+          "KafkaTruncateToHighWatermark_3brokers": os.path.join(ROOT, "tests", "golden", "oracle_thw_3_5_5_2.json")}
 
 
 def oracle_cfg(cc, **kw):
