@@ -244,6 +244,34 @@ class NativeLoopbackExchange:
         pass
 
 
+class _watchdog:
+    """A collective that never completes (a rank missing, a transport that does not come up) blocks inside the library,
+    where no exception can reach it, and a multi-GPU job that hangs tells its user nothing.  After KMC_COLLECTIVE_TIMEOUT
+    seconds (default 180) the rank says what it was waiting for and exits with status 3; the launcher then ends the other
+    ranks.  Used around the communicator's creation and its self-test — the two places where "never" shows first."""
+
+    def __init__(self, what, rank):
+        self.what, self.rank = what, rank
+        self.limit = float(os.environ.get("KMC_COLLECTIVE_TIMEOUT", "180"))
+
+    def _give_up(self):
+        import sys
+        print(f"[kmc] rank {self.rank}: {self.what} did not complete within {self.limit:.0f} s — giving up instead of hanging",
+              file=sys.stderr, flush=True)
+        os._exit(3)
+
+    def __enter__(self):
+        import threading
+        self.timer = threading.Timer(self.limit, self._give_up)
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
 class RcclExchange:
     """One native HipShardEngine per process, one process per GPU: the per-level exchange under the C ABI
     (kmc_step_exchange_counts / kmc_step_exchange_payload: an RCCL all-gather of counts + statistics, grouped
@@ -271,10 +299,13 @@ class RcclExchange:
         if not isinstance(box[0], bytes):
             raise nat.KmcError(2, f"rank 0 could not create an RCCL unique id: {box[0]}")
         uid = (C.c_uint8 * nat.KMC_COMM_ID_BYTES)(*box[0])
-        nat.check(self.lib.kmc_comm_init(engine.mc.handle, uid))
+        with _watchdog("ncclCommInitRank (every rank of the job has to join the communicator)", self.rank):
+            nat.check(self.lib.kmc_comm_init(engine.mc.handle, uid))
 
     def selftest(self):
-        nat.check(self.lib.kmc_comm_selftest(self.engine.mc.handle))
+        with _watchdog("the exchange self-test (an all-gather and a send/receive ring over RCCL on the engine's stream)",
+                       getattr(self, "rank", "?")):
+            nat.check(self.lib.kmc_comm_selftest(self.engine.mc.handle))
 
     def exchange(self, sends, stats):
         (st,) = stats

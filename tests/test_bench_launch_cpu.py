@@ -70,3 +70,19 @@ def test_tlc_front_end_under_torchrun_shards_over_the_ranks():
     assert f"State {o.viol_depth}: <" in out and f"State {o.viol_depth + 1}: <" not in out
     assert f"{o.generated} states generated, {o.distinct} distinct states found" in out
     assert p.returncode != 0                                                   # TLC's exit code 12 travels through the launcher
+
+
+def test_a_collective_that_never_completes_ends_the_rank_with_a_message():
+    """sharded._watchdog guards the communicator's creation and its self-test: a rank that would hang inside the library
+    says what it was waiting for and exits with status 3 (the launcher then ends the others); when the call returns in
+    time nothing happens."""
+    import subprocess
+    import sys
+    code = ("import os, sys, time\nsys.path.insert(0, %r)\nos.environ['KMC_COLLECTIVE_TIMEOUT'] = '1'\n"
+            "from kafka_specification_amd.sharded import _watchdog\n"
+            "with _watchdog('a pretend collective', 5):\n    time.sleep(%s)\nprint('returned')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code % (root, 30)], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3 and "a pretend collective did not complete within 1 s" in p.stderr and "returned" not in p.stdout
+    p = subprocess.run([sys.executable, "-c", code % (root, 0)], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "returned" in p.stdout
