@@ -832,6 +832,14 @@ static inline uint64_t hash_bytes(const uint8_t *b, int n) {
     return h;
 }
 
+/* Fingerprint-only mode (CLI --fp-only, or KMO_FP_ONLY=1): the table holds this file's own 64-bit hash of a state's
+ * canonical bytes instead of a reference to the stored state, so states of finished levels can be thrown away and a
+ * search far beyond the exact mode's RAM fits (8 B per state in the table + two levels of states).  It is NOT exact any
+ * more — two states with one hash lose a state, n^2 / 2^65 expected — but it is an engine-independent second opinion on
+ * the GPU's counts where the exact mode cannot go: another hash function over another state encoding, another table,
+ * another BFS.  Parent links (traces) are meaningless in this mode.  --table-log2 N fixes the table size (no growth). */
+static int g_fp_only = 0;
+static int g_table_log2 = 0;
 #define SLOT_BUSY 1ull
 /* returns 1 when the state was new (and stores it with parent/action) */
 /* Arena indices are handed out in blocks of IDX_BLOCK per worker: one shared fetch-add per new state serialised the
@@ -857,6 +865,26 @@ static int engine_insert(Engine *e, const uint8_t *st, uint64_t parent, int acti
             return 0;
         }
         uint64_t v = atomic_load_explicit(&e->table[i], memory_order_acquire);
+        if (g_fp_only) {
+            const uint64_t hv = h < 2 ? h + 2 : h; /* never 0 (empty) */
+            if (v == 0) {
+                uint64_t exp = 0;
+                if (atomic_compare_exchange_strong(&e->table[i], &exp, hv)) {
+                    uint64_t idx = take_index(e, blk_next, blk_end);
+                    ensure_chunk(e, idx);
+                    uint8_t *r = rec_ptr(e, idx);
+                    memcpy(r, st, sb);
+                    memset(r + sb, 0xFF, 4);
+                    r[sb + 4] = (uint8_t)action;
+                    return 1;
+                }
+                continue; /* somebody else took the slot: re-read it */
+            }
+            if (v == hv) return 0;
+            probes++;
+            i = (i + 1) & (e->cap - 1);
+            continue;
+        }
         if (v == 0) {
             uint64_t exp = 0;
             if (atomic_compare_exchange_strong(&e->table[i], &exp, SLOT_BUSY)) {
@@ -937,6 +965,15 @@ static void rehash_slice(void *a, uint64_t lo, uint64_t hi) {
     }
 }
 static void engine_grow(Engine *e, uint64_t want, int T) {
+    if (g_fp_only && e->cap) {
+        /* the table cannot be rebuilt from states that are no longer kept: it has its final size from the start */
+        if (atomic_load(&e->nstates) > e->cap - e->cap / 8) {
+            fprintf(stderr, "kmc_oracle: --fp-only table of 2^%d slots is full; rerun with a larger --table-log2\n", g_table_log2);
+            abort();
+        }
+        return;
+    }
+    if (g_fp_only) want = 1ull << (g_table_log2 ? g_table_log2 : 28);
     uint64_t cap = e->cap ? e->cap : 1024;
     while (cap < want) cap <<= 1;
     if (cap == e->cap) return;
@@ -1013,6 +1050,7 @@ static void compact_level(Engine *e, Worker *ws, int T, uint64_t lo) {
         /* src >= new_top holds a state: move it to dst and repoint its table entry */
         uint8_t *from = rec_ptr(e, src), *to = rec_ptr(e, dst);
         memcpy(to, from, e->rs);
+        if (g_fp_only) continue; /* the table holds hashes, not references */
         uint64_t h = hash_bytes(to, e->p.sb), tag = (h >> 40) << 40, i = h & (e->cap - 1);
         for (;;) {
             uint64_t v = atomic_load_explicit(&e->table[i], memory_order_relaxed);
@@ -1082,6 +1120,8 @@ void *kmo_run(const kmo_config *cfg, kmo_result *res) {
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     memset(res, 0, sizeof *res);
+    if (getenv("KMO_FP_ONLY") && atoi(getenv("KMO_FP_ONLY"))) g_fp_only = 1;
+    if (getenv("KMO_TABLE_LOG2")) g_table_log2 = atoi(getenv("KMO_TABLE_LOG2"));
     Engine *e = calloc(1, sizeof *e);
     e->cfg = *cfg;
     if (!setup_params(&e->p, cfg)) {
@@ -1216,6 +1256,12 @@ void *kmo_run(const kmo_config *cfg, kmo_result *res) {
             res->verdict = V_DEADLOCK;
             break;
         }
+        if (g_fp_only) /* the states of the level just expanded are never read again */
+            for (uint64_t c = lo >> CHUNK_BITS; c < (hi >> CHUNK_BITS); c++)
+                if (e->chunks[c]) {
+                    free(e->chunks[c]);
+                    e->chunks[c] = NULL;
+                }
         lo = hi;
         hi = atomic_load(&e->nstates);
         if (hi == lo) break;
@@ -1304,6 +1350,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--continue")) c.stop_on_violation = 0;
         else if (!strcmp(argv[i], "--deadlock")) c.check_deadlock = 1;
         else if (!strcmp(argv[i], "--max-states")) c.max_states = strtoull(argv[++i], NULL, 0);
+        else if (!strcmp(argv[i], "--fp-only")) g_fp_only = 1;
+        else if (!strcmp(argv[i], "--table-log2")) g_table_log2 = atoi(argv[++i]);
         else {
             fprintf(stderr, "unknown arg %s\n", argv[i]);
             return 2;
@@ -1313,12 +1361,12 @@ int main(int argc, char **argv) {
     void *h = kmo_run(&c, &r);
     printf("{\"model\": \"%s\", \"N\": %d, \"L\": %d, \"R\": %d, \"E\": %d, \"distinct\": %llu, \"generated\": %llu, "
            "\"depth\": %llu, \"verdict\": %d, \"viol_inv\": %d, \"viol_depth\": %llu, \"viol_count\": [%llu,%llu,%llu,%llu], "
-           "\"deadlock_states\": %llu, \"threads\": %d, \"seconds\": %.3f, \"levels\": [",
+           "\"deadlock_states\": %llu, \"threads\": %d, \"seconds\": %.3f, \"fp_only\": %d, \"levels\": [",
            c.model >= 0 ? MODEL_NAMES[c.model] : "?", c.N, c.L, c.R, c.E, (unsigned long long)r.distinct,
            (unsigned long long)r.generated, (unsigned long long)r.depth, r.verdict, r.viol_inv,
            (unsigned long long)r.viol_depth, (unsigned long long)r.viol_count[0], (unsigned long long)r.viol_count[1],
            (unsigned long long)r.viol_count[2], (unsigned long long)r.viol_count[3],
-           (unsigned long long)r.deadlock_states, c.threads, r.seconds);
+           (unsigned long long)r.deadlock_states, c.threads, r.seconds, g_fp_only);
     for (uint64_t i = 0; i < r.nlevels && i < KMO_MAX_LEVELS; i++)
         printf("%s%llu", i ? "," : "", (unsigned long long)r.levels[i]);
     printf("], \"action_generated\": [");

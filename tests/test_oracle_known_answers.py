@@ -159,3 +159,23 @@ def test_golden_fixtures_are_consistent():
         assert sum(g["levels"]) == g["distinct"] and len(g["levels"]) == g["depth"]
         assert sum(g["action_generated"]) + 1 == g["generated"]
         assert g["verdict"] == 0 and g["levels"][:3] == [1, 2 * n, n * (5 * n - 3)]
+
+
+def test_fingerprint_only_mode_of_the_c_oracle_agrees_with_its_exact_mode():
+    """oracle/kmc_oracle --fp-only keeps 64-bit hashes instead of states (so that searches beyond the exact mode's RAM
+    fit: the 810 M-state KafkaTruncateToHighWatermark 3/6/6/2 run that cross-checks the GPU's count).  Where both modes
+    fit they must report the same numbers."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "kmc_oracle")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe)])
+    runs = []
+    for extra in ([], ["--fp-only", "--table-log2", "22"]):
+        out = subprocess.run([exe, "--model", "Kip320", "--N", "3", "--L", "3", "--R", "3", "--E", "1", "--threads", "4",
+                              "--inv", "7"] + extra, capture_output=True, text=True, timeout=300).stdout
+        runs.append(json.loads(out))
+    a, b = runs
+    assert (a["fp_only"], b["fp_only"]) == (0, 1)
+    for k in ("distinct", "generated", "depth", "levels", "action_generated", "deadlock_states", "verdict"):
+        assert a[k] == b[k], k
+    assert a["distinct"] == 176440
