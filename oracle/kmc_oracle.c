@@ -840,6 +840,35 @@ static inline uint64_t hash_bytes(const uint8_t *b, int n) {
  * another BFS.  Parent links (traces) are meaningless in this mode.  --table-log2 N fixes the table size (no growth). */
 static int g_fp_only = 0;
 static int g_table_log2 = 0;
+/* The exact mode's hash_bytes only spreads states over the table (a state is confirmed by memcmp), and one
+ * multiply-xorshift round per 8 bytes is enough for that.  It is NOT enough to BE the state: on the 810 M-state
+ * KafkaTruncateToHighWatermark 3/6/6/2 run it lost 23,131 states to systematic collisions (the same lesson the GPU's
+ * fingerprint taught at 7.6e7 states).  Fingerprint-only mode therefore absorbs every 8 bytes through
+ * a full-avalanche finaliser — murmur3's fmix64, not the splitmix64 constants of the GPU's kmc_fingerprint, over this
+ * file's byte-per-field encoding, not the GPU's bit packing: an independent function of an independent representation. */
+static inline uint64_t fmix64(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+static inline uint64_t hash_bytes_strong(const uint8_t *b, int n) {
+    uint64_t h = fmix64(0x2545F4914F6CDD1Dull + (uint64_t)n);
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, b + i, 8);
+        h = fmix64(h ^ w) + 0x9E3779B97F4A7C15ull;
+    }
+    if (i < n) {
+        uint64_t w = 0;
+        memcpy(&w, b + i, n - i);
+        h = fmix64(h ^ w) + 0x9E3779B97F4A7C15ull;
+    }
+    return fmix64(h);
+}
 #define SLOT_BUSY 1ull
 /* returns 1 when the state was new (and stores it with parent/action) */
 /* Arena indices are handed out in blocks of IDX_BLOCK per worker: one shared fetch-add per new state serialised the
@@ -856,7 +885,7 @@ static uint64_t take_index(Engine *e, uint64_t *blk_next, uint64_t *blk_end) {
 }
 static int engine_insert(Engine *e, const uint8_t *st, uint64_t parent, int action, uint64_t *blk_next, uint64_t *blk_end) {
     int sb = e->p.sb;
-    uint64_t h = hash_bytes(st, sb);
+    uint64_t h = g_fp_only ? hash_bytes_strong(st, sb) : hash_bytes(st, sb);
     uint64_t tag = (h >> 40) << 40; /* high 24 bits */
     uint64_t i = h & (e->cap - 1);
     for (uint64_t probes = 0;;) {

@@ -11,3 +11,7 @@ make -s -C oracle
 # SURVEY §8d names two bindings for the headline: Kip320, and KafkaTruncateToHighWatermark with TypeOk only (its Next is built
 # purely from KafkaReplication.tla actions).  At LogSize 6 the latter outgrows the oracle's RAM; LogSize 5 (221 M states) is pinned.
 ./oracle/kmc_oracle --model KafkaTruncateToHighWatermark --N 3 --L 5 --R 5 --E 2 --threads 8 --inv 1 > tests/golden/oracle_thw_3_5_5_2.json
+# ... and at the headline's LogSize 6 (810,380,080 states) in the oracle's fingerprint-only mode: 17 GB and ~10 minutes on 8
+# cores where the exact mode would need ~90 GB.  Not exact (n^2/2^65 = 0.02 expected collisions), but a hash, an encoding, a
+# table and a BFS that share nothing with the GPU's.
+./oracle/kmc_oracle --model KafkaTruncateToHighWatermark --N 3 --L 6 --R 6 --E 2 --threads 8 --inv 1 --fp-only --table-log2 31 > tests/golden/oracle_fp_thw_3_6_6_2.json

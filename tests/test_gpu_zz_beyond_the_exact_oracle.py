@@ -1,0 +1,27 @@
+"""GPU: the second binding SURVEY 8d names for "KafkaReplication.tla, 3 brokers, maxLogLen=6" — KafkaTruncateToHighWatermark,
+whose Next (KafkaTruncateToHighWatermark.tla:33-42) is built purely from KafkaReplication.tla's actions — at the headline's
+own constants.  810,380,080 distinct states: more than the exact CPU oracle can hold, so the fixture comes from the oracle's
+fingerprint-only mode (tests/golden/oracle_fp_thw_3_6_6_2.json: another hash over another state encoding, another table,
+another BFS).  (The file name sorts last on purpose: the largest single-GPU test of the suite.)"""
+import json
+import os
+
+import pytest
+
+from kafka_specification_amd import CheckerConfig, ModelChecker
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_truncate_to_hw_at_the_headline_constants_matches_the_fingerprint_only_oracle():
+    g = json.load(open(os.path.join(GOLDEN, "oracle_fp_thw_3_6_6_2.json")))
+    cfg = CheckerConfig(model="KafkaTruncateToHighWatermark", n_replicas=g["N"], log_size=g["L"], max_records=g["R"],
+                        max_leader_epoch=g["E"], invariants=("TypeOk",), table_capacity=1 << 31, frontier_capacity=1 << 27)
+    with ModelChecker(cfg) as mc:
+        r = mc.run()
+    assert r.verdict == "ok" and r.queue_left == 0
+    assert (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
+    assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
+    assert r.deadlock_states == g["deadlock_states"]
+    assert sum(r.levels) == r.distinct and sum(r.action_generated.values()) + 1 == r.generated

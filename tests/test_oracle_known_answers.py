@@ -179,3 +179,22 @@ def test_fingerprint_only_mode_of_the_c_oracle_agrees_with_its_exact_mode():
     for k in ("distinct", "generated", "depth", "levels", "action_generated", "deadlock_states", "verdict"):
         assert a[k] == b[k], k
     assert a["distinct"] == 176440
+
+
+def test_fp_only_fixture_of_the_headline_truncate_to_hw_binding_equals_the_gpu_record():
+    """KafkaTruncateToHighWatermark at the headline's constants (3 brokers, LogSize 6): 810,380,080 states — beyond the
+    exact oracle's RAM, so the CPU side is the oracle's fingerprint-only mode (tests/golden/oracle_fp_thw_3_6_6_2.json, ten
+    minutes on 8 cores).  The GPU's committed runs of the same binding (profiles/r02_ladder.jsonl, two hash seeds) report
+    the same distinct / generated / depth and the same first and last levels: three unrelated 64-bit hash functions agree."""
+    g = json.load(open(os.path.join(GOLDEN, "oracle_fp_thw_3_6_6_2.json")))
+    assert g["fp_only"] == 1 and g["verdict"] == 0
+    assert sum(g["levels"]) == g["distinct"] == 810380080 and len(g["levels"]) == g["depth"] == 52
+    assert sum(g["action_generated"]) + 1 == g["generated"] == 3462005758
+    assert g["levels"][:3] == [1, 6, 36]
+    ladder = os.path.join(os.path.dirname(GOLDEN), "..", "profiles", "r02_ladder.jsonl")
+    runs = [json.loads(l) for l in open(ladder) if "stretch_truncate_to_hw_3_6_6_2" in l]
+    assert len(runs) >= 2 and len({r["config"].get("hash_seed", 0) for r in runs}) >= 2
+    for r in runs:
+        assert (r["verdict"], r["distinct"], r["generated"], r["depth"]) == ("ok", g["distinct"], g["generated"], g["depth"])
+        assert r["levels_head"] == g["levels"][:len(r["levels_head"])] and r["levels_tail"] == g["levels"][-len(r["levels_tail"]):]
+        assert r["widest_level"] == max(g["levels"])
