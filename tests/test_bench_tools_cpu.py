@@ -113,3 +113,16 @@ def test_summarize_profile_derives_dram_bytes_from_the_32_byte_unit_counters(tmp
     assert p["hbm_bytes"] == 32 * 1030 and p["hbm_bytes_per_launch"] == 32 * 1030 / 2
     assert p["read_bytes"] == 2 * p["FETCH_SIZE_bytes_as_reported"]
     assert len(p["device_source_sha256"]) == 64
+
+
+def test_ladder_tool_configurations_are_valid_bindings():
+    """tools/run_ladder.py: every configuration of the ladder is a binding the ABI accepts, every oracle prefix belongs
+    to one of them and starts with the known first levels 1, 2N."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    ladder = importlib.import_module("run_ladder")
+    from kafka_specification_amd import CheckerConfig
+    for name, c in ladder.RUNS.items():
+        CheckerConfig(**c).to_native()
+    for name, levels in ladder.ORACLE_PREFIX.items():
+        assert name in ladder.RUNS
+        assert levels[:2] == [1, 2 * ladder.RUNS[name]["n_replicas"]]
