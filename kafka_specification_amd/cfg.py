@@ -72,7 +72,10 @@ def parse_cfg(text: str) -> ModelCfg:
             i += 1
             continue
         if section in ("CONSTANT", "CONSTANTS"):
-            if i + 2 < len(toks) + 1 and i + 1 < len(toks) and toks[i + 1] in ("=", "<-"):
+            if i + 1 < len(toks) and toks[i + 1] == "<-":
+                raise CfgError(f"`{t} <- ...` (substitution by an operator of the spec) is not supported: no TLA+ is parsed, "
+                               "so a replaced definition cannot be honoured; assign a value with `=`")
+            if i + 2 < len(toks) + 1 and i + 1 < len(toks) and toks[i + 1] == "=":
                 if i + 2 >= len(toks):
                     raise CfgError(f"constant {t} has no value")
                 cfg.constants[t] = _parse_value(toks[i + 2])
@@ -119,8 +122,14 @@ def to_checker_config(module: str, cfg: ModelCfg, **overrides) -> CheckerConfig:
             raise CfgError(f"constant {name} is not assigned in the .cfg")
         return c[name]
 
+    def need_int(name):
+        v = need(name)
+        if isinstance(v, bool) or not isinstance(v, int):
+            raise CfgError(f"constant {name} must be an integer, got {v!r}")
+        return v
+
     if module == "IdSequence":
-        kw["max_id"] = int(need("MaxId"))
+        kw["max_id"] = need_int("MaxId")
         allowed_inv = {"TypeOk"}
     elif model == "AsyncIsr":
         # AsyncIsr.tla:22-29 + MaxVersion / StateConstraint of models/MCAsyncIsr.tla
@@ -129,19 +138,19 @@ def to_checker_config(module: str, cfg: ModelCfg, **overrides) -> CheckerConfig:
             raise CfgError("Replicas must be a set of distinct model values")
         if str(need("Leader")) not in map(str, reps):
             raise CfgError("Leader must be an element of Replicas (ASSUME Leader \\in Replicas, AsyncIsr.tla:29)")
-        if int(need("MaxOffset")) <= 0:
+        if need_int("MaxOffset") <= 0:
             raise CfgError("MaxOffset must be positive (ASSUME MaxOffset > 0, AsyncIsr.tla:28)")
         if cfg.constraints != ["StateConstraint"]:
             raise CfgError("MCAsyncIsr needs exactly `CONSTRAINT StateConstraint`: AsyncIsr is unbounded without it")
         # the engine numbers the replicas with Leader first; the others keep their order
-        kw.update(n_replicas=len(reps), log_size=int(need("MaxOffset")), max_leader_epoch=int(need("MaxVersion")))
+        kw.update(n_replicas=len(reps), log_size=need_int("MaxOffset"), max_leader_epoch=need_int("MaxVersion"))
         allowed_inv = set(ASYNC_INVARIANTS)
     elif module == "FiniteReplicatedLog":
         reps, recs = need("Replicas"), need("LogRecords")
         if not isinstance(reps, list) or not isinstance(recs, list):
             raise CfgError("Replicas and LogRecords must be sets of model values")
         need("Nil")
-        kw.update(n_replicas=len(reps), n_log_records=len(recs), log_size=int(need("LogSize")))
+        kw.update(n_replicas=len(reps), n_log_records=len(recs), log_size=need_int("LogSize"))
         allowed_inv = {"TypeOk"}
     else:
         reps = need("Replicas")
@@ -149,11 +158,14 @@ def to_checker_config(module: str, cfg: ModelCfg, **overrides) -> CheckerConfig:
             raise CfgError("Replicas must be a set of distinct model values")
         if "NONE" in map(str, reps):
             raise CfgError('Replicas must not contain "NONE" (ASSUME None \\notin Replicas, KafkaReplication.tla:42)')
-        kw.update(n_replicas=len(reps), log_size=int(need("LogSize")), max_records=int(need("MaxRecords")),
-                  max_leader_epoch=int(need("MaxLeaderEpoch")))
+        kw.update(n_replicas=len(reps), log_size=need_int("LogSize"), max_records=need_int("MaxRecords"),
+                  max_leader_epoch=need_int("MaxLeaderEpoch"))
         allowed_inv = set(INVARIANTS)
     if cfg.specification is not None and cfg.specification != "Spec":
         raise CfgError("only SPECIFICATION Spec is known")
+    if cfg.specification is not None and (cfg.init is not None or cfg.next is not None):
+        # [TLC-recall] TLC refuses the combination too (EC.TLC_CONFIG_NOT_BOTH_SPEC_AND_INIT)
+        raise CfgError("a .cfg gives either SPECIFICATION or INIT / NEXT, not both")
     if cfg.init not in (None, "Init") or cfg.next not in (None, "Next"):
         raise CfgError("only INIT Init / NEXT Next are known")
     for inv in cfg.invariants:

@@ -162,6 +162,7 @@ struct Cfg {
     std::map<std::string, std::string> constants;  // raw value text ("{b1, b2}" or "6")
     std::vector<std::string> invariants, constraints;
     int check_deadlock = 1;  // TLC's default
+    bool has_init_next = false, has_specification = false;
     std::string error;
 };
 
@@ -194,11 +195,11 @@ std::vector<std::string> tokenize(const std::string& s) {
             t.push_back("=");
             ++i;
         } else if (s.compare(i, 2, "<-") == 0) {
-            t.push_back("=");
+            t.push_back("<-");
             i += 2;
         } else {
             size_t e = i;
-            while (e < s.size() && !isspace((unsigned char)s[e]) && s[e] != '=' && s[e] != '{') ++e;
+            while (e < s.size() && !isspace((unsigned char)s[e]) && s[e] != '=' && s[e] != '{' && s.compare(e, 2, "<-") != 0) ++e;
             t.push_back(s.substr(i, e - i));
             i = e;
         }
@@ -231,6 +232,11 @@ Cfg parse_cfg(const std::string& text) {
             continue;
         }
         if (section == "CONSTANT" || section == "CONSTANTS") {
+            if (i + 1 < t.size() && t[i + 1] == "<-") {
+                c.error = "`" + w + " <- ...` (substitution by an operator of the spec) is not supported: no TLA+ is parsed, so a "
+                          "replaced definition cannot be honoured; assign a value with `=`";
+                return c;
+            }
             if (i + 2 < t.size() + 0 && t[i + 1] == "=") {
                 c.constants[w] = t[i + 2];
                 i += 2;
@@ -240,10 +246,13 @@ Cfg parse_cfg(const std::string& text) {
             }
         } else if (section == "INIT") {
             if (w != "Init") c.error = "only INIT Init is known";
+            c.has_init_next = true;
         } else if (section == "NEXT") {
             if (w != "Next") c.error = "only NEXT Next is known";
+            c.has_init_next = true;
         } else if (section == "SPECIFICATION") {
             if (w != "Spec") c.error = "only SPECIFICATION Spec is known";
+            c.has_specification = true;
         } else if (section == "INVARIANT" || section == "INVARIANTS") {
             c.invariants.push_back(w);
         } else if (section == "CONSTRAINT" || section == "CONSTRAINTS") {
@@ -255,6 +264,8 @@ Cfg parse_cfg(const std::string& text) {
         }
         if (!c.error.empty()) return c;
     }
+    // [TLC-recall] TLC refuses the combination too (EC.TLC_CONFIG_NOT_BOTH_SPEC_AND_INIT)
+    if (c.has_init_next && c.has_specification) c.error = "a .cfg gives either SPECIFICATION or INIT / NEXT, not both";
     return c;
 }
 
@@ -432,8 +443,18 @@ int main(int argc, char** argv) {
         if (it == cfg.constants.end()) { fprintf(stderr, "Error: constant %s is not assigned in the .cfg\n", name); exit(2); }
         return it->second;
     };
+    auto need_int = [&](const char* name) -> long long {
+        const std::string v = need(name);
+        char* end = nullptr;
+        const long long x = strtoll(v.c_str(), &end, 10);
+        if (v.empty() || end == v.c_str() || *end != 0) {
+            fprintf(stderr, "Error: constant %s must be an integer, got %s\n", name, v.c_str());
+            exit(2);
+        }
+        return x;
+    };
     if (c.model == KMC_IDSEQUENCE) {
-        c.max_id = atoll(need("MaxId").c_str());
+        c.max_id = need_int("MaxId");
     } else if (c.model == KMC_ASYNC_ISR) {
         const std::string reps = need("Replicas"), leader = need("Leader");
         if (reps.find(leader) == std::string::npos) {
@@ -445,13 +466,13 @@ int main(int argc, char** argv) {
             return 2;
         }
         c.n_replicas = set_size(reps);
-        c.log_size = atoi(need("MaxOffset").c_str());
-        c.max_leader_epoch = atoi(need("MaxVersion").c_str());
+        c.log_size = (int32_t)need_int("MaxOffset");
+        c.max_leader_epoch = (int32_t)need_int("MaxVersion");
     } else if (c.model == KMC_FINITE_REPLICATED_LOG) {
         c.n_replicas = set_size(need("Replicas"));
         c.n_log_records = set_size(need("LogRecords"));
         need("Nil");
-        c.log_size = atoi(need("LogSize").c_str());
+        c.log_size = (int32_t)need_int("LogSize");
     } else {
         const std::string reps = need("Replicas");
         if (reps.find("NONE") != std::string::npos) {
@@ -459,9 +480,9 @@ int main(int argc, char** argv) {
             return 2;
         }
         c.n_replicas = set_size(reps);
-        c.log_size = atoi(need("LogSize").c_str());
-        c.max_records = atoi(need("MaxRecords").c_str());
-        c.max_leader_epoch = atoi(need("MaxLeaderEpoch").c_str());
+        c.log_size = (int32_t)need_int("LogSize");
+        c.max_records = (int32_t)need_int("MaxRecords");
+        c.max_leader_epoch = (int32_t)need_int("MaxLeaderEpoch");
     }
     for (const std::string& inv : cfg.invariants) {
         int bit = -1;

@@ -55,6 +55,10 @@ def test_cfg_syntax():
     ("CONSTANT MaxId = 1", "AsyncIsr"),                                        # unbounded without MCAsyncIsr's constraint
     ("CONSTANT MaxId = 1", "KafkaReplication"),                                # has no Next: no lowered model
     ("CONSTANT MaxId = 1\nPROPERTY Live", "IdSequence"),
+    ("CONSTANT MaxId <- SmallId", "IdSequence"),                               # substitution: nothing is parsed to honour it
+    ("CONSTANT MaxId = many", "IdSequence"),                                   # a model value where an integer is needed
+    ("CONSTANTS Replicas = {b1, b2}\nLogSize=two\nMaxRecords=1\nMaxLeaderEpoch=1", "Kip320"),
+    ("CONSTANT MaxId = 1\nSPECIFICATION Spec\nINIT Init\nNEXT Next", "IdSequence"),   # TLC refuses both, too
 ])
 def test_cfg_rejections(text, module):
     with pytest.raises(CfgError):
@@ -94,6 +98,12 @@ def test_native_cli_error_paths(tmp_path):
     r = subprocess.run([exe, "-config", str(bad), os.path.join(ROOT, "models", "IdSequence.tla")],
                        capture_output=True, text=True)
     assert r.returncode == 2 and "SYMMETRY is not supported" in r.stderr
+    for text, msg in (("CONSTANT MaxId <- SmallId\n", "is not supported"), ("CONSTANT MaxId = many\n", "must be an integer"),
+                      ("CONSTANT MaxId = 3\nSPECIFICATION Spec\nINIT Init\nNEXT Next\n", "not both")):
+        bad.write_text(text)
+        r = subprocess.run([exe, "-config", str(bad), os.path.join(ROOT, "models", "IdSequence.tla")],
+                           capture_output=True, text=True)
+        assert r.returncode == 2 and msg in r.stderr, (text, r.stderr)
     r = subprocess.run([exe, os.path.join(ROOT, "models", "AsyncIsr.tla"), "-config",
                         os.path.join(ROOT, "models", "IdSequence.cfg")], capture_output=True, text=True)
     assert r.returncode == 2 and "unbounded" in r.stderr               # needs MCAsyncIsr's CONSTRAINT
