@@ -382,6 +382,40 @@ void on_level(const kmc_level_info* i, void*) {
 
 }  // namespace
 
+// Stock TLC's other switches [TLC-recall] (kafka_specification_amd/tlc.py holds the same tables): what does not change the
+// question is accepted and ignored with a note, what asks for another mode of operation is refused.
+static const char* lookup_flag(const std::string& a, const char* const (*table)[2], size_t n) {
+    for (size_t k = 0; k < n; ++k)
+        if (a == table[k][0]) return table[k][1];
+    return nullptr;
+}
+static const char* tlc_ignored_flag(const std::string& a) {
+    static const char* const t[][2] = {
+        {"-modelcheck", "model checking is the only mode"}, {"-cleanup", "no states directory is written"},
+        {"-nowarning", "no TLA+ is evaluated, so no evaluation warnings exist"}, {"-terse", "values are printed in full"},
+        {"-tool", "no tool-mode message codes"}, {"-gzip", "checkpoints are not compressed"}, {"-debug", "no debug output"},
+        {"-noGenerateSpecTE", "no trace-expression spec is generated"},
+        {"-difftrace", "traces print every variable of every state"}};
+    return lookup_flag(a, t, sizeof t / sizeof t[0]);
+}
+static const char* tlc_ignored_with_value(const std::string& a) {
+    static const char* const t[][2] = {
+        {"-metadir", "nothing is written there"}, {"-userFile", "the lowered models print nothing"},
+        {"-fpmem", "the fingerprint table lives in HBM: -table SLOTS sizes it"}, {"-fpbits", "one table, no partitioning by bits"},
+        {"-maxSetSize", "no set is enumerated at run time"}, {"-coverage", "action coverage is not collected"},
+        {"-lncheck", "no liveness checking"}};
+    return lookup_flag(a, t, sizeof t / sizeof t[0]);
+}
+static const char* tlc_refused_flag(const std::string& a) {
+    static const char* const t[][2] = {
+        {"-simulate", "random simulation is another mode of TLC; only exhaustive breadth-first model checking is implemented"},
+        {"-depth", "it belongs to -simulate"}, {"-seed", "it belongs to -simulate"}, {"-aril", "it belongs to -simulate"},
+        {"-dump", "the reachable states stay on the GPU (kmc_frontier_states gives a level's states through the C ABI)"},
+        {"-view", "a VIEW changes the distinct-state count"}, {"-dfid", "depth-first iterative deepening is another search order"},
+        {"-generateSpecTE", "no trace-expression spec is generated"}};
+    return lookup_flag(a, t, sizeof t / sizeof t[0]);
+}
+
 int main(int argc, char** argv) {
     std::string spec, cfg_path;
     kmc_config c;
@@ -407,6 +441,18 @@ int main(int argc, char** argv) {
         else if (a == "-fpcheck") fpcheck = true;
         else if (a == "-force") force = true;
         else if (a == "-verify") setenv("KMC_VERIFY", "1", 1);  // every level is regenerated by a second build of the kernels
+        else if (const char* why = tlc_ignored_flag(a)) fprintf(stderr, "Note: %s is accepted for compatibility and ignored (%s)\n", a.c_str(), why);
+        else if (const char* why = tlc_ignored_with_value(a)) {
+            const char* v = val(a.c_str());
+            fprintf(stderr, "Note: %s %s is accepted for compatibility and ignored (%s)\n", a.c_str(), v, why);
+        } else if (const char* why = tlc_refused_flag(a)) {
+            fprintf(stderr, "Error: %s is not supported: %s\n", a.c_str(), why);
+            return 2;
+        } else if (a == "-checkpoint") {
+            const char* v = val("-checkpoint");   // TLC's interval in minutes; this front end has no sharded checkpoints
+            fprintf(stderr, "Note: -checkpoint %s is accepted and ignored (a search takes milliseconds to seconds; the Python front "
+                            "end's -checkpoint DIR saves a level-limited sharded search)\n", v);
+        }
         else if (!a.empty() && a[0] == '-') { fprintf(stderr, "Error: unknown option %s\n", a.c_str()); return 2; }
         else spec = a;
     }

@@ -43,6 +43,27 @@ def collision_report(distinct: int, generated: int):
             f"  birthday bound on the stored fingerprints:  val = {birthday:.2E}"]
 
 
+TLC_IGNORED_FLAGS = {
+    "-modelcheck": "model checking is the only mode", "-cleanup": "no states directory is written",
+    "-nowarning": "no TLA+ is evaluated, so no evaluation warnings exist", "-terse": "values are printed in full",
+    "-tool": "no tool-mode message codes", "-gzip": "checkpoints are not compressed", "-debug": "no debug output",
+    "-noGenerateSpecTE": "no trace-expression spec is generated", "-difftrace": "traces print every variable of every state",
+}
+TLC_IGNORED_WITH_VALUE = {
+    "-metadir": "nothing is written there", "-userFile": "the lowered models print nothing",
+    "-fpmem": "the fingerprint table lives in HBM: -table SLOTS sizes it", "-fpbits": "one table, no partitioning by bits",
+    "-maxSetSize": "no set is enumerated at run time", "-coverage": "action coverage is not collected",
+    "-lncheck": "no liveness checking",
+}
+TLC_REFUSED_FLAGS = {
+    "-simulate": "random simulation is another mode of TLC; only exhaustive breadth-first model checking is implemented",
+    "-depth": "it belongs to -simulate", "-seed": "it belongs to -simulate", "-aril": "it belongs to -simulate",
+    "-dump": "the reachable states stay on the GPU (kmc_frontier_states gives a level's states through the C ABI)",
+    "-view": "a VIEW changes the distinct-state count", "-dfid": "depth-first iterative deepening is another search order",
+    "-generateSpecTE": "no trace-expression spec is generated",
+}
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="tlc", add_help=True, prefix_chars="-")
     ap.add_argument("spec")
@@ -69,7 +90,32 @@ def main(argv=None) -> int:
                     help="differential self-check: a second, differently compiled build of the kernels regenerates every "
                          "level and the per-action / deadlock / violation counts must agree (for constants no oracle reaches)")
     ap.add_argument("-force", action="store_true", help="check the built-in lowering although the spec text differs from it")
-    a = ap.parse_args(argv)
+    # Stock TLC's other command-line switches [TLC-recall]: the ones that do not change what is checked are accepted and
+    # ignored with a note (a wrapper script written for `java tlc2.TLC` keeps working); the ones that ask for another mode
+    # of operation are refused — silently dropping them would answer a different question than the one asked.
+    argv = list(sys.argv[1:] if argv is None else argv)
+    kept, i = [], 0
+    while i < len(argv):
+        t = argv[i]
+        if t in TLC_IGNORED_FLAGS:
+            print(f"Note: {t} is accepted for compatibility and ignored ({TLC_IGNORED_FLAGS[t]})", file=sys.stderr)
+        elif t in TLC_IGNORED_WITH_VALUE:
+            print(f"Note: {t} {argv[i + 1] if i + 1 < len(argv) else ''} is accepted for compatibility and ignored "
+                  f"({TLC_IGNORED_WITH_VALUE[t]})", file=sys.stderr)
+            i += 1
+        elif t in TLC_REFUSED_FLAGS:
+            print(f"Error: {t} is not supported: {TLC_REFUSED_FLAGS[t]}", file=sys.stderr)
+            return 2
+        elif t == "-checkpoint" and i + 1 < len(argv) and argv[i + 1].lstrip("-").isdigit():
+            # TLC's -checkpoint takes an interval in minutes; here a search takes milliseconds to seconds and -checkpoint DIR
+            # names where a level-limited sharded search leaves its state
+            print(f"Note: -checkpoint {argv[i + 1]} (TLC's interval in minutes) is accepted and ignored; "
+                  "-checkpoint DIR saves a level-limited sharded search", file=sys.stderr)
+            i += 1
+        else:
+            kept.append(t)
+        i += 1
+    a = ap.parse_args(kept)
 
     module = os.path.splitext(os.path.basename(a.spec))[0]
     cfg_path = a.config or os.path.splitext(a.spec)[0] + ".cfg"

@@ -192,3 +192,19 @@ def test_collision_estimate_and_tlc_log_parser():
            "663643 states generated, 171601 distinct states found, 90210 states left on queue.\n")
     p = tlc_log_diff.parse(bad)
     assert (p["verdict"], p["invariant"], p["trace_length"], p["left"]) == ("invariant", "StrongIsr", 2, 90210)
+
+
+def test_stock_tlc_switches_are_ignored_with_a_note_or_refused_never_misread():
+    """A wrapper script written for `java tlc2.TLC` passes switches this engine has no use for.  Those that do not change
+    what is checked are accepted and ignored (the run goes on: without a GPU it then ends at the device, status 3);
+    those that ask for another mode of operation end the run with status 2 and the reason.  Both front ends alike."""
+    spec, cfg = os.path.join(ROOT, "models", "IdSequence.tla"), os.path.join(ROOT, "models", "IdSequence.cfg")
+    import torch
+    has_gpu = torch.cuda.is_available()
+    harmless = ["-modelcheck", "-cleanup", "-nowarning", "-coverage", "1", "-checkpoint", "0", "-workers", "auto", "-metadir", "/tmp/x"]
+    for (rc, err) in _both_clis(harmless + ["-config", cfg, "-force", "-deadlock", spec]):
+        assert rc == (0 if has_gpu else 3), err
+        assert err.count("accepted") >= 5 and "unknown option" not in err and "unrecognized" not in err
+    for flag, why in (("-simulate", "another mode"), ("-dump", "stay on the GPU"), ("-view", "distinct-state count")):
+        for (rc, err) in _both_clis([flag, "-config", cfg, "-force", spec]):
+            assert rc == 2 and f"{flag} is not supported" in err and why in err, (flag, err)
