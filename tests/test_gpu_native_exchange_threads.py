@@ -17,7 +17,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _build_mock():
     so, src = os.path.join(HERE, "_mock_rccl.so"), os.path.join(HERE, "mock_rccl.cpp")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-w", "-o", so, src])
+        rc = subprocess.call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-w", "-o", so + ".new", src])
+        if rc == 0:
+            os.replace(so + ".new", so)
+        elif not os.path.exists(so):     # a copy built by __graft_entry__.build() is good enough when the rebuild is not possible
+            raise RuntimeError("cannot build tests/_mock_rccl.so (hipcc failed) and no prebuilt copy exists")
     return so
 
 
