@@ -15,3 +15,7 @@ make -s -C oracle
 # cores where the exact mode would need ~90 GB.  Not exact (n^2/2^65 = 0.02 expected collisions), but a hash, an encoding, a
 # table and a BFS that share nothing with the GPU's.
 ./oracle/kmc_oracle --model KafkaTruncateToHighWatermark --N 3 --L 6 --R 6 --E 2 --threads 8 --inv 1 --fp-only --table-log2 31 > tests/golden/oracle_fp_thw_3_6_6_2.json
+# the three other Kafka models at the same near-headline constants (TypeOk only: they violate StrongIsr by design), 160-177 M states
+for m in Kip101 Kip279 Kip320FirstTry; do
+  ./oracle/kmc_oracle --model $m --N 3 --L 5 --R 5 --E 2 --threads 8 --inv 1 > tests/golden/oracle_$(echo $m | tr A-Z a-z)_3_5_5_2.json
+done

@@ -154,7 +154,8 @@ def test_golden_fixtures_are_consistent():
         assert sum(g["action_generated"]) + 1 == g["generated"]
         assert g["verdict"] == 0 and g["levels"][:3] == [1, 6, 30]
     # the other models start 1, 2N, N(5N-3); Kip279 with 5 brokers and the TruncateToHW headline binding
-    for name, n in (("oracle_kip279_5_2_2_1.json", 5), ("oracle_thw_3_5_5_2.json", 3)):
+    for name, n in (("oracle_kip279_5_2_2_1.json", 5), ("oracle_thw_3_5_5_2.json", 3), ("oracle_kip101_3_5_5_2.json", 3),
+                    ("oracle_kip279_3_5_5_2.json", 3), ("oracle_kip320firsttry_3_5_5_2.json", 3)):
         g = json.load(open(os.path.join(GOLDEN, name)))
         assert sum(g["levels"]) == g["distinct"] and len(g["levels"]) == g["depth"]
         assert sum(g["action_generated"]) + 1 == g["generated"]
