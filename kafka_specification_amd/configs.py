@@ -38,6 +38,7 @@ def precompile_list():
             dict(model="KafkaTruncateToHighWatermark", n_replicas=3, log_size=5, max_records=5, max_leader_epoch=2),
             dict(model="KafkaTruncateToHighWatermark", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=2)]
     out += [dict(model=m, n_replicas=3, log_size=5, max_records=5, max_leader_epoch=2) for m in ("Kip101", "Kip279", "Kip320FirstTry")]
+    out += [dict(model=m, n_replicas=3, log_size=6, max_records=6, max_leader_epoch=2) for m in ("Kip101", "Kip279", "Kip320FirstTry")]
     # wider replica sets: more words per state, several 64-bit words of action-instance bits
     out += [dict(model="Kip320", n_replicas=4, log_size=2, max_records=2, max_leader_epoch=1),
             dict(model="Kip279", n_replicas=5, log_size=1, max_records=1, max_leader_epoch=1),

@@ -19,3 +19,7 @@ make -s -C oracle
 for m in Kip101 Kip279 Kip320FirstTry; do
   ./oracle/kmc_oracle --model $m --N 3 --L 5 --R 5 --E 2 --threads 8 --inv 1 > tests/golden/oracle_$(echo $m | tr A-Z a-z)_3_5_5_2.json
 done
+# ... and at the headline's own constants, 607-655 M states each, in the fingerprint-only mode (2-3 minutes each on 8 cores)
+for m in Kip101 Kip279 Kip320FirstTry; do
+  ./oracle/kmc_oracle --model $m --N 3 --L 6 --R 6 --E 2 --threads 8 --inv 1 --fp-only --table-log2 31 > tests/golden/oracle_fp_$(echo $m | tr A-Z a-z)_3_6_6_2.json
+done

@@ -75,6 +75,7 @@ const Entry TABLE[] = {
     // test_gpu_sharded_and_traces.py): the lowering at exactly these bit offsets is checked state by state on CPU
     KAFKA(KMC_MODEL_TRUNCATE_TO_HW, 3, 6, 6, 2), KAFKA(KMC_MODEL_TRUNCATE_TO_HW, 3, 5, 5, 2), KAFKA(KMC_MODEL_KIP101, 3, 5, 5, 2),
     KAFKA(KMC_MODEL_KIP279, 3, 5, 5, 2), KAFKA(KMC_MODEL_KIP320_FIRST_TRY, 3, 5, 5, 2),
+    KAFKA(KMC_MODEL_KIP101, 3, 6, 6, 2), KAFKA(KMC_MODEL_KIP279, 3, 6, 6, 2), KAFKA(KMC_MODEL_KIP320_FIRST_TRY, 3, 6, 6, 2),
     ASYNC(3, 2, 2), ASYNC(4, 2, 2), ASYNC(2, 3, 7), ASYNC(1, 4, 0),
     FRL(2, 4, 2), FRL(3, 2, 2),
 };

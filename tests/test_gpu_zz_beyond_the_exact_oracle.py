@@ -42,3 +42,20 @@ def test_the_other_kafka_models_near_the_headline_size(model, fixture):
     assert (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
     assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
     assert r.deadlock_states == g["deadlock_states"]
+
+
+@pytest.mark.parametrize("model,fixture", [("Kip101", "oracle_fp_kip101_3_6_6_2.json"), ("Kip279", "oracle_fp_kip279_3_6_6_2.json"),
+                                           ("Kip320FirstTry", "oracle_fp_kip320firsttry_3_6_6_2.json")])
+def test_the_other_kafka_models_at_the_headline_constants(model, fixture):
+    """... and at the headline's own constants (3 brokers, LogSize 6, MaxRecords 6, MaxLeaderEpoch 2; TypeOk only):
+    607-655 M states each, against the C oracle's fingerprint-only mode.  Every Kafka model of the reference is then
+    cross-checked at "3 brokers, maxLogLen=6" by an engine that shares nothing with the GPU's."""
+    g = json.load(open(os.path.join(GOLDEN, fixture)))
+    cfg = CheckerConfig(model=model, n_replicas=g["N"], log_size=g["L"], max_records=g["R"], max_leader_epoch=g["E"],
+                        invariants=("TypeOk",), table_capacity=1 << 31, frontier_capacity=1 << 27)
+    with ModelChecker(cfg) as mc:
+        r = mc.run()
+    assert r.verdict == "ok" and r.queue_left == 0
+    assert (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
+    assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
+    assert r.deadlock_states == g["deadlock_states"]

@@ -199,3 +199,11 @@ def test_fp_only_fixture_of_the_headline_truncate_to_hw_binding_equals_the_gpu_r
         assert (r["verdict"], r["distinct"], r["generated"], r["depth"]) == ("ok", g["distinct"], g["generated"], g["depth"])
         assert r["levels_head"] == g["levels"][:len(r["levels_head"])] and r["levels_tail"] == g["levels"][-len(r["levels_tail"]):]
         assert r["widest_level"] == max(g["levels"])
+
+
+def test_fp_only_fixtures_at_the_headline_constants_are_consistent():
+    for name in ("oracle_fp_kip101_3_6_6_2.json", "oracle_fp_kip279_3_6_6_2.json", "oracle_fp_kip320firsttry_3_6_6_2.json"):
+        g = json.load(open(os.path.join(GOLDEN, name)))
+        assert g["fp_only"] == 1 and g["verdict"] == 0 and (g["N"], g["L"], g["R"], g["E"]) == (3, 6, 6, 2)
+        assert sum(g["levels"]) == g["distinct"] and len(g["levels"]) == g["depth"]
+        assert sum(g["action_generated"]) + 1 == g["generated"] and g["levels"][:3] == [1, 6, 36]
