@@ -144,6 +144,9 @@ typedef struct kmc_result {
     uint64_t expand_launches;
     uint64_t state_words;       /* W: 64-bit words per packed state */
     uint64_t state_bits;
+    uint64_t generated_repeats; /* of `generated`: successors TLC's enumeration yields a second time because two disjuncts
+                                   of one binding hold at once (Kip279.tla:47-51, Kip320.tla:82-83); each is one successor
+                                   and one seen-set probe, so probes = generated - 1 - generated_repeats */
 } kmc_result;
 
 typedef struct kmc_handle kmc_handle;

@@ -69,7 +69,7 @@ class KmcResult(C.Structure):
         ("deadlock_states", C.c_uint64), ("action_generated", C.c_uint64 * KMC_MAX_KINDS),
         ("n_levels", C.c_uint64), ("table_capacity", C.c_uint64), ("frontier_capacity", C.c_uint64),
         ("seconds_total", C.c_double), ("seconds_expand", C.c_double), ("expand_launches", C.c_uint64),
-        ("state_words", C.c_uint64), ("state_bits", C.c_uint64),
+        ("state_words", C.c_uint64), ("state_bits", C.c_uint64), ("generated_repeats", C.c_uint64),
     ]
 
 

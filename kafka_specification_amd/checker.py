@@ -82,6 +82,7 @@ class CheckResult:
     state_words: int
     state_bits: int
     trace: list = field(default_factory=list)
+    generated_repeats: int = 0   # of `generated`: successors yielded twice by two disjuncts of one binding (one probe each)
 
 
 def precompile(cfg: CheckerConfig, arch: str = "gfx950") -> None:
@@ -175,7 +176,8 @@ class ModelChecker:
             levels=[int(buf[i]) for i in range(nlev)],
             table_capacity=int(r.table_capacity), frontier_capacity=int(r.frontier_capacity),
             seconds_total=float(r.seconds_total), seconds_expand=float(r.seconds_expand),
-            expand_launches=int(r.expand_launches), state_words=int(r.state_words), state_bits=int(r.state_bits))
+            expand_launches=int(r.expand_launches), state_words=int(r.state_words), state_bits=int(r.state_bits),
+            generated_repeats=int(r.generated_repeats))
 
     # -- states as data -------------------------------------------------------------------
     def unpack(self, words) -> bytes:

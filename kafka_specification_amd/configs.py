@@ -25,7 +25,7 @@ BASELINE_CONFIGS = {
 def precompile_list():
     out = []
     for m in KAFKA:
-        for (N, L, R, E) in [(2, 2, 2, 1), (3, 2, 2, 1), (3, 1, 1, 2), (2, 3, 3, 2), (3, 2, 2, 2)]:
+        for (N, L, R, E) in [(2, 2, 2, 1), (3, 2, 2, 1), (3, 1, 1, 2), (2, 3, 3, 2), (3, 2, 2, 2), (2, 2, 2, 2)]:
             out.append(dict(model=m, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E))
     out += [dict(model="Kip320", n_replicas=3, log_size=3, max_records=3, max_leader_epoch=2),
             dict(model="KafkaTruncateToHighWatermark", n_replicas=3, log_size=3, max_records=3, max_leader_epoch=1),

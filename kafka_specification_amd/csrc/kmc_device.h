@@ -129,6 +129,15 @@ typedef unsigned int u32;
 #else
 #define KMC_INV_MASK(a) ((a).inv_mask)
 #endif
+#ifndef KMC_LINE_PROBE
+#define KMC_LINE_PROBE 0  // 1: a probe sequence first walks the 16 slots of the 128-byte line it starts in (wrapping inside the
+                          //    line) and only then moves to the next line.  Every probe of a fresh line is a 128-byte DRAM fill;
+                          //    plain linear probing crosses into the next line whenever a chain reaches a line's end
+#endif
+#ifndef KMC_FLUSH_DEDUP
+#define KMC_FLUSH_DEDUP 0 // 1: successors of one flush batch with the same fingerprint are resolved once (a 128-entry per-wave
+                          //    LDS lane map): two lanes probing the same empty slot both issue a CAS and one loses
+#endif
 #ifndef KMC_PREFETCH
 #define KMC_PREFETCH 0    // 1: request the next tile's state words while the current tile is processed (measured: no gain)
 #endif
@@ -164,6 +173,8 @@ struct alignas(128) KmcLevelCtl {
     u64 deadlock_fp_inv;
     u64 enum_count;                  // ENUM: records written
     u64 send_filtered;               // SHARDED: remote successors dropped by the sender-side filter
+    u64 repeats;                     // of generated[]: successors counted a second time because another disjunct of the same
+                                     // binding also holds (models with HAS_EXTRA); they are one successor, probed once
     u64 oviol_count[4];              // successors OUTSIDE the state constraint violating invariant k (per generation)
     u64 oviol_fp_inv[4];             // max over those of ~fp
     u64 prof[8];                     // KMC_PROFILE: summed per-wave s_memtime ticks per phase (tuning aid)
@@ -536,7 +547,12 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
     static constexpr bool FIRST = MODEL == KMC_MODEL_KIP320_FIRST_TRY;
     static constexpr bool K320 = MODEL == KMC_MODEL_KIP320;
     static constexpr int NKINDS = FIRST ? 10 : 9;
-    static constexpr bool HAS_EXTRA = MODEL == KMC_MODEL_KIP279;  // Kip279.tla:47-51: two disjuncts can coincide
+    // Bindings that generate the same successor twice: TLC's next-state enumeration continues from EVERY disjunct that
+    // holds [TLC-recall: Tool.getNextStates, OPCODE_lor] and counts each result as "generated".  Kip279.tla:47-51
+    // (an empty follower satisfies both disjuncts of BecomeFollowerTruncateKip279) and Kip320.tla:82-83 (both reasons
+    // to shrink the ISR can hold at once; found by Oracle-R, which executes the module text).  One kind per model.
+    static constexpr bool HAS_EXTRA = MODEL == KMC_MODEL_KIP279 || MODEL == KMC_MODEL_KIP320;
+    static constexpr int EXTRA_KIND = MODEL == KMC_MODEL_KIP279 ? 7 : 4;
     static constexpr bool HAS_CONSTRAINT = false;
     static constexpr int NP = N * (N - 1);  // ordered pairs of distinct replicas
     // action instances, in the order of the Next disjuncts (the index of the disjunct is
@@ -773,6 +789,7 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             u32 g = kmc_bit(p.tm, l) & kmc_bit(isr, r);
             if constexpr (K320) {  // FencedLeaderShrinkIsr (Kip320.tla:78-85)
                 g = kmc_and(g, kmc_bit64(p.fm, l * N + r) == 0u || p.end(r) < p.end(l));
+                extra = (kmc_bit64(p.fm, l * N + r) == 0u && p.end(r) < p.end(l)) ? 1u : 0u;  // both disjuncts of :82-83
             } else if constexpr (FIRST) {  // LeaderShrinkIsrBetterFencing (Kip320FirstTry.tla:114-120)
                 g = kmc_and(g, !caught_up_epoch<l, r>(p, p.end(l)));
             } else {  // LeaderShrinkIsr (KafkaReplication.tla:233-239)
@@ -1112,7 +1129,11 @@ template <class M> struct KmcSink {
             }
 #endif
             if (v == fp) return false;
+#if KMC_LINE_PROBE
+            i = ((probes & 15) == 15) ? (((i | 15ull) + 1) & a.table_mask) | (fp & 15ull) : (i & ~15ull) | ((i + 1) & 15ull);
+#else
             i = (i + 1) & a.table_mask;
+#endif
         }
         atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
         return false;
@@ -1195,7 +1216,21 @@ template <class M> struct KmcSink {
             // (A per-wave LDS filter of recently resolved fingerprints was tried here to skip
             // duplicate probes: only 4.9 % of the successors hit it — duplicates are not local to
             // a wave — so it was dropped.)
+#if KMC_FLUSH_DEDUP
+            // lanes of this batch with the same fingerprint: one of them (the last writer of the map slot) resolves it
+            __shared__ u32 kmc_dd[4][128];  // KMC_BLOCK / 64 waves
+            volatile u32* dd = kmc_dd[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];  // volatile: the read must see the
+                                                                                         // OTHER lanes' stores, not be forwarded
+            const u32 me = kmc_lane();
+            const u32 slot = (u32)(fp >> 7) & 127u;
+            if (valid) dd[slot] = me;
+            const u32 other = valid ? dd[slot] : me;
+            const u32 olo = (u32)__shfl((int)(u32)fp, (int)other), ohi = (u32)__shfl((int)(u32)(fp >> 32), (int)other);
+            const bool twin = valid && other != me && ((((u64)ohi << 32) | olo) == fp);
+            const bool isnew = valid && !twin && claim(a, fp, meta);
+#else
             const bool isnew = valid && claim(a, fp, meta);
+#endif
             if (!(a.flags & KMC_FLAG_X_NOSTAGE)) out.push(a, isnew, t);
         } else if (a.mode == KMC_MODE_SHARDED) {
             // successors this shard owns take the local path at once (probe, claim, stage): only
@@ -1272,6 +1307,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     out.init(q + ring_planes * KMC_RING);
     u32 head = 0, count = 0;  // wave-uniform: ring read position / number of QUEUED successors
     u32 gen_lane = 0;         // lane k accumulates the successors generated by action kind k
+    u32 extra_lane = 0;       // HAS_EXTRA: this lane's states' additional bindings with a repeated successor (kind EXTRA_KIND)
     u32 deadlocks = 0;
 #if KMC_PROFILE
     u64 prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 0 load+extract+inv 1 guards 2 effects+push 3 flush 4 tail 7 total
@@ -1407,9 +1443,10 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         KMC_T(tp2);
         KMC_TADD(1, tp1, tp2);
         // Pass 2 — wave-uniform walk over the instances; only those some lane enabled dispatch
-        // to their (statically specialised) effect.  This loop is where the kernel's time goes
-        // (ALU-bound, ~45 % of the VALU work): an effect leaf runs for the whole
-        // wave although ~3.4 of 64 lanes enabled it.  Measured and dropped here: a fall-through
+        // to their (statically specialised) effect.  This loop is the arithmetic half of the kernel
+        // (30.1 leaves are dispatched per 64-state tile at the headline and an effect
+        // leaf runs for the whole wave although ~6.7 of 64 lanes enabled it; the other half is the
+        // memory system under the flushes' random probes).  Measured and dropped here: a fall-through
         // `switch`, walking only the set bits of the wave-wide OR of en32 (s_ff1), per-kind
         // `generated` counters in scalars (the array lands in scratch) or bumped with v_writelane.
         u32 cur = 0;
@@ -1439,14 +1476,10 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
                 (void)M::template inst<decltype(I)::value>(pre, s, t, kind, extra);
             });
             const u32 n = __popcll(m);
-            u32 weight = n;
-            if constexpr (M::HAS_EXTRA) {  // bindings that repeat a successor (TLC counts them as generated)
-                u32 x = e ? extra : 0u;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-                weight += __builtin_amdgcn_readfirstlane(x);
-            }
-            gen_lane += (lane == (u32)kind) ? weight : 0u;
+            // bindings that repeat a successor (TLC counts them as generated): summed per lane, reduced once per wave at
+            // the end of the kernel (a wave reduction in every leaf cost 7 cross-lane operations per dispatched leaf)
+            if constexpr (M::HAS_EXTRA) extra_lane += e ? extra : 0u;
+            gen_lane += (lane == (u32)kind) ? n : 0u;
             bool keep = e;
             u64 mk = m;
             if constexpr (M::HAS_CONSTRAINT) {
@@ -1500,6 +1533,13 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     if (lane == 0)
         for (int k = 0; k < 8; ++k) atomicAdd(&a.ctl->prof[k], prof_acc[k]);
 #endif
+    if constexpr (M::HAS_EXTRA) {
+        u32 x = extra_lane;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        gen_lane += (lane == (u32)M::EXTRA_KIND) ? x : 0u;
+        if (lane == 0 && x) atomicAdd(&a.ctl->repeats, (u64)x);
+    }
     if (lane < (u32)M::NKINDS && gen_lane) atomicAdd(&a.ctl->generated[lane], (u64)gen_lane);
     if (lane == 0 && deadlocks) atomicAdd(&a.ctl->deadlock_count, (u64)deadlocks);
 }

@@ -580,6 +580,7 @@ bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, con
         r.generated += c.generated[k];
         r.action_generated[k] += c.generated[k];
     }
+    r.generated_repeats += c.repeats;
     r.deadlock_states += c.deadlock_count;
     if (c.err & KMC_ERR_TABLE_FULL) { r.verdict = KMC_V_TABLE_FULL; return true; }
     if (c.err & (KMC_ERR_FRONTIER_FULL | KMC_ERR_SEND_FULL)) { r.verdict = KMC_V_FRONTIER_FULL; return true; }
@@ -1447,7 +1448,7 @@ int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap
 // predecessor table when traces are kept) and the current frontier's planes, segment by segment.
 namespace {
 struct CkptHeader {
-    char magic[8];          // "KMCCKPT1"
+    char magic[8];          // "KMCCKPT2"
     kmc_config cfg;         // pointers inside are not meaningful in the file
     uint64_t table_cap, fcap, seg_cap, level, n_cur, n_levels, w, has_pred;
 };
@@ -1495,7 +1496,7 @@ int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     FILE* f = fopen(path, "wb");
     if (!f) return fail(KMC_E_ARG, "cannot open %s for writing", path);
     CkptHeader hd{};
-    memcpy(hd.magic, "KMCCKPT1", 8);
+    memcpy(hd.magic, "KMCCKPT2", 8);
     hd.cfg = h->cfg;
     hd.cfg.cache_dir = nullptr;
     hd.table_cap = h->table_cap; hd.fcap = h->fcap; hd.seg_cap = h->seg_cap; hd.level = h->level;
@@ -1522,7 +1523,7 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
     if (!f) return fail(KMC_E_ARG, "cannot open %s", path);
     CkptHeader hd{};
     int rc = KMC_OK;
-    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT1", 8) != 0) rc = fail(KMC_E_ARG, "%s is not a checkpoint", path);
+    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT2", 8) != 0) rc = fail(KMC_E_ARG, "%s is not a checkpoint", path);
     const kmc_config& a = hd.cfg;
     const kmc_config& b = h->cfg;
     if (!rc && (a.model != b.model || a.n_replicas != b.n_replicas || a.log_size != b.log_size ||
@@ -1679,6 +1680,7 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
         r.generated += c.generated[k];
         r.action_generated[k] += c.generated[k];
     }
+    r.generated_repeats += c.repeats;
     r.deadlock_states += c.deadlock_count;
     h->cur = nxt;
     h->n_cur = produced;

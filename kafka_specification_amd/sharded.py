@@ -582,7 +582,8 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
         table_capacity=sum(r.table_capacity for r in local), frontier_capacity=sum(r.frontier_capacity for r in local),
         seconds_total=time.perf_counter() - t0, seconds_expand=max(r.seconds_expand for r in local),
         expand_launches=max(r.expand_launches for r in local), state_words=local[0].state_words,
-        state_bits=local[0].state_bits, trace=trace)
+        state_bits=local[0].state_bits, trace=trace,
+        generated_repeats=int(exchange.all_reduce_sum([np.array([sum(r.generated_repeats for r in local)], dtype=np.int64)])[0]))
 
 
 def _split64(x):

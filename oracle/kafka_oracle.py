@@ -558,11 +558,16 @@ class Kafka:
             isr = s.replicaState[leader][3]
             leaderEndOffset = GetEndOffset(s.replicaLog, leader)
             for follower in sorted(isr - {leader}):
-                if ((not self.IsFollowingLeaderEpoch(s, leader, follower))
-                        or GetEndOffset(s.replicaLog, follower) < leaderEndOffset):
-                    t = self.QuorumUpdateLeaderAndIsr(s, leader, isr - {follower})
-                    if t is not None:
-                        out.append(t)
+                # :82-83 is a DISJUNCTION in front of the primed conjunct :84.  TLC's next-state enumeration walks
+                # every disjunct that holds and continues with the rest of the conjunction from each of them
+                # (Tool.getNextStates, OPCODE_lor [TLC-recall]), so when both hold the same successor is generated
+                # twice.  (Found by Oracle-R, oracle/tlar, which executes the module's text that way.)
+                for holds in ((not self.IsFollowingLeaderEpoch(s, leader, follower)),
+                              GetEndOffset(s.replicaLog, follower) < leaderEndOffset):
+                    if holds:
+                        t = self.QuorumUpdateLeaderAndIsr(s, leader, isr - {follower})
+                        if t is not None:
+                            out.append(t)
         return out
 
     def HasHighWatermarkReachedCurrentEpoch(self, s, leader):  # Kip320.tla:87-92 / Kip320FirstTry.tla:122-127

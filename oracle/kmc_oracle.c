@@ -465,8 +465,14 @@ static void FencedLeaderShrinkIsr(const P *p, const uint8_t *s, int a, emit_fn e
     for (int l = 0; l < p->N; l++) {
         int isr = ISR(s, l);
         for (int f = 0; f < p->N; f++)
-            if (f != l && (isr & BIT(f)) && (!is_following_leader_epoch(p, s, l, f) || END(s, f) < END(s, l)))
-                quorum_update(p, s, l, isr & ~BIT(f), a, emit, ctx);
+            if (f != l && (isr & BIT(f))) {
+                /* :82-83 is a disjunction of two state predicates in front of the primed conjunct :84: TLC's
+                 * next-state enumeration continues from EVERY disjunct that holds (Tool.getNextStates, OPCODE_lor
+                 * [TLC-recall]), so the successor is generated once per disjunct — twice when both hold.
+                 * (Found by Oracle-R, oracle/tlar, which executes the module's text that way.) */
+                if (!is_following_leader_epoch(p, s, l, f)) quorum_update(p, s, l, isr & ~BIT(f), a, emit, ctx);
+                if (END(s, f) < END(s, l)) quorum_update(p, s, l, isr & ~BIT(f), a, emit, ctx);
+            }
     }
 }
 static int hw_reached_current_epoch(const P *p, const uint8_t *s, int l) { /* Kip320.tla:87-92, Kip320FirstTry.tla:122-127 */
