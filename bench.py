@@ -168,7 +168,8 @@ def cpu_baseline(c, budget_states, total_states):
 def run_single(c, steps, warmup):
     import kafka_specification_amd as kmc
     cfg = kmc.CheckerConfig(**c, device=0, table_capacity=int(os.environ.get("KMC_BENCH_TABLE", 1 << 30)),
-                            frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", 1 << 26)))
+                            frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", 1 << 26)),
+                            wide_fingerprint=os.environ.get("KMC_BENCH_FP128", "0") == "1")   # tuning: 128-bit entries
     results = []
     with kmc.ModelChecker(cfg) as mc:
         for _ in range(warmup):

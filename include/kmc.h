@@ -99,6 +99,12 @@ typedef struct kmc_config {
     uint64_t hash_seed;         /* results must not depend on it (collisions aside) */
     uint64_t max_levels;        /* 0 = unlimited (internal cap 4096) */
     const char* cache_dir;      /* compiled-kernel cache; NULL = $KMC_CACHE_DIR or <libdir>/kmc_cache */
+    int32_t wide_fingerprint;   /* 1: 128-bit seen-set entries — every slot holds the 64-bit fingerprint AND a second,
+                                   independent 64-bit hash of the state (16 bytes, one line fill per probe as before).  Two
+                                   distinct states with the same fingerprint are then told apart instead of merged: the
+                                   distinct-state count is exact up to a 128-bit collision (n^2 / 2^129).  TLC has no such
+                                   switch (its FPSet is 64-bit); table_capacity still counts slots */
+    int32_t pad_;
 } kmc_config;
 
 typedef struct kmc_level_info {

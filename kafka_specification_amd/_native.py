@@ -49,6 +49,7 @@ class KmcConfig(C.Structure):
         ("n_shards", C.c_int32), ("shard_id", C.c_int32),
         ("table_capacity", C.c_uint64), ("frontier_capacity", C.c_uint64), ("send_capacity", C.c_uint64),
         ("hash_seed", C.c_uint64), ("max_levels", C.c_uint64), ("cache_dir", C.c_char_p),
+        ("wide_fingerprint", C.c_int32), ("pad_", C.c_int32),
     ]
 
 

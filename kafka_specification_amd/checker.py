@@ -38,6 +38,8 @@ class CheckerConfig:
     hash_seed: int = 0
     max_levels: int = 0
     cache_dir: Optional[str] = None
+    wide_fingerprint: bool = False          # 128-bit seen-set entries (fingerprint + an independent check word): a 64-bit
+                                            # fingerprint collision is recognised instead of silently merging two states
 
     def to_native(self) -> nat.KmcConfig:
         if self.model not in nat.MODELS:
@@ -57,7 +59,8 @@ class CheckerConfig:
             shard_id=self.shard_id, table_capacity=self.table_capacity,
             frontier_capacity=self.frontier_capacity, send_capacity=self.send_capacity,
             hash_seed=self.hash_seed, max_levels=self.max_levels,
-            cache_dir=self.cache_dir.encode() if self.cache_dir else None)
+            cache_dir=self.cache_dir.encode() if self.cache_dir else None,
+            wide_fingerprint=int(self.wide_fingerprint))
 
 
 @dataclass

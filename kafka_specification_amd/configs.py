@@ -65,6 +65,7 @@ def precompile_list():
                       (4, 1, 2), (3, 3, 4), (4, 2, 3), (5, 1, 2), (2, 6, 7), (2, 3, 1), (4, 2, 2), (2, 3, 7), (4, 3, 4),
                       (2, 1, 0), (2, 2, 0), (2, 3, 0), (2, 5, 0)]:
         out.append(dict(model="AsyncIsr", n_replicas=N, log_size=M, max_leader_epoch=V))
+    out.append(dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3))  # 6.45 G states: the -fp128 run
     for name, c in BASELINE_CONFIGS.items():
         # (config 4, 7 brokers: 357 action instances, 9-word states — minutes of hiprtc time, but the -m gpu prefix test
         # needs it and a GPU box should not spend its minutes compiling)
@@ -76,6 +77,18 @@ def precompile_list():
             seen.add(key)
             uniq.append(c)
     return uniq
+
+
+def precompile_variants():
+    """(config, environment) pairs `build()` also specialises: code objects that are only loaded under an environment
+    switch — the second build of the differential self-check (KMC_VERIFY) and the fault-injection build the self-check
+    tests run against (KMC_FAULT_DROP) — so that the GPU box spends none of its minutes in hiprtc."""
+    small = dict(model="Kip320", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1)
+    wide = dict(model="Kip279", n_replicas=5, log_size=1, max_records=1, max_leader_epoch=1)
+    fault = {"KMC_JIT_DEFINES": "-DKMC_FAULT_DROP=1"}
+    return [(small, {"KMC_VERIFY": "1"}), (wide, {"KMC_VERIFY": "1"}), (small, fault), (small, dict(fault, KMC_VERIFY="1")),
+            (dict(model="AsyncIsr", n_replicas=3, log_size=2, max_leader_epoch=2), fault),
+            (small, {"KMC_JIT_DEFINES": "-DKMC_TEST_FP_BITS=10"})]   # collisions on demand for the wide-fingerprint test
 
 
 def all_precompile_configs():

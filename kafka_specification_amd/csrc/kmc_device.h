@@ -52,6 +52,7 @@ typedef unsigned int u32;
 #define KMC_ERR_TABLE_FULL 2u
 #define KMC_ERR_SEND_FULL 4u
 #define KMC_ERR_ENUM_FULL 8u
+#define KMC_ERR_CHECK_WORD 16u  // FP128: a claimed slot's check word never appeared (bounded wait)
 
 #define KMC_FLAG_TRACE 1u
 
@@ -129,14 +130,10 @@ typedef unsigned int u32;
 #else
 #define KMC_INV_MASK(a) ((a).inv_mask)
 #endif
-#ifndef KMC_LINE_PROBE
-#define KMC_LINE_PROBE 0  // 1: a probe sequence first walks the 16 slots of the 128-byte line it starts in (wrapping inside the
-                          //    line) and only then moves to the next line.  Every probe of a fresh line is a 128-byte DRAM fill;
-                          //    plain linear probing crosses into the next line whenever a chain reaches a line's end
-#endif
-#ifndef KMC_FLUSH_DEDUP
-#define KMC_FLUSH_DEDUP 0 // 1: successors of one flush batch with the same fingerprint are resolved once (a 128-entry per-wave
-                          //    LDS lane map): two lanes probing the same empty slot both issue a CAS and one loses
+#ifndef KMC_FAULT_DROP
+#define KMC_FAULT_DROP 0  // 1 (fault injection, tests only): the first flush of block 0 / wave 0 of every LOCAL launch loses the
+                          //    successor in lane 5 between the ring and the seen-set — the failure class of round 1's miscompiled
+                          //    kernel.  The conservation check (generated = probed) and KMC_VERIFY's checksum must both catch it
 #endif
 #ifndef KMC_PREFETCH
 #define KMC_PREFETCH 0    // 1: request the next tile's state words while the current tile is processed (measured: no gain)
@@ -153,6 +150,8 @@ typedef unsigned int u32;
 #define KMC_FLAG_DRY_RAND 256u  // tuning: DRY mode does one load from an uncorrelated random table slot
 #define KMC_FLAG_ENUM_MATCH 512u  // ENUM lists only the successors whose fingerprint is KmcArgs::match_fp, with their parent's fp
 #define KMC_FLAG_META 2u  // the ring carries a meta plane (predecessor fp for traces / kind for ENUM)
+#define KMC_FLAG_FP128 1024u  // the seen-set's slots are 16 bytes: the fingerprint and a second, independent 64-bit hash of the
+                              // state (kmc_config.wide_fingerprint): a 64-bit collision is then recognised, not lost
 
 // A counter alone on its 128-byte line.  Device-scope atomics serialise per cache line at the
 // memory side (~90 M/s): eight "separate" 8-byte append counters packed into one 64-byte line were
@@ -175,6 +174,13 @@ struct alignas(128) KmcLevelCtl {
     u64 send_filtered;               // SHARDED: remote successors dropped by the sender-side filter
     u64 repeats;                     // of generated[]: successors counted a second time because another disjunct of the same
                                      // binding also holds (models with HAS_EXTRA); they are one successor, probed once
+    // Conservation (checked by the host after every level, always on): what pass 2 dispatched must be what reached the sink,
+    // and what the sink claimed must be what was appended:   sum(generated) - repeats - outside = probed,   won = appended.
+    u64 probed;                      // successors that entered KmcSink::process (valid lanes), k_insert's records included
+    u64 won;                         // claims won (new states), counted at the claim; the appends are counted by next_count[]
+    u64 outside;                     // successors outside the state constraint (generated, never probed)
+    u64 fp_sum, fp_xor;              // order-independent checksum of the probed successors' fingerprints (KMC_VERIFY compares
+                                     // it between the two builds of the kernel)
     u64 oviol_count[4];              // successors OUTSIDE the state constraint violating invariant k (per generation)
     u64 oviol_fp_inv[4];             // max over those of ~fp
     u64 prof[8];                     // KMC_PROFILE: summed per-wave s_memtime ticks per phase (tuning aid)
@@ -1037,11 +1043,21 @@ template <int W> struct KmcStager {
     u32 filtered;  // SHARDED: remote successors this wave's sender-side filter dropped (added to the level's counter once,
                    // in finish(): one atomicAdd per flush on that single line capped the sharded kernel at ~90 M flushes/s,
                    // 5.6x the time of the local kernel for the same work)
+    u32 probed, won, outside;  // wave-uniform conservation counters (KmcLevelCtl), added to the level's once, in finish()
+    u64* chk;      // LDS, [2][64]: per-lane running sum and xor of the fingerprints this lane probed
 #if KMC_PROFILE
     u64* prof;     // the wave's phase accumulators (5 = fingerprint, 6 = probe/claim)
 #endif
 
-    KMC_DEV void init(u64* lds) { planes = lds; count = 0; filtered = 0; }
+    KMC_DEV void init(u64* lds) {
+        planes = lds; count = 0; filtered = 0; probed = 0; won = 0; outside = 0;
+        chk = lds + W * KMC_QCAP;
+        chk[kmc_lane()] = 0; chk[64 + kmc_lane()] = 0;
+    }
+    KMC_DEV void account(bool valid, u64 fp) {  // every successor on its way into the sink
+        probed += (u32)__popcll(__ballot(valid));
+        if (valid) { chk[kmc_lane()] += fp; chk[64 + kmc_lane()] ^= fp; }
+    }
 
     KMC_DEV void drain(const KmcArgs& a, u32 n) {  // the n <= 64 staged states -> next frontier
         const u32 lane = kmc_lane();
@@ -1067,6 +1083,7 @@ template <int W> struct KmcStager {
         const u64 m = __ballot(isnew);
         if (m == 0) return;
         const u32 n = __popcll(m);
+        won += n;
         const u32 rank = kmc_rank_in(m);
         const u32 room = KMC_QCAP - count;   // >= 1
         if (isnew && rank < room) {
@@ -1088,14 +1105,72 @@ template <int W> struct KmcStager {
         if (count) drain(a, count);
         if (filtered && kmc_lane() == 0) atomicAdd(&a.ctl->send_filtered, (u64)filtered);
         filtered = 0;
+        if (probed | outside) {
+            u64 sm = chk[kmc_lane()], xr = chk[64 + kmc_lane()];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                sm += ((u64)(u32)__shfl_xor((int)(u32)(sm >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)sm, off);
+                xr ^= ((u64)(u32)__shfl_xor((int)(u32)(xr >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)xr, off);
+            }
+            if (kmc_lane() == 0) {
+                atomicAdd(&a.ctl->probed, (u64)probed);
+                if (won) atomicAdd(&a.ctl->won, (u64)won);
+                if (outside) atomicAdd(&a.ctl->outside, (u64)outside);
+                atomicAdd(&a.ctl->fp_sum, sm);
+                atomicXor(&a.ctl->fp_xor, xr);
+            }
+        }
+        probed = won = outside = 0;
     }
 };
+
+struct alignas(16) KmcSlot2 { u64 x, y; };   // a wide seen-set slot: fingerprint, check word
 
 template <class M> struct KmcSink {
     static constexpr int W = M::W;
 
     // probe/insert fp; returns true when this lane claimed the slot (the state is new)
     static KMC_DEV bool claim(const KmcArgs& a, u64 fp, u64 meta) { return claim_from(a, fp, fp & a.table_mask, meta); }
+
+    // The same with 16-byte slots (KMC_FLAG_FP128): word 0 is the fingerprint and is claimed exactly as above; word 1 is a
+    // second, independent 64-bit hash of the state, published by the claimer right after its CAS.  Both words sit in the same
+    // 128-byte line, so the probe (ONE 16-byte load) moves no more DRAM than the narrow one.  A probe that finds its
+    // fingerprint compares the check word: equal -> the same state; different -> a 64-bit collision between two distinct
+    // states, which the narrow table would have lost — the probe goes on to the next slot.  A check word that is still 0
+    // (the claimer has not published yet, or this XCD's L2 holds the line from before it did) is re-read at the memory side
+    // (an atomic, like the claim itself) until it appears; the claimer's store precedes every wait in program order, so two
+    // lanes of one wave cannot wait on each other.
+    static KMC_DEV bool claim_wide(const KmcArgs& a, u64 fp, u64 chk, u64 meta) {
+        u64 i = fp & a.table_mask;
+        const u64 max_probes = a.table_mask < (1ull << 10) ? a.table_mask : (1ull << 10);
+        for (u64 probes = 0; probes <= max_probes; ++probes) {
+            u64* slot = a.table + 2 * i;
+            const KmcSlot2 v = *(const KmcSlot2*)slot;   // one 16-byte load
+            u64 v0 = v.x, v1 = v.y;
+            if (v0 == 0) {
+                v0 = atomicCAS(slot, 0ull, fp);
+                if (v0 == 0) {
+                    __hip_atomic_store(slot + 1, chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a.pred) a.pred[i] = meta;
+                    return true;
+                }
+                v1 = 0;  // somebody else's claim: its check word must be (re)read
+            }
+            if (v0 == fp) {
+                for (u32 spins = 0; v1 == 0; ++spins) {
+                    v1 = atomicOr(slot + 1, 0ull);
+                    if (spins > (1u << 16)) {
+                        atomicOr(&a.ctl->err, KMC_ERR_CHECK_WORD);
+                        return false;
+                    }
+                }
+                if (v1 == chk) return false;
+            }
+            i = (i + 1) & a.table_mask;
+        }
+        atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
+        return false;
+    }
     static KMC_DEV bool claim_from(const KmcArgs& a, u64 fp, u64 i, u64 meta) {
         // open addressing, linear probing.  Slots only ever change 0 -> fp, so a plain
         // (possibly stale) load can only mis-report "empty", which the CAS then corrects.
@@ -1129,14 +1204,17 @@ template <class M> struct KmcSink {
             }
 #endif
             if (v == fp) return false;
-#if KMC_LINE_PROBE
-            i = ((probes & 15) == 15) ? (((i | 15ull) + 1) & a.table_mask) | (fp & 15ull) : (i & ~15ull) | ((i + 1) & 15ull);
-#else
             i = (i + 1) & a.table_mask;
-#endif
         }
         atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
         return false;
+    }
+
+    // the narrow or the wide table, as the handle was opened (a wave-uniform branch); the check word is the same
+    // fingerprint function under another seed
+    static KMC_DEV bool claim_any(const KmcArgs& a, const u64* t, u64 fp, u64 meta) {
+        if (a.flags & KMC_FLAG_FP128) return claim_wide(a, fp, kmc_fingerprint<W>(t, a.seed ^ 0x6a09e667f3bcc908ull), meta);
+        return claim(a, fp, meta);
     }
 
     // Sender-side duplicate filter of the sharded path: true when fp was not yet in `set` (and is now).
@@ -1183,7 +1261,13 @@ template <class M> struct KmcSink {
 
     // Executed by the whole wave; lanes with valid=false only take part in the ballots.
     static KMC_DEV void process(const KmcArgs& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta) {
+#ifdef KMC_TEST_FP_BITS   // tests only: a fingerprint of that many bits, i.e. collisions on demand (the wide table's check
+                          // word keeps its 64 bits) — tests/test_gpu_selfcheck_and_fp128.py
+        const u64 fp = kmc_mix64((kmc_fingerprint<W>(t, a.seed) & ((1ull << (KMC_TEST_FP_BITS)) - 1)) + 0x9E3779B97F4A7C15ull) | 1ull;
+#else
         const u64 fp = kmc_fingerprint<W>(t, a.seed);
+#endif
+        out.account(valid, fp);
         if (a.mode == KMC_MODE_DRY) {
             u64 acc = fp;
             if (valid && (a.flags & KMC_FLAG_DRY_RAND)) {  // ONE load from an unrelated random slot per successor
@@ -1216,27 +1300,16 @@ template <class M> struct KmcSink {
             // (A per-wave LDS filter of recently resolved fingerprints was tried here to skip
             // duplicate probes: only 4.9 % of the successors hit it — duplicates are not local to
             // a wave — so it was dropped.)
-#if KMC_FLUSH_DEDUP
-            // lanes of this batch with the same fingerprint: one of them (the last writer of the map slot) resolves it
-            __shared__ u32 kmc_dd[4][128];  // KMC_BLOCK / 64 waves
-            volatile u32* dd = kmc_dd[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];  // volatile: the read must see the
-                                                                                         // OTHER lanes' stores, not be forwarded
-            const u32 me = kmc_lane();
-            const u32 slot = (u32)(fp >> 7) & 127u;
-            if (valid) dd[slot] = me;
-            const u32 other = valid ? dd[slot] : me;
-            const u32 olo = (u32)__shfl((int)(u32)fp, (int)other), ohi = (u32)__shfl((int)(u32)(fp >> 32), (int)other);
-            const bool twin = valid && other != me && ((((u64)ohi << 32) | olo) == fp);
-            const bool isnew = valid && !twin && claim(a, fp, meta);
-#else
-            const bool isnew = valid && claim(a, fp, meta);
-#endif
+            // (Resolving the successors of one batch that share a fingerprint only once — a per-wave LDS lane map — and walking
+            // a probe chain inside its 128-byte line before moving on were measured in round 3 and change nothing:
+            // profiles/r03_probe_knobs.txt.)
+            const bool isnew = valid && claim_any(a, t, fp, meta);
             if (!(a.flags & KMC_FLAG_X_NOSTAGE)) out.push(a, isnew, t);
         } else if (a.mode == KMC_MODE_SHARDED) {
             // successors this shard owns take the local path at once (probe, claim, stage): only
             // the (P-1)/P that belong elsewhere travel
             const u32 dst = valid ? kmc_owner(fp, a.nshards) : ~0u;
-            const bool isnew = dst == a.shard && claim(a, fp, meta);
+            const bool isnew = dst == a.shard && claim_any(a, t, fp, meta);
             out.push(a, isnew, t);
             // bucket the rest by owner: one wave-aggregated atomicAdd per destination present in this batch
             const u32 sub = blockIdx.x % KMC_SEGS;
@@ -1302,7 +1375,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, keep it scalar
     const bool has_meta = (a.flags & KMC_FLAG_META) != 0;
     const u32 ring_planes = W + (has_meta ? 1u : 0u);
-    u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + W * KMC_QCAP);  // q[k*KMC_RING + pos]
+    u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + W * KMC_QCAP + 128);  // q[k*KMC_RING + pos]
     KmcStager<W> out;
     out.init(q + ring_planes * KMC_RING);
     u32 head = 0, count = 0;  // wave-uniform: ring read position / number of QUEUED successors
@@ -1316,6 +1389,11 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #endif
 
     u32 table_full = 0;  // wave-uniform; KMC_ERRCHK_TILE: refreshed once per tile
+    const u32 nwaves = gridDim.x * KMC_WAVES;
+    const u32 wave0 = blockIdx.x * KMC_WAVES + wib;
+#if KMC_FAULT_DROP
+    u32 nflush = 0;
+#endif
     auto flush = [&](u32 nv) {  // nv <= KMC_FLUSH_N queued successors leave the ring
         u64 t0[W];
         KMC_FENCE_LDS();
@@ -1326,7 +1404,13 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #if KMC_SETPRIO
         __builtin_amdgcn_s_setprio(2);
 #endif
+#if KMC_FAULT_DROP
+        const bool dropped = a.mode == KMC_MODE_LOCAL && wave0 == 0 && nflush == 0 && lane == 5;
+        ++nflush;
+        KmcSink<M>::process(a, out, lane < nv && !table_full && !dropped, t0, meta0);
+#else
         KmcSink<M>::process(a, out, lane < nv && !table_full, t0, meta0);
+#endif
 #if KMC_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1337,8 +1421,6 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     // Segment by segment; within a segment the 64-state tiles are dealt round-robin to all waves
     // of the grid.  (One flat tile index over all segments needed their prefix sums live in
     // SGPRs for the whole kernel.)
-    const u32 nwaves = gridDim.x * KMC_WAVES;
-    const u32 wave0 = blockIdx.x * KMC_WAVES + wib;
     if (a.prev) {
         // chained launch: every wave reads the finished control block of the producing level (wave-uniform values)
         const KmcLevelCtl* pv = a.prev;
@@ -1496,6 +1578,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
                         }
                         keep = e && !outside;
                         mk = __ballot(keep);
+                        out.outside += (u32)(__popcll(m) - __popcll(mk));
                     }
                 }
             }
@@ -1546,16 +1629,16 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 
 // dynamic LDS bytes k_expand needs for a state of W words
 KMC_HD inline unsigned kmc_expand_lds_bytes(int W, bool has_meta) {
-    return (unsigned)(KMC_WAVES * ((W + (has_meta ? 1 : 0)) * KMC_RING + W * KMC_QCAP) * 8);
+    return (unsigned)(KMC_WAVES * ((W + (has_meta ? 1 : 0)) * KMC_RING + W * KMC_QCAP + 128) * 8);  // + the stager's checksum cells
 }
 
 // Inserts a list of AoS records (W state words + predecessor fp) into the local table:
 // the initial state, and the receive side of the multi-GPU exchange.
 template <class M> KMC_DEV void kmc_insert_body(const KmcArgs& a) {
     constexpr int W = M::W;
-    __shared__ u64 stage[KMC_WAVES][W][KMC_QCAP];
+    __shared__ u64 stage[KMC_WAVES][W * KMC_QCAP + 128];   // the stager's planes + its checksum cells
     KmcStager<W> out;
-    out.init(&stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0][0]);
+    out.init(&stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0]);
 #if KMC_PROFILE
     u64 prof_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     out.prof = prof_dummy;

@@ -29,6 +29,8 @@
 #define KMC_CHAIN 8
 #define KMC_CTL_SLOTS (3 + KMC_CHAIN)   // two alternating levels + one auxiliary + one per chained level
 
+#define KMC_VERIFY_OPTIONS "-O1 -DKMC_MIN_WAVES=2"   // how the second build of KMC_VERIFY differs from the first
+
 namespace {
 
 thread_local std::string g_err;
@@ -333,7 +335,9 @@ struct kmc_handle {
     u64 *table = nullptr, *pred = nullptr, *table2 = nullptr;
     u64* sent = nullptr;      // n_shards > 1: sender-side filter of fingerprints already shipped
     uint64_t sent_cap = 0;
-    uint64_t table_cap = 0;
+    uint64_t table_cap = 0;      // slots
+    uint64_t slot_words = 1;     // 64-bit words per slot: 1, or 2 with kmc_config.wide_fingerprint (fingerprint + check word)
+    uint64_t inserted_level = 0; // stepping: records handed to k_insert since the last kmc_step_finish (conservation check)
     u64* frontier[2] = {nullptr, nullptr};
     uint64_t fcap = 0;
     KmcLevelCtl* ctl = nullptr;       // 3 device slots: two alternating levels + one auxiliary
@@ -399,7 +403,7 @@ KmcArgs base_args(kmc_handle* h, int ctl_slot) {
     a.ctl = h->ctl + ctl_slot;
     a.seed = h->cfg.hash_seed;
     a.inv_mask = h->cfg.invariant_mask;
-    a.flags = h->cfg.keep_trace ? KMC_FLAG_TRACE : 0u;
+    a.flags = (h->cfg.keep_trace ? KMC_FLAG_TRACE : 0u) | (h->slot_words == 2 ? KMC_FLAG_FP128 : 0u);
     a.nshards = (uint32_t)h->cfg.n_shards;
     a.shard = (uint32_t)h->cfg.shard_id;
     a.rec_words = (uint32_t)h->rec_words;
@@ -511,7 +515,7 @@ int find_outside_witness(kmc_handle* h, const u64* frontier, const uint64_t seg[
 }
 
 int reset_run(kmc_handle* h) {
-    HIP_TRY(hipMemsetAsync(h->table, 0, h->table_cap * 8, h->stream));
+    HIP_TRY(hipMemsetAsync(h->table, 0, h->table_cap * h->slot_words * 8, h->stream));
     if (h->pred) HIP_TRY(hipMemsetAsync(h->pred, 0, h->table_cap * 8, h->stream));
     if (h->sent) HIP_TRY(hipMemsetAsync(h->sent, 0, h->sent_cap * 8, h->stream));
     HIP_TRY(hipMemsetAsync(h->ctl, 0, KMC_CTL_SLOTS * sizeof(KmcLevelCtl), h->stream));
@@ -540,9 +544,44 @@ int reset_run(kmc_handle* h) {
 // to ITS states, generated / next_count to the level it produced.  Returns true when the search
 // must stop.  On a stopping invariant violation the produced level is rolled back (not counted), so
 // the reported numbers are those of a checker that tests each state when it is first found.
+// Conservation of successors through one level's kernels (always on; two counters per wave on the device):
+//   what pass 2 of k_expand dispatched, less the repeats (one successor, two bindings) and the successors outside the state
+//   constraint, plus the records k_insert was handed, must be what entered the sink:  generated - repeats - outside + inserted = probed
+//   and every claim the sink won must have been appended to the next frontier:       won = sum(next_count).
+// Round 1 met a build of k_expand that LOST successors between dispatch and sink; every counter the old
+// self-check compared is bumped before that point.  These two are taken on either side of it.
+int check_conservation(kmc_handle* h, const KmcLevelCtl& c, uint64_t inserted) {
+    if (c.err) return KMC_OK;   // a full table / frontier / send area stops probing and appending on purpose
+    uint64_t gen = 0, appended = 0;
+    for (int k = 0; k < KMC_MAX_KINDS; ++k) gen += c.generated[k];
+    for (int sg = 0; sg < KMC_SEGS; ++sg) appended += c.next_count[sg].v;
+    const uint64_t expect = gen - c.repeats - c.outside + inserted;
+    if (expect != c.probed)
+        return fail(KMC_E_DEVICE, "conservation violated at level %llu of kmc_expand_%s: %llu successors were dispatched "
+                                  "(%llu generated - %llu repeats - %llu outside the constraint + %llu inserted) but %llu reached "
+                                  "the seen-set: the kernel lost or invented successors",
+                    (unsigned long long)h->level, h->kname.c_str(), (unsigned long long)expect, (unsigned long long)gen,
+                    (unsigned long long)c.repeats, (unsigned long long)c.outside, (unsigned long long)inserted,
+                    (unsigned long long)c.probed);
+    if (c.won != appended)
+        return fail(KMC_E_DEVICE, "conservation violated at level %llu of kmc_expand_%s: %llu claims were won but %llu states "
+                                  "were appended to the next frontier", (unsigned long long)h->level, h->kname.c_str(),
+                    (unsigned long long)c.won, (unsigned long long)appended);
+    return KMC_OK;
+}
+
 bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, const uint64_t* parent_seg, int* rc) {
     kmc_result& r = h->res;
     *rc = KMC_OK;
+    if (c.err & KMC_ERR_CHECK_WORD) {
+        *rc = fail(KMC_E_DEVICE, "wide fingerprints: a claimed slot's check word did not appear (level %llu)", (unsigned long long)h->level);
+        r.verdict = KMC_V_ERROR;
+        return true;
+    }
+    if ((*rc = check_conservation(h, c, 0))) {
+        r.verdict = KMC_V_ERROR;
+        return true;
+    }
     if (r.violated_invariant < 0) {
         for (int k = 0; k < 4; ++k) {
             if ((h->cfg.invariant_mask >> k & 1u) && c.viol_count[k]) {
@@ -674,7 +713,11 @@ int kmc_precompile(const kmc_config* cfg, const char* arch) {
     if (!cfg) return fail(KMC_E_ARG, "null config");
     std::vector<char> code;
     std::string kname;
-    return get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname);
+    int rc = get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname);
+    // with KMC_VERIFY set, also the second build kmc_open would load for the differential self-check
+    if (!rc && getenv("KMC_VERIFY") && atoi(getenv("KMC_VERIFY")))
+        rc = get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname, KMC_VERIFY_OPTIONS);
+    return rc;
 }
 
 static void comm_release(kmc_handle* h);
@@ -754,7 +797,7 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
         // per-action counts, deadlock counts and violation counts of the two builds must agree.
         std::vector<char> vcode;
         std::string vname;
-        rc = get_code_object(h->cfg, arch, &vcode, &vname, "-O1 -DKMC_MIN_WAVES=2");
+        rc = get_code_object(h->cfg, arch, &vcode, &vname, KMC_VERIFY_OPTIONS);
         if (rc) return rc;
         HIP_TRY(hipModuleLoadData(&h->mod_verify, vcode.data()));
         HIP_TRY(hipModuleGetFunction(&h->f_expand_verify, h->mod_verify, ("kmc_expand_" + vname).c_str()));
@@ -777,7 +820,8 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double budget = 0.85 * (double)free_b;
-    const uint64_t slot_bytes = cfg->keep_trace ? 16 : 8;
+    h->slot_words = cfg->wide_fingerprint ? 2 : 1;
+    const uint64_t slot_bytes = 8 * h->slot_words + (cfg->keep_trace ? 8 : 0);
     // auto-sizing: half of the budget for the table; a shard also keeps a sender-side filter of twice the table
     // (0.15 + 0.30), two frontiers (2 x 0.09), a send area and a receive area (0.12 each)
     const double table_share = h->cfg.n_shards > 1 ? 0.15 : 0.5;
@@ -795,7 +839,7 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     h->table_cap = tcap;
     h->fcap = fcap;
     h->seg_cap = fcap / KMC_SEGS;
-    if (hipMalloc(&h->table, tcap * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate %llu table slots", (unsigned long long)tcap);
+    if (hipMalloc(&h->table, tcap * h->slot_words * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate %llu table slots", (unsigned long long)tcap);
     if (cfg->keep_trace && hipMalloc(&h->pred, tcap * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate predecessor table");
     for (int i = 0; i < 2; ++i)
         if (hipMalloc(&h->frontier[i], fcap * 8ull * h->W) != hipSuccess)
@@ -992,6 +1036,7 @@ int kmc_pack_state(kmc_handle* h, const uint8_t* c, uint64_t* words) {
 
 static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh);
 
+
 int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
     if (!h) return fail(KMC_E_ARG, "null handle");
     if (!h->table) return fail(KMC_E_STATE, "host-only handle (device = -1) cannot run");
@@ -1045,6 +1090,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             for (int k = 0; k < KMC_MAX_KINDS; ++k) c.generated[k] = 0;
             c.deadlock_count = 0;
             c.err = 0;
+            c.probed = c.won = c.outside = c.repeats = 0;   // an invariant-only pass: nothing was dispatched for the record
             absorb(h, c, h->frontier[h->cur], h->seg_n, &rc);
             if (rc) return rc;
             if (r.verdict == KMC_V_OK) r.verdict = KMC_V_LEVEL_LIMIT;
@@ -1144,8 +1190,8 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
         a.fout = h->frontier[nxt];
         a.mode = KMC_MODE_LOCAL;
         if (shadow) {  // tuning aid: the identical level first runs on a copy of the table, with KMC_XFLAGS applied
-            if (!h->table2) HIP_TRY(hipMalloc(&h->table2, h->table_cap * 8));
-            HIP_TRY(hipMemcpyAsync(h->table2, h->table, h->table_cap * 8, hipMemcpyDeviceToDevice, h->stream));
+            if (!h->table2) HIP_TRY(hipMalloc(&h->table2, h->table_cap * h->slot_words * 8));
+            HIP_TRY(hipMemcpyAsync(h->table2, h->table, h->table_cap * h->slot_words * 8, hipMemcpyDeviceToDevice, h->stream));
             HIP_TRY(hipMemsetAsync(h->ctl + 2, 0, sizeof(KmcLevelCtl), h->stream));
             KmcArgs x = a;
             x.table = h->table2;
@@ -1181,11 +1227,17 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             bool same = vc.deadlock_count == c.deadlock_count;
             for (int k = 0; k < KMC_MAX_KINDS; ++k) same = same && vc.generated[k] == c.generated[k];
             for (int k = 0; k < 4; ++k) same = same && vc.viol_count[k] == c.viol_count[k];
-            if (!same) {
+            // ... and the successors themselves: how many reached the sink, and the order-independent checksum of their
+            // fingerprints (taken where a successor enters the sink — behind the ring and the flush, where round 1's
+            // miscompiled kernel lost some while every count above still agreed)
+            const bool same_succ = vc.probed == c.probed && vc.fp_sum == c.fp_sum && vc.fp_xor == c.fp_xor &&
+                                   vc.repeats == c.repeats && vc.outside == c.outside;
+            if (!same || !same_succ) {
                 r.verdict = KMC_V_ERROR;
-                return fail(KMC_E_DEVICE, "KMC_VERIFY: the two builds of kmc_expand_%s disagree at level %llu (generated / "
-                                          "deadlock / violation counts differ): one of them is miscompiled", h->kname.c_str(),
-                            (unsigned long long)h->level);
+                return fail(KMC_E_DEVICE, "KMC_VERIFY: the two builds of kmc_expand_%s disagree at level %llu (%s): one of them "
+                                          "is miscompiled", h->kname.c_str(), (unsigned long long)h->level,
+                            same ? "the successors reaching the seen-set differ: count or fingerprint checksum"
+                                 : "generated / deadlock / violation counts differ");
             }
             h->verify_levels++;
         }
@@ -1339,7 +1391,9 @@ static int table_lookup(kmc_handle* h, uint64_t fp, uint64_t* slot) {
     uint64_t i = fp & mask;
     for (uint64_t probes = 0; probes <= mask; ++probes) {
         uint64_t v = 0;
-        HIP_TRY(hipMemcpy(&v, h->table + i, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&v, h->table + i * h->slot_words, 8, hipMemcpyDeviceToHost));
+        // (with wide slots two distinct states may carry this fingerprint; the first one is reported — the check word
+        // needs the state, which the callers of this lookup do not have)
         if (v == fp) {
             *slot = i;
             return KMC_OK;
@@ -1505,7 +1559,7 @@ int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     bool ok = wr(f, &hd, sizeof hd) && wr(f, &h->res, sizeof h->res) && wr(f, h->levels.data(), h->levels.size() * 8) &&
               wr(f, h->seg_n, sizeof h->seg_n) && wr(f, h->init_words.data(), h->W * 8);
     if (!ok) rc = fail(KMC_E_STATE, "checkpoint: short write");
-    if (!rc) rc = dev_to_file(f, h->table, h->table_cap);
+    if (!rc) rc = dev_to_file(f, h->table, h->table_cap * h->slot_words);
     if (!rc && h->pred) rc = dev_to_file(f, h->pred, h->table_cap);
     for (int sg = 0; sg < KMC_SEGS && !rc; ++sg)
         for (int k = 0; k < h->W && !rc; ++k)
@@ -1529,8 +1583,9 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
     if (!rc && (a.model != b.model || a.n_replicas != b.n_replicas || a.log_size != b.log_size ||
                 a.max_records != b.max_records || a.max_leader_epoch != b.max_leader_epoch ||
                 a.n_log_records != b.n_log_records || a.max_id != b.max_id || a.hash_seed != b.hash_seed ||
-                a.n_shards != b.n_shards || a.shard_id != b.shard_id || hd.w != (uint64_t)h->W))
-        rc = fail(KMC_E_ARG, "checkpoint was taken for a different model / constants / hash seed / shard");
+                a.n_shards != b.n_shards || a.shard_id != b.shard_id || hd.w != (uint64_t)h->W ||
+                (a.wide_fingerprint != 0) != (b.wide_fingerprint != 0)))
+        rc = fail(KMC_E_ARG, "checkpoint was taken for a different model / constants / hash seed / shard / fingerprint width");
     if (!rc && (hd.table_cap != h->table_cap || hd.fcap != h->fcap || hd.seg_cap != h->seg_cap ||
                 hd.has_pred != (uint64_t)(h->pred != nullptr)))
         rc = fail(KMC_E_ARG, "checkpoint capacities differ: open the handle with table_capacity=%llu frontier_capacity=%llu keep_trace=%d",
@@ -1569,7 +1624,7 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
             h->init_words = init;
         }
     }
-    if (!rc) rc = file_to_dev(f, h->table, h->table_cap);
+    if (!rc) rc = file_to_dev(f, h->table, h->table_cap * h->slot_words);
     if (!rc && h->pred) rc = file_to_dev(f, h->pred, h->table_cap);
     h->cur = 0;
     for (int sg = 0; sg < KMC_SEGS && !rc; ++sg)
@@ -1657,6 +1712,7 @@ int kmc_step_insert(kmc_handle* h, const void* dev_records, uint64_t n_records) 
     KmcArgs a = base_args(h, slot);
     a.recv = (const u64*)dev_records;
     a.n_in = n_records;
+    h->inserted_level += n_records;
     a.fout = h->frontier[h->cur ^ 1];
     a.mode = KMC_MODE_LOCAL;
     uint64_t blocks = (n_records + KMC_BLOCK - 1) / KMC_BLOCK;
@@ -1672,6 +1728,12 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
     int rc = read_ctl(h, slot);
     if (rc) return rc;
     const KmcLevelCtl c = *h->ctl_host;
+    if (c.err & KMC_ERR_CHECK_WORD)
+        return fail(KMC_E_DEVICE, "wide fingerprints: a claimed slot's check word did not appear (level %llu)", (unsigned long long)h->level);
+    // the level's kernels on this shard: one k_expand (local successors probed at once, remote ones bucketed — both enter
+    // the sink) and the k_insert launches over what the other shards sent
+    if ((rc = check_conservation(h, c, h->inserted_level))) return rc;
+    h->inserted_level = 0;
     const int nxt = h->cur ^ 1;
     uint64_t new_seg[KMC_SEGS];
     const uint64_t produced = produced_segments(h, c, new_seg);
@@ -1846,6 +1908,7 @@ int insert_received(kmc_handle* h, uint64_t n_records) {
     KmcArgs a = base_args(h, slot);
     a.recv = h->recv;
     a.n_in = n_records;
+    h->inserted_level += n_records;
     a.fout = h->frontier[h->cur ^ 1];
     a.mode = KMC_MODE_LOCAL;
     uint64_t blocks = (n_records + KMC_BLOCK - 1) / KMC_BLOCK;

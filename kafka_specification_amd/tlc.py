@@ -1,7 +1,7 @@
 """`tlc2.TLC`-shaped command line [TLC-recall]:
 
     python -m kafka_specification_amd.tlc [-config X.cfg] [-deadlock] [-continue] [-workers N]
-                                          [-fp SEED] [-fpcheck] [-verify] [-force] [-gpus P] [-table SLOTS]
+                                          [-fp SEED] [-fp128] [-fpcheck] [-verify] [-force] [-gpus P] [-table SLOTS]
                                           [-frontier STATES] Spec.tla
 
 Maps the root module's name to its lowered GPU model, reads constants / invariants from the
@@ -32,9 +32,14 @@ def _now():
     return time.strftime("%Y-%m-%d %H:%M:%S")
 
 
-def collision_report(distinct: int, generated: int):
+def collision_report(distinct: int, generated: int, wide: bool = False):
     """TLC's closing estimate [TLC-recall: "calculated (optimistic)" = distinct x (generated - distinct) / 2^64], plus
-    the birthday bound n^2 / 2^65 for the fingerprints that were stored."""
+    the birthday bound n^2 / 2^65 for the fingerprints that were stored.  With -fp128 every entry also holds a second,
+    independent 64-bit hash of the state: two states are only merged when both words agree."""
+    if wide:
+        return ["The seen-set stores 128 bits per state (the fingerprint and an independent check word); probability that two "
+                "distinct states were merged:",
+                f"  birthday bound on the stored entries:  val = {distinct * distinct / 2.0 ** 129:.2E}"]
     opt = distinct * max(generated - distinct, 0) / 2.0 ** 64
     birthday = distinct * distinct / 2.0 ** 65
     return ["The seen-set stores 64-bit fingerprints; estimates of the probability that not all reachable states were "
@@ -79,6 +84,10 @@ def main(argv=None) -> int:
     ap.add_argument("-frontier", type=int, default=0)
     ap.add_argument("-device", type=int, default=0)
     ap.add_argument("-notrace", action="store_true", help="do not keep predecessor links (no counterexample trace)")
+    ap.add_argument("-fp128", action="store_true",
+                    help="128-bit seen-set entries: the fingerprint plus an independent 64-bit check word per state, in the same "
+                         "cache line (no extra memory traffic per probe, twice the table bytes); a 64-bit fingerprint collision "
+                         "is then recognised instead of losing a state")
     ap.add_argument("-fpcheck", action="store_true",
                     help="run the search again with a second fingerprint seed and compare the counts")
     ap.add_argument("-maxlevels", type=int, default=0, help="stop after this many BFS levels (verdict level_limit)")
@@ -125,7 +134,8 @@ def main(argv=None) -> int:
     try:
         mcfg = parse_cfg(open(cfg_path).read())
         over = dict(hash_seed=a.fp, device=a.device, continue_on_violation=a.cont, keep_trace=not a.notrace,
-                    table_capacity=a.table, frontier_capacity=a.frontier, max_levels=a.maxlevels)
+                    table_capacity=a.table, frontier_capacity=a.frontier, max_levels=a.maxlevels,
+                    wide_fingerprint=a.fp128)
         if a.deadlock:
             over["check_deadlock"] = False
         cc = to_checker_config(module, mcfg, **over)
@@ -228,7 +238,7 @@ def main(argv=None) -> int:
     print(f"{res.generated} states generated, {res.distinct} distinct states found, "
           f"{res.queue_left} states left on queue.")
     print(f"The depth of the complete state graph search is {res.depth}.")
-    for line in collision_report(res.distinct, res.generated):
+    for line in collision_report(res.distinct, res.generated, a.fp128):
         print(line)
     if second is not None:
         seed2, r2 = second

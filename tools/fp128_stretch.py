@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Kip320 3/6/6/3 (6.45 G states: the configuration whose seven narrow-table runs of round 2 lost 0, 1 or 9 states to 64-bit
+fingerprint collisions, profiles/r02_ladder.jsonl) with 128-bit seen-set entries, under several hash seeds.  One JSON line
+per run -> stdout.   python tools/fp128_stretch.py [seed ...]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("KMC_NO_TORCH", "0") != "1":
+    import torch  # noqa: F401
+import kafka_specification_amd as kmc
+
+seeds = [int(x, 0) for x in sys.argv[1:]] or [0, 0x5EED2, 0xC0FFEE]
+wide = os.environ.get("KMC_NARROW", "0") != "1"
+for seed in seeds:
+    cfg = kmc.CheckerConfig(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3,
+                            invariants=("TypeOk", "WeakIsr", "StrongIsr"), hash_seed=seed, wide_fingerprint=wide,
+                            table_capacity=1 << 33, frontier_capacity=1 << 29)
+    t0 = time.time()
+    with kmc.ModelChecker(cfg) as mc:
+        r = mc.run()
+    print(json.dumps(dict(config="Kip320 3/6/6/3", wide_fingerprint=wide, hash_seed=seed, verdict=r.verdict, distinct=r.distinct,
+                          generated=r.generated, generated_repeats=r.generated_repeats, depth=r.depth,
+                          seconds_total=round(r.seconds_total, 3), seconds_expand=round(r.seconds_expand, 3),
+                          table_slots=r.table_capacity, wall_s=round(time.time() - t0, 1))), flush=True)
