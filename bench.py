@@ -257,7 +257,7 @@ def main():
     probes = generated - getattr(r, "generated_repeats", 0)
     g = probes / max(distinct, 1)
     alg_bytes_per_state = 2 * S + 8 * g + 8          # frontier read+write, g probes, 1 claim
-    kernel_s = sum(x.seconds_expand for x in results) / len(results)
+    kernel_s = sum(x.seconds_expand for x in results) / len(results)   # N > 1: the slowest rank's (run_sharded takes the max)
     launches = r.expand_launches
     achieved = alg_bytes_per_state * distinct / max(kernel_s, 1e-12)
     traffic, traffic_source = measured_traffic()
@@ -292,6 +292,14 @@ def main():
                 "ratio_to_randbench_same_mix": dram_bps / ceiling,   # ~1: a microbenchmark of the same mix, not a hard bound
                 "randbench_source": f"{rates_file} mode {mix} = {rates[mix] / 1e9:.1f} G accesses/s x {per_access[0]:.1f} "
                                          f"DRAM B/access ({per_access[1]})"})
+    # N > 1: every rank's own k_expand time against the algorithmic bytes of the states it owns, and what the exchange moved
+    per_rank = extra.pop("per_rank", None) if isinstance(extra, dict) else None
+    if per_rank:
+        for pr in per_rank:
+            ks = max(pr["expand_kernel_seconds_last_step"], 1e-12)
+            pr["achieved_GBps"] = alg_bytes_per_state * pr["states_owned"] / ks / 1e9
+            pr["frac"] = pr["achieved_GBps"] * 1e9 / HBM_PEAK_BPS
+        extra["exchange_bytes_per_step"] = sum(pr["received_bytes_last_step"] for pr in per_rank)
     out = {
         "metric": "distinct states/sec + time-to-exhaustive, KafkaReplication 3-broker",
         "value": value, "unit": "distinct states/s", "n_gpus": max(a.gpus, world), "steps": a.steps,
@@ -312,7 +320,7 @@ def main():
                      "line_granular_bytes_per_distinct_state": 2 * S + 128 * g + 64 * claims / max(distinct, 1),
                      "line_granular_GBps": (2 * S + 128 * g + 64 * claims / max(distinct, 1)) * distinct / max(kernel_s, 1e-12) / 1e9,
                      "useful_fraction_ceiling_of_a_probe": 8.0 / 128.0,
-                     "traffic_source": traffic_source, "random_access": random_access,
+                     "traffic_source": traffic_source, "random_access": random_access, "per_rank": per_rank,
                      "device_source_sha256": device_source_sha256()[:16],
                      "note": "achieved = algorithmic bytes (2*S + 8*g + 8 per distinct state) over the summed durations "
                              "of the step's per-level k_expand launches (HIP events on the engine stream).  traffic = DRAM bytes "

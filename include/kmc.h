@@ -273,6 +273,11 @@ int kmc_comm_selftest(kmc_handle* h);
 int kmc_step_exchange_counts(kmc_handle* h, const int64_t* stats, int32_t n_stats, int64_t* stats_sum,
                              uint64_t* recv_records);
 int kmc_step_exchange_payload(kmc_handle* h);
+/* kmc_step_expand and kmc_step_exchange_counts in one call with ONE stream synchronisation: the send counts go from
+ * k_expand's control block into the all-gather's row on the device (the statistics vector rides in a kernel argument),
+ * so nothing crosses the host between the expansion and the collective.  send_counts may be NULL. */
+int kmc_step_expand_counts(kmc_handle* h, const int64_t* stats, int32_t n_stats, int64_t* stats_sum,
+                           uint64_t* recv_records, uint64_t* send_counts);
 /* The same level step for n_shards handles living in one process on one device (RCCL refuses two ranks on one
  * device): counts and statistics ([n_shards][n_stats]) are combined on the host, runs move device-to-device. */
 int kmc_step_exchange_local(kmc_handle** shards, int32_t n_shards, const int64_t* stats, int32_t n_stats,

@@ -130,6 +130,12 @@ typedef unsigned int u32;
 #else
 #define KMC_INV_MASK(a) ((a).inv_mask)
 #endif
+#ifndef KMC_CHECKSUM
+#define KMC_CHECKSUM 0    // 1: every lane keeps a running sum and xor of the fingerprints it sends into the sink and the level's
+                          //    control block receives their totals — the order-independent checksum KMC_VERIFY compares between
+                          //    its two builds (both are compiled with it).  Not in the default build: four live VGPRs and a
+                          //    wave reduction per launch cost the headline 3 ms when it was always on (profiles/r03_selfcheck_cost.txt)
+#endif
 #ifndef KMC_FAULT_DROP
 #define KMC_FAULT_DROP 0  // 1 (fault injection, tests only): the first flush of block 0 / wave 0 of every LOCAL launch loses the
                           //    successor in lane 5 between the ring and the seen-set — the failure class of round 1's miscompiled
@@ -1044,19 +1050,25 @@ template <int W> struct KmcStager {
                    // in finish(): one atomicAdd per flush on that single line capped the sharded kernel at ~90 M flushes/s,
                    // 5.6x the time of the local kernel for the same work)
     u32 probed, won, outside;  // wave-uniform conservation counters (KmcLevelCtl), added to the level's once, in finish()
-    u64* chk;      // LDS, [2][64]: per-lane running sum and xor of the fingerprints this lane probed
+#if KMC_CHECKSUM
+    u64 csum, cxor;            // per lane: running sum and xor of the fingerprints this lane sent into the sink
+#endif
 #if KMC_PROFILE
     u64* prof;     // the wave's phase accumulators (5 = fingerprint, 6 = probe/claim)
 #endif
 
     KMC_DEV void init(u64* lds) {
         planes = lds; count = 0; filtered = 0; probed = 0; won = 0; outside = 0;
-        chk = lds + W * KMC_QCAP;
-        chk[kmc_lane()] = 0; chk[64 + kmc_lane()] = 0;
+#if KMC_CHECKSUM
+        csum = 0; cxor = 0;
+#endif
     }
     KMC_DEV void account(bool valid, u64 fp) {  // every successor on its way into the sink
         probed += (u32)__popcll(__ballot(valid));
-        if (valid) { chk[kmc_lane()] += fp; chk[64 + kmc_lane()] ^= fp; }
+#if KMC_CHECKSUM
+        csum += valid ? fp : 0ull;
+        cxor ^= valid ? fp : 0ull;
+#endif
     }
 
     KMC_DEV void drain(const KmcArgs& a, u32 n) {  // the n <= 64 staged states -> next frontier
@@ -1106,18 +1118,23 @@ template <int W> struct KmcStager {
         if (filtered && kmc_lane() == 0) atomicAdd(&a.ctl->send_filtered, (u64)filtered);
         filtered = 0;
         if (probed | outside) {
-            u64 sm = chk[kmc_lane()], xr = chk[64 + kmc_lane()];
+#if KMC_CHECKSUM
+            u64 sm = csum, xr = cxor;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 sm += ((u64)(u32)__shfl_xor((int)(u32)(sm >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)sm, off);
                 xr ^= ((u64)(u32)__shfl_xor((int)(u32)(xr >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)xr, off);
             }
+            csum = 0; cxor = 0;
+#endif
             if (kmc_lane() == 0) {
                 atomicAdd(&a.ctl->probed, (u64)probed);
                 if (won) atomicAdd(&a.ctl->won, (u64)won);
                 if (outside) atomicAdd(&a.ctl->outside, (u64)outside);
+#if KMC_CHECKSUM
                 atomicAdd(&a.ctl->fp_sum, sm);
                 atomicXor(&a.ctl->fp_xor, xr);
+#endif
             }
         }
         probed = won = outside = 0;
@@ -1147,25 +1164,28 @@ template <class M> struct KmcSink {
             u64* slot = a.table + 2 * i;
             const KmcSlot2 v = *(const KmcSlot2*)slot;   // one 16-byte load
             u64 v0 = v.x, v1 = v.y;
+            bool mine = false;
             if (v0 == 0) {
                 v0 = atomicCAS(slot, 0ull, fp);
-                if (v0 == 0) {
-                    __hip_atomic_store(slot + 1, chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (a.pred) a.pred[i] = meta;
-                    return true;
-                }
+                mine = v0 == 0;
                 v1 = 0;  // somebody else's claim: its check word must be (re)read
             }
-            if (v0 == fp) {
-                for (u32 spins = 0; v1 == 0; ++spins) {
-                    v1 = atomicOr(slot + 1, 0ull);
-                    if (spins > (1u << 16)) {
-                        atomicOr(&a.ctl->err, KMC_ERR_CHECK_WORD);
-                        return false;
-                    }
-                }
-                if (v1 == chk) return false;
+            // The publication sits HERE, in the straight-line body of the iteration and ahead of every wait below.  Written
+            // as "store; return true" inside the branch above it ended up in the loop's exit block, which a wave only
+            // executes once all its lanes have left the loop — and a lane of the same wave waiting for this very check
+            // word never leaves: the first -fp128 run of the headline hung in exactly that way (bounded, so it reported
+            // KMC_ERR_CHECK_WORD at level 3).
+            if (mine) {
+                __hip_atomic_store(slot + 1, chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.pred) a.pred[i] = meta;
             }
+            const bool wait = !mine && v0 == fp;
+            if (wait) {
+                for (u32 spins = 0; v1 == 0 && spins <= (1u << 16); ++spins) v1 = atomicOr(slot + 1, 0ull);
+                if (v1 == 0) atomicOr(&a.ctl->err, KMC_ERR_CHECK_WORD);
+            }
+            if (mine) return true;
+            if (wait && (v1 == chk || v1 == 0)) return false;
             i = (i + 1) & a.table_mask;
         }
         atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
@@ -1375,7 +1395,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, keep it scalar
     const bool has_meta = (a.flags & KMC_FLAG_META) != 0;
     const u32 ring_planes = W + (has_meta ? 1u : 0u);
-    u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + W * KMC_QCAP + 128);  // q[k*KMC_RING + pos]
+    u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + W * KMC_QCAP);  // q[k*KMC_RING + pos]
     KmcStager<W> out;
     out.init(q + ring_planes * KMC_RING);
     u32 head = 0, count = 0;  // wave-uniform: ring read position / number of QUEUED successors
@@ -1405,7 +1425,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         __builtin_amdgcn_s_setprio(2);
 #endif
 #if KMC_FAULT_DROP
-        const bool dropped = a.mode == KMC_MODE_LOCAL && wave0 == 0 && nflush == 0 && lane == 5;
+        const bool dropped = (a.mode == KMC_MODE_LOCAL || a.mode == KMC_MODE_SHARDED) && wave0 == 0 && nflush == 0 && lane == 5;
         ++nflush;
         KmcSink<M>::process(a, out, lane < nv && !table_full && !dropped, t0, meta0);
 #else
@@ -1629,16 +1649,16 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 
 // dynamic LDS bytes k_expand needs for a state of W words
 KMC_HD inline unsigned kmc_expand_lds_bytes(int W, bool has_meta) {
-    return (unsigned)(KMC_WAVES * ((W + (has_meta ? 1 : 0)) * KMC_RING + W * KMC_QCAP + 128) * 8);  // + the stager's checksum cells
+    return (unsigned)(KMC_WAVES * ((W + (has_meta ? 1 : 0)) * KMC_RING + W * KMC_QCAP) * 8);
 }
 
 // Inserts a list of AoS records (W state words + predecessor fp) into the local table:
 // the initial state, and the receive side of the multi-GPU exchange.
 template <class M> KMC_DEV void kmc_insert_body(const KmcArgs& a) {
     constexpr int W = M::W;
-    __shared__ u64 stage[KMC_WAVES][W * KMC_QCAP + 128];   // the stager's planes + its checksum cells
+    __shared__ u64 stage[KMC_WAVES][W][KMC_QCAP];
     KmcStager<W> out;
-    out.init(&stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0]);
+    out.init(&stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0][0]);
 #if KMC_PROFILE
     u64 prof_dummy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     out.prof = prof_dummy;
@@ -1688,6 +1708,30 @@ template <class M> KMC_DEV void kmc_find_body(const KmcArgs& a) {
         }
 }
 
+// SHARDED: this shard's row of the level's count exchange, built ON THE DEVICE from the control block k_expand has just
+// filled (kmc_step_expand_counts): [destination][sub-buffer] records to ship (clamped to the sub-buffer's capacity, 0 for
+// itself), then the caller's statistics vector, which arrives in the kernel arguments — no host round trip between the
+// expansion and the all-gather.
+#define KMC_ROW_STATS 64
+struct KmcPackArgs {
+    const KmcLevelCtl* ctl;
+    long long* row;     // [nshards * KMC_SEGS + KMC_ROW_STATS]
+    u64 send_cap;
+    u32 nshards, shard;
+    long long stats[KMC_ROW_STATS];
+};
+KMC_DEV void kmc_pack_row_body(const KmcPackArgs& a) {
+    const u32 i = threadIdx.x;
+    const u32 ncount = a.nshards * KMC_SEGS;
+    if (i < ncount) {
+        const u32 d = i / KMC_SEGS, sb = i % KMC_SEGS;
+        const u64 c = a.ctl->send_count[d][sb].v;
+        a.row[i] = d == a.shard ? 0ll : (long long)(c < a.send_cap ? c : a.send_cap);
+    } else if (i < ncount + KMC_ROW_STATS) {
+        a.row[i] = a.stats[i - ncount];
+    }
+}
+
 #ifndef KMC_MIN_WAVES
 #define KMC_MIN_WAVES 6   // __launch_bounds__ second argument for k_expand: minimum waves per SIMD (LDS admits 6 blocks/CU)
 #endif
@@ -1703,5 +1747,8 @@ template <class M> KMC_DEV void kmc_find_body(const KmcArgs& a) {
     }                                                                                                    \
     extern "C" __global__ __launch_bounds__(KMC_BLOCK) void kmc_find_##NAME(KmcArgs a) {                 \
         kmc_find_body<__VA_ARGS__>(a);                                                                   \
+    }                                                                                                    \
+    extern "C" __global__ __launch_bounds__(KMC_BLOCK) void kmc_packrow_##NAME(KmcPackArgs a) {          \
+        kmc_pack_row_body(a);                                                                            \
     }
 #endif  // !KMC_HOST_EMU

@@ -29,7 +29,10 @@
 #define KMC_CHAIN 8
 #define KMC_CTL_SLOTS (3 + KMC_CHAIN)   // two alternating levels + one auxiliary + one per chained level
 
-#define KMC_VERIFY_OPTIONS "-O1 -DKMC_MIN_WAVES=2"   // how the second build of KMC_VERIFY differs from the first
+// KMC_VERIFY: both builds carry the fingerprint checksum (KMC_CHECKSUM, kmc_device.h); the second one differs in how it is
+// compiled — optimisation level and a quarter of the occupancy target, i.e. another register allocation
+#define KMC_VERIFY_PRIMARY_OPTIONS "-DKMC_CHECKSUM=1"
+#define KMC_VERIFY_OPTIONS "-O1 -DKMC_MIN_WAVES=2 -DKMC_CHECKSUM=1"
 
 namespace {
 
@@ -322,7 +325,7 @@ struct kmc_handle {
     int W = 0;
     std::string kname;
     hipModule_t mod = nullptr;
-    hipFunction_t f_expand = nullptr, f_insert = nullptr, f_init = nullptr, f_find = nullptr;
+    hipFunction_t f_expand = nullptr, f_insert = nullptr, f_init = nullptr, f_find = nullptr, f_packrow = nullptr;
     hipModule_t mod_verify = nullptr;       // KMC_VERIFY=1: the same kernels from a second, differently compiled code object
     hipFunction_t f_expand_verify = nullptr;
     uint64_t verify_levels = 0;
@@ -713,11 +716,12 @@ int kmc_precompile(const kmc_config* cfg, const char* arch) {
     if (!cfg) return fail(KMC_E_ARG, "null config");
     std::vector<char> code;
     std::string kname;
-    int rc = get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname);
-    // with KMC_VERIFY set, also the second build kmc_open would load for the differential self-check
-    if (!rc && getenv("KMC_VERIFY") && atoi(getenv("KMC_VERIFY")))
-        rc = get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname, KMC_VERIFY_OPTIONS);
-    return rc;
+    // with KMC_VERIFY set: the two builds kmc_open would load for the differential self-check
+    if (getenv("KMC_VERIFY") && atoi(getenv("KMC_VERIFY"))) {
+        int rc = get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname, KMC_VERIFY_PRIMARY_OPTIONS);
+        return rc ? rc : get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname, KMC_VERIFY_OPTIONS);
+    }
+    return get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname);
 }
 
 static void comm_release(kmc_handle* h);
@@ -783,14 +787,16 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
     std::vector<char> code;
-    int rc = get_code_object(h->cfg, arch, &code, &h->kname);
+    const bool verify = getenv("KMC_VERIFY") && atoi(getenv("KMC_VERIFY"));
+    int rc = get_code_object(h->cfg, arch, &code, &h->kname, verify ? KMC_VERIFY_PRIMARY_OPTIONS : nullptr);
     if (rc) return rc;
     HIP_TRY(hipModuleLoadData(&h->mod, code.data()));
     HIP_TRY(hipModuleGetFunction(&h->f_expand, h->mod, ("kmc_expand_" + h->kname).c_str()));
     HIP_TRY(hipModuleGetFunction(&h->f_insert, h->mod, ("kmc_insert_" + h->kname).c_str()));
     HIP_TRY(hipModuleGetFunction(&h->f_init, h->mod, ("kmc_init_" + h->kname).c_str()));
     HIP_TRY(hipModuleGetFunction(&h->f_find, h->mod, ("kmc_find_" + h->kname).c_str()));
-    if (getenv("KMC_VERIFY") && atoi(getenv("KMC_VERIFY"))) {
+    HIP_TRY(hipModuleGetFunction(&h->f_packrow, h->mod, ("kmc_packrow_" + h->kname).c_str()));
+    if (verify) {
         // Differential self-check for constants no oracle can reach (round 1 met a k_expand build that LOST successors
         // under heavy register spilling): a second code object of the same source, compiled at -O1 with a quarter of
         // the occupancy target, re-generates every level's successors (DRY mode: no table, no frontier) and the
@@ -2048,6 +2054,84 @@ int kmc_step_exchange_counts(kmc_handle* h, const int64_t* stats, int32_t n_stat
     plan_level(h->xcounts.data(), P, me, h->send_cap, (uint64_t)h->rec_words, &sv, &rv, &nrec);
     if (recv_records) *recv_records = nrec;
     h->xcounts_valid = true;
+    return KMC_OK;
+}
+
+// kmc_step_expand + kmc_step_exchange_counts with one stream synchronisation (round 2 took two, with a host-to-device copy
+// of the counts in between): k_expand fills the control block, k_packrow turns its send counters into this shard's row
+// of the all-gather on the device, the collective runs behind it on the same stream, and the host reads the gathered
+// rows back once.  Its own counts come out of the same rows.
+int kmc_step_expand_counts(kmc_handle* h, const int64_t* stats, int32_t n_stats, int64_t* stats_sum, uint64_t* recv_records,
+                           uint64_t* send_counts) {
+    if (!h || !h->stepping) return fail(KMC_E_STATE, "kmc_step_begin first");
+    const int P = h->cfg.n_shards, me = h->cfg.shard_id;
+    if (P == 1 || !h->comm) {  // nothing to gather, or no communicator: the two-step path
+        int rc = kmc_step_expand(h, send_counts);
+        return rc ? rc : kmc_step_exchange_counts(h, stats, n_stats, stats_sum, recv_records);
+    }
+    if (!h->send) return fail(KMC_E_STATE, "no send area");
+    if (n_stats < 0 || n_stats > KMC_EXCHANGE_STATS || (n_stats && (!stats || !stats_sum)))
+        return fail(KMC_E_ARG, "bad statistics vector");
+    static_assert(KMC_ROW_STATS == KMC_EXCHANGE_STATS, "row layout");
+    KmcRccl* r = rccl();
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int rc = ensure_exchange_buffers(h);
+    if (rc) return rc;
+    const int slot = (int)(h->level & 1);
+    if ((rc = zero_ctl(h, slot))) return rc;
+    KmcArgs a = base_args(h, slot);
+    a.fin = h->frontier[h->cur];
+    a.fout = h->frontier[h->cur ^ 1];
+    a.mode = KMC_MODE_SHARDED;
+    a.send = h->send;
+    a.send_cap = h->send_cap;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    if (h->n_cur && (rc = launch(h, h->f_expand, a, expand_grid(h, h->n_cur)))) return rc;
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    const size_t row = (size_t)P * KMC_SEGS + KMC_EXCHANGE_STATS;
+    KmcPackArgs pa{};
+    pa.ctl = h->ctl + slot;
+    pa.row = (long long*)h->xrow_dev;
+    pa.send_cap = h->send_cap;
+    pa.nshards = (uint32_t)P;
+    pa.shard = (uint32_t)me;
+    for (int k = 0; k < KMC_EXCHANGE_STATS; ++k) pa.stats[k] = k < n_stats ? stats[k] : 0;
+    {
+        size_t size = sizeof(pa);
+        void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &pa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+        HIP_TRY(hipModuleLaunchKernel(h->f_packrow, 1, 1, 1, KMC_BLOCK, 1, 1, 0, h->stream, nullptr, config));
+    }
+    NCCL_TRY(r->AllGather(h->xrow_dev, h->xrow_dev + row, row, ncclInt64, h->comm, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->xrow_host + row, h->xrow_dev + row, (size_t)P * row * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the level's only host wait before the payload is posted
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->res.seconds_expand += 1e-3 * ms;
+    h->res.expand_launches++;
+    h->xcounts.assign((size_t)P * P * KMC_SEGS, 0);
+    for (int k = 0; k < n_stats; ++k) stats_sum[k] = 0;
+    for (int s2 = 0; s2 < P; ++s2) {
+        const int64_t* g = h->xrow_host + (size_t)(1 + s2) * row;
+        for (int d = 0; d < P; ++d)
+            for (int sb = 0; sb < KMC_SEGS; ++sb) {
+                const int64_t c = g[d * KMC_SEGS + sb];
+                if (c < 0 || (uint64_t)c > h->send_cap)
+                    return fail(KMC_E_STATE, "exchange: rank %d announces %lld records for a sub-buffer of %llu", s2,
+                                (long long)c, (unsigned long long)h->send_cap);
+                h->xcounts[((size_t)s2 * P + d) * KMC_SEGS + sb] = (uint64_t)c;
+                if (s2 == me) {
+                    h->last_send_counts[d * KMC_SEGS + sb] = (uint64_t)c;
+                    if (send_counts) send_counts[d * KMC_SEGS + sb] = (uint64_t)c;
+                }
+            }
+        for (int k = 0; k < n_stats; ++k) stats_sum[k] += g[P * KMC_SEGS + k];
+    }
+    std::vector<KmcXfer> sv, rv;
+    uint64_t nrec = 0;
+    plan_level(h->xcounts.data(), P, me, h->send_cap, (uint64_t)h->rec_words, &sv, &rv, &nrec);
+    if (recv_records) *recv_records = nrec;
+    h->xcounts_valid = true;
+    h->step_expanded = true;
     return KMC_OK;
 }
 

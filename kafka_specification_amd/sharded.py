@@ -301,6 +301,7 @@ class RcclExchange:
         uid = (C.c_uint8 * nat.KMC_COMM_ID_BYTES)(*box[0])
         with _watchdog("ncclCommInitRank (every rank of the job has to join the communicator)", self.rank):
             nat.check(self.lib.kmc_comm_init(engine.mc.handle, uid))
+        self.level_bytes = []   # bytes this rank received per BFS level (observability: bench.py --gpus N reports them)
 
     def selftest(self):
         with _watchdog("the exchange self-test (an all-gather and a send/receive ring over RCCL on the engine's stream)",
@@ -314,6 +315,18 @@ class RcclExchange:
         nrecv = C.c_uint64()
         nat.check(self.lib.kmc_step_exchange_counts(self.engine.mc.handle, st.ctypes.data_as(C.POINTER(C.c_int64)), N_STATS,
                                                     out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nrecv)))
+        return out, self._deliver
+
+    def expand_and_exchange(self, engines, stats):
+        """The level's expansion and its count exchange in one call under the ABI (kmc_step_expand_counts): the send counts
+        go from k_expand's control block into the all-gather on the device, and the host waits once."""
+        (st,) = stats
+        st = np.ascontiguousarray(st, dtype=np.int64)
+        out = np.zeros(N_STATS, dtype=np.int64)
+        nrecv = C.c_uint64()
+        nat.check(self.lib.kmc_step_expand_counts(self.engine.mc.handle, st.ctypes.data_as(C.POINTER(C.c_int64)), N_STATS,
+                                                  out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nrecv), None))
+        self.level_bytes.append((int(nrecv.value)) * self.engine.record_words * 8)
         return out, self._deliver
 
     def _deliver(self):
@@ -524,7 +537,9 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
     while True:
         # the engines hold level depth+1 (complete); like kmc_run, level l is expanded iff l < max_levels
         can_expand = depth + 1 < max_levels
-        if can_expand and pipelined:
+        if can_expand and pipelined and hasattr(exchange, "expand_and_exchange"):
+            st, deliver = exchange.expand_and_exchange(engines, pending)   # fused under the ABI: one host wait
+        elif can_expand and pipelined:
             sends = [e.expand() for e in engines]
             st, deliver = exchange.exchange(sends, pending)
         else:
@@ -790,6 +805,23 @@ def bench_sharded(c: dict, steps: int, warmup: int, backend: str = "nccl"):
             results.append(run_sharded([eng], ex, cfg, names))
         sync()
         dt = ex.all_reduce_max(time.perf_counter() - t0)
+        # what each rank did in the timed steps, gathered for rank 0's line: seconds inside k_expand (HIP events on the
+        # rank's engine stream), states it owns, bytes it received over the exchange, BFS levels that moved data
+        own = eng.result()
+        lb = getattr(ex, "level_bytes", [])
+        mine = np.zeros((world, 4), dtype=np.float64)
+        mine[rank] = [own.seconds_expand, float(own.distinct), float(sum(lb[-len(results[-1].levels):]) if lb else 0),
+                      float(sum(1 for b in lb[-len(results[-1].levels):] if b))]
+        if world > 1:
+            t = torch.from_numpy(mine).to(device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            per_rank = t.cpu().numpy()
+        else:
+            per_rank = mine
     finally:
         eng.close()
-    return results, dt, {"shards": world, "exchange": type(ex).__name__}
+    extra = {"shards": world, "exchange": type(ex).__name__,
+             "per_rank": [dict(rank=i, expand_kernel_seconds_last_step=float(per_rank[i][0]), states_owned=int(per_rank[i][1]),
+                               received_bytes_last_step=int(per_rank[i][2]), levels_with_traffic=int(per_rank[i][3]))
+                          for i in range(world)]}
+    return results, dt, extra

@@ -200,7 +200,8 @@ def test_live_kip279_double_binding_and_kip320_double_disjunct():
             bf = [k for lab, k in succ if lab == "BecomeFollowerTruncateKip279"]
             for k in set(bf):
                 n = bf.count(k)
-                follower_empty = any(ck.unkey(k)["replicaLog"].d[rr].d["endOffset"] == 0 and
+                # the replica that became a follower is the one whose state changed; was ITS log empty before the step?
+                follower_empty = any(st["replicaLog"].d[rr].d["endOffset"] == 0 and
                                      ck.unkey(k)["replicaState"].d[rr] != st["replicaState"].d[rr] for rr in consts["Replicas"])
                 assert n == (2 if follower_empty else 1)
                 doubles += n == 2
