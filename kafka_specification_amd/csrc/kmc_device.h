@@ -1113,10 +1113,11 @@ template <int W> struct KmcStager {
         }
         count = n - room;
     }
-    KMC_DEV void finish(const KmcArgs& a) {
+    KMC_DEV void finish(const KmcArgs& a, bool publish_counters = true) {
         if (count) drain(a, count);
         if (filtered && kmc_lane() == 0) atomicAdd(&a.ctl->send_filtered, (u64)filtered);
         filtered = 0;
+        if (!publish_counters) return;   // k_expand folds them into its per-block tail (kmc_expand_body)
         if (probed | outside) {
 #if KMC_CHECKSUM
             u64 sm = csum, xr = cxor;
@@ -1454,6 +1455,9 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             return;
         }
     }
+    __shared__ u32 kmc_tail[32];   // per block: generated[0..15], deadlocks, probed, won, outside, repeats (see the end)
+    if (threadIdx.x < 32) kmc_tail[threadIdx.x] = 0;
+    __syncthreads();
 #pragma clang loop unroll(disable)
     for (int sg = 0; sg < KMC_SEGS; ++sg) {
     u64 seg_n = a.seg_count[sg];
@@ -1622,13 +1626,16 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         const u64 dm = __ballot(valid && nsucc == 0);
         if (dm) {
             deadlocks += __popcll(dm);
+            // one no-return atomicMax per deadlocked state (1.4 M at the headline, all on one line: fire-and-forget).
+            // Reducing over the wave first was tried: its twelve cross-lane moves and their temporaries pushed k_expand over
+            // the 80-VGPR budget (107 VGPRs, 4 waves per SIMD) and the headline to 38.8 ms (profiles/r03_tail.txt)
             if (valid && nsucc == 0) atomicMax(&a.ctl->deadlock_fp_inv, ~kmc_fingerprint<W>(s, a.seed));
         }
     }
     }
     KMC_T(tt0);
     while (count) flush(count < KMC_FLUSH_N ? count : KMC_FLUSH_N);
-    out.finish(a);
+    out.finish(a, KMC_CHECKSUM != 0);
     KMC_T(tt1);
     KMC_TADD(4, tt0, tt1);
 #if KMC_PROFILE
@@ -1636,15 +1643,34 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     if (lane == 0)
         for (int k = 0; k < 8; ++k) atomicAdd(&a.ctl->prof[k], prof_acc[k]);
 #endif
+    // The level's counters leave the kernel ONCE PER BLOCK: every wave adds its share to an LDS tail, the block's last
+    // barrier, and wave 0 issues one atomicAdd instruction over the 21 cells.  (Published per wave — two more atomic
+    // instructions and their operands live to the end — k_expand no longer fitted 80 VGPRs: more than 8 spilled at 6 waves
+    // per SIMD, so the register-budget rule of get_code_object rebuilt it for 4 waves per SIMD, 107 VGPRs, and the
+    // headline took 38.9 ms instead of 35.0: profiles/r03_tail.txt.  The kernel sits on the edge of that budget; any
+    // addition to this function has to be checked against `.vgpr_count` of the headline's code object.)
+    u32 repeats = 0;
     if constexpr (M::HAS_EXTRA) {
         u32 x = extra_lane;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
         gen_lane += (lane == (u32)M::EXTRA_KIND) ? x : 0u;
-        if (lane == 0 && x) atomicAdd(&a.ctl->repeats, (u64)x);
+        repeats = x;
     }
-    if (lane < (u32)M::NKINDS && gen_lane) atomicAdd(&a.ctl->generated[lane], (u64)gen_lane);
-    if (lane == 0 && deadlocks) atomicAdd(&a.ctl->deadlock_count, (u64)deadlocks);
+    if (lane < (u32)M::NKINDS && gen_lane) atomicAdd(&kmc_tail[lane], gen_lane);
+#if !KMC_CHECKSUM   // (the checksum builds publish probed / won / outside per wave, with the checksum: KmcStager::finish)
+    const u32 mine = lane == 16 ? deadlocks : lane == 17 ? out.probed : lane == 18 ? out.won : lane == 19 ? out.outside : lane == 20 ? repeats : 0u;
+#else
+    const u32 mine = lane == 16 ? deadlocks : lane == 20 ? repeats : 0u;
+#endif
+    if (lane >= 16 && mine) atomicAdd(&kmc_tail[lane], mine);
+    __syncthreads();
+    if (wib == 0 && lane < 21) {
+        const u32 v = kmc_tail[lane];
+        u64* dst = lane < 16 ? &a.ctl->generated[lane] : lane == 16 ? &a.ctl->deadlock_count : lane == 17 ? &a.ctl->probed
+                 : lane == 18 ? &a.ctl->won : lane == 19 ? &a.ctl->outside : &a.ctl->repeats;
+        if (v) atomicAdd(dst, (u64)v);
+    }
 }
 
 // dynamic LDS bytes k_expand needs for a state of W words

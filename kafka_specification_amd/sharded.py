@@ -326,7 +326,9 @@ class RcclExchange:
         nrecv = C.c_uint64()
         nat.check(self.lib.kmc_step_expand_counts(self.engine.mc.handle, st.ctypes.data_as(C.POINTER(C.c_int64)), N_STATS,
                                                   out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nrecv), None))
-        self.level_bytes.append((int(nrecv.value)) * self.engine.record_words * 8)
+        if not hasattr(self, "level_bytes"):
+            self.level_bytes = []
+        self.level_bytes.append(int(nrecv.value) * self.engine.record_words * 8)
         return out, self._deliver
 
     def _deliver(self):

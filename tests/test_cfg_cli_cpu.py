@@ -178,14 +178,14 @@ def test_collision_estimate_and_tlc_log_parser():
     """The summary prints TLC's estimate of a silent fingerprint collision; tools/tlc_log_diff.py reads the same
     message formats back (it is what tools/verify_with_tlc.sh uses on a real TLC log)."""
     import sys
-    lines = tlc.collision_report(279753922, 888138046)
+    lines = tlc.collision_report(279753922, 901914892)
     assert "calculated (optimistic):  val = 9.23E-03" in lines[1] and "2.12E-03" in lines[2]
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import tlc_log_diff
     ok = ("Model checking completed. No error has been found.\n"
-          "888138046 states generated, 279753922 distinct states found, 0 states left on queue.\n"
+          "901914892 states generated, 279753922 distinct states found, 0 states left on queue.\n"
           "The depth of the complete state graph search is 46.\n")
-    assert tlc_log_diff.parse(ok) == dict(verdict="ok", invariant=None, trace_length=0, generated=888138046,
+    assert tlc_log_diff.parse(ok) == dict(verdict="ok", invariant=None, trace_length=0, generated=901914892,
                                           distinct=279753922, left=0, depth=46)
     bad = ("Error: Invariant StrongIsr is violated.\nError: The behavior up to this point is:\n"
            "State 1: <Initial predicate>\n/\\ x = 1\n\nState 2: <Next line 3, col 1 to line 4, col 2 of module M>\n/\\ x = 2\n\n"

@@ -140,7 +140,7 @@ def test_headline_seed_independence_at_medium_size():
         with ModelChecker(c) as mc:
             res.append(mc.run())
     assert res[0].distinct == res[1].distinct == 18731224
-    assert res[0].levels == res[1].levels and res[0].generated == res[1].generated == 55208512
+    assert res[0].levels == res[1].levels and res[0].generated == res[1].generated == 56197186   # 55,208,512 probed successors + 988,674 double disjuncts (Kip320.tla:82-83)
 
 
 def test_cli_prints_tlc_shaped_output(capsys):

@@ -17,11 +17,11 @@ wide = os.environ.get("KMC_NARROW", "0") != "1"
 for seed in seeds:
     cfg = kmc.CheckerConfig(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3,
                             invariants=("TypeOk", "WeakIsr", "StrongIsr"), hash_seed=seed, wide_fingerprint=wide,
-                            table_capacity=1 << 33, frontier_capacity=1 << 29)
+                            table_capacity=1 << 33, frontier_capacity=1 << 30)
     t0 = time.time()
     with kmc.ModelChecker(cfg) as mc:
         r = mc.run()
     print(json.dumps(dict(config="Kip320 3/6/6/3", wide_fingerprint=wide, hash_seed=seed, verdict=r.verdict, distinct=r.distinct,
-                          generated=r.generated, generated_repeats=r.generated_repeats, depth=r.depth,
+                          generated=r.generated, generated_repeats=r.generated_repeats, depth=r.depth, widest_level=max(r.levels),
                           seconds_total=round(r.seconds_total, 3), seconds_expand=round(r.seconds_expand, 3),
                           table_slots=r.table_capacity, wall_s=round(time.time() - t0, 1))), flush=True)
