@@ -179,7 +179,7 @@ def test_collision_estimate_and_tlc_log_parser():
     message formats back (it is what tools/verify_with_tlc.sh uses on a real TLC log)."""
     import sys
     lines = tlc.collision_report(279753922, 901914892)
-    assert "calculated (optimistic):  val = 9.23E-03" in lines[1] and "2.12E-03" in lines[2]
+    assert "calculated (optimistic):  val = 9.44E-03" in lines[1] and "2.12E-03" in lines[2]
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import tlc_log_diff
     ok = ("Model checking completed. No error has been found.\n"

@@ -278,18 +278,18 @@ def test_checkpoint_and_recover(tmp_path):
     # vector, or a truncated body are refused before anything is copied to the device
     import struct
     raw = bytearray(open(path, "rb").read())
-    hdr = 8 + 112 + 8 * 8                       # magic + kmc_config + 8 header words
-    res_bytes = len(raw)                        # (located below through the known tail layout)
-    nlev = struct.unpack_from("<Q", raw, 8 + 112 + 5 * 8)[0]
-    assert nlev == 11
     from kafka_specification_amd import _native as nat
     import ctypes as C
+    cfg_bytes = C.sizeof(nat.KmcConfig)
+    hdr = 8 + cfg_bytes + 8 * 8                 # magic + kmc_config + 8 header words
+    nlev = struct.unpack_from("<Q", raw, 8 + cfg_bytes + 5 * 8)[0]
+    assert nlev == 11
     seg_off = hdr + C.sizeof(nat.KmcResult) + 8 * nlev
     bad = bytearray(raw)
     struct.pack_into("<Q", bad, seg_off, 1 << 40)          # seg_n[0]: far beyond seg_cap
     (tmp_path / "bad_seg.ckpt").write_bytes(bad)
     bad = bytearray(raw)
-    struct.pack_into("<Q", bad, 8 + 112 + 5 * 8, 1 << 50)  # n_levels
+    struct.pack_into("<Q", bad, 8 + cfg_bytes + 5 * 8, 1 << 50)  # n_levels
     (tmp_path / "bad_levels.ckpt").write_bytes(bad)
     (tmp_path / "short.ckpt").write_bytes(raw[:len(raw) // 2])
     for name in ("bad_seg.ckpt", "bad_levels.ckpt", "short.ckpt"):
