@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1119,8 +1120,24 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             // (46 levels, 7 of them under 1024 states: 2.4 ms of a 38 ms check in round 1).
             uint64_t B = max_levels - h->level;
             if (B > KMC_CHAIN) B = KMC_CHAIN;
-            HIP_TRY(hipMemsetAsync(h->ctl + 3, 0, B * sizeof(KmcLevelCtl), h->stream));
             const uint64_t fan = max_fanout(h) ? max_fanout(h) : 1;
+            {
+                // The load limit of the table (0.92, below) is a HOST decision, taken after a level: a batch is therefore
+                // only as long as its levels provably stay under it — each level adds at most min(fan x its input,
+                // frontier capacity) states.  (Without this a batch could run the table far past the limit before the
+                // host looked, and after such a stop h->cur / seg_n no longer described the device's frontier: ADVICE r2.)
+                const double room = 0.92 * (double)h->table_cap - (double)r.distinct;
+                uint64_t in = h->n_cur, fit = 0;
+                double sum = 0;
+                for (; fit < B; ++fit) {
+                    const uint64_t out = in > h->fcap / fan ? h->fcap : in * fan;
+                    sum += (double)out;
+                    if (fit > 0 && sum > room) break;   // (the first level always runs: the host checks right after it)
+                    in = out;
+                }
+                B = fit ? fit : 1;
+            }
+            HIP_TRY(hipMemsetAsync(h->ctl + 3, 0, B * sizeof(KmcLevelCtl), h->stream));
             uint64_t bound = h->n_cur;   // upper bound on the size of the level launch i expands
             for (uint64_t i = 0; i < B; ++i) {
                 if (!h->ev_chain[2 * i]) {
@@ -1813,20 +1830,20 @@ struct KmcRccl {
 // librccl is bound at run time: libkmc.so must load on a box without RCCL (single-GPU use, the CPU-side
 // ABI tests), and inside a PyTorch process the name resolves to the copy the wheel has already loaded
 // (same SONAME), so both sides of the process talk to one RCCL.
-KmcRccl* rccl() {
-    static KmcRccl r;
-    static bool tried = false;
-    if (tried) return r.lib ? &r : nullptr;
-    tried = true;
+std::string g_rccl_error;   // why librccl could not be bound (dlerror() is read ONCE, where it happens: a second call returns NULL)
+
+void rccl_bind(KmcRccl& r) {
     const char* names[] = {getenv("KMC_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         if (!n || !*n) continue;
         if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        const char* e = dlerror();
+        g_rccl_error += std::string(g_rccl_error.empty() ? "" : "; ") + n + ": " + (e ? e : "dlopen failed");
     }
-    if (!r.lib) return nullptr;
+    if (!r.lib) return;
 #define KMC_SYM(field, name)                                                     \
     r.field = (decltype(r.field))dlsym(r.lib, name);                             \
-    if (!r.field) { r.lib = nullptr; return nullptr; }
+    if (!r.field) { const char* e = dlerror(); g_rccl_error = std::string(name) + ": " + (e ? e : "symbol not found"); r.lib = nullptr; return; }
     KMC_SYM(GetUniqueId, "ncclGetUniqueId")
     KMC_SYM(CommInitRank, "ncclCommInitRank")
     KMC_SYM(CommDestroy, "ncclCommDestroy")
@@ -1837,7 +1854,13 @@ KmcRccl* rccl() {
     KMC_SYM(GroupEnd, "ncclGroupEnd")
     KMC_SYM(GetErrorString, "ncclGetErrorString")
 #undef KMC_SYM
-    return &r;
+}
+
+KmcRccl* rccl() {   // bound once per process, also when several host threads arrive at the same time
+    static KmcRccl r;
+    static std::once_flag once;
+    std::call_once(once, rccl_bind, std::ref(r));
+    return r.lib ? &r : nullptr;
 }
 
 #define NCCL_TRY(expr)                                                                                          \
@@ -1933,7 +1956,7 @@ static void comm_release(kmc_handle* h) {
 int kmc_comm_unique_id(uint8_t* id) {
     if (!id) return fail(KMC_E_ARG, "null argument");
     KmcRccl* r = rccl();
-    if (!r) return fail(KMC_E_DEVICE, "librccl not found (dlopen librccl.so.1): %s", dlerror() ? dlerror() : "?");
+    if (!r) return fail(KMC_E_DEVICE, "librccl could not be bound: %s", g_rccl_error.empty() ? "?" : g_rccl_error.c_str());
     ncclUniqueId u;
     NCCL_TRY(r->GetUniqueId(&u));
     static_assert(sizeof u == KMC_COMM_ID_BYTES, "ncclUniqueId size");

@@ -715,6 +715,18 @@ def make_engine_and_exchange(cfg: CheckerConfig, rank: int, world: int, local: i
     eng, ex, err = None, None, ""
     try:
         eng = HipShardEngine(cfg, rank, world, local, native=True)
+    except Exception as e:   # noqa: BLE001 — out of memory, a kernel that does not compile: the other ranks must hear of it
+        err = f"{type(e).__name__}: {e}"
+    # agree on the engines BEFORE the unique-id broadcast inside RcclExchange: a rank that skipped that broadcast would leave
+    # the others waiting in it for ever (the watchdog only covers ncclCommInitRank and the self-test)
+    flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if eng is not None:
+            eng.close()
+        raise RuntimeError(f"rank {rank}: a shard engine could not be created on some rank"
+                           f"{' (here: ' + err + ')' if err else ''}; no rank continues")
+    try:
         ex = RcclExchange(eng, device)
         ex.selftest()
     except Exception as e:   # noqa: BLE001 — any failure here must reach the agreement below, not kill one rank

@@ -115,9 +115,11 @@ def main(argv=None) -> int:
         elif t in TLC_REFUSED_FLAGS:
             print(f"Error: {t} is not supported: {TLC_REFUSED_FLAGS[t]}", file=sys.stderr)
             return 2
-        elif t == "-checkpoint" and i + 1 < len(argv) and argv[i + 1].lstrip("-").isdigit():
+        elif (t == "-checkpoint" and i + 1 < len(argv) and argv[i + 1].lstrip("-").isdigit()
+              and not os.path.isdir(argv[i + 1])):
             # TLC's -checkpoint takes an interval in minutes; here a search takes milliseconds to seconds and -checkpoint DIR
-            # names where a level-limited sharded search leaves its state
+            # names where a level-limited sharded search leaves its state (a directory that exists under a numeric name is
+            # a directory; to CREATE one with a numeric name say ./2024)
             print(f"Note: -checkpoint {argv[i + 1]} (TLC's interval in minutes) is accepted and ignored; "
                   "-checkpoint DIR saves a level-limited sharded search", file=sys.stderr)
             i += 1

@@ -5,7 +5,8 @@ concurrent rank: each thread drives its own HipShardEngine through sharded.run_s
 rank does; only the transport under the nccl* calls is the stand-in (tests/mock_rccl.cpp).  Checked against the C oracle.
 Run by tests/test_gpu_native_exchange_threads.py in a fresh process (the engine binds "RCCL" once per process).
 
-usage: native_exchange_threads.py MODEL N L R E P inv1,inv2 [trace]     -> one JSON line, exit code 0 when everything agrees"""
+usage: native_exchange_threads.py MODEL N L R E P inv1,inv2 [trace] [levels=K]   -> one JSON line, exit code 0 when everything agrees
+(levels=K: stop after K BFS levels and compare with the oracle's prefix — for constants nothing can exhaust)"""
 import ctypes as C
 import json
 import os
@@ -64,13 +65,20 @@ class ThreadRcclExchange(sharded.RcclExchange):
 def main():
     model, N, L, R, E, P = sys.argv[1], *map(int, sys.argv[2:7])
     inv = tuple(x for x in sys.argv[7].split(",") if x)
-    trace = len(sys.argv) > 8 and sys.argv[8] == "trace"
-    o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv))
+    trace = "trace" in sys.argv[8:]
+    K = next((int(a[7:]) for a in sys.argv[8:] if a.startswith("levels=")), 0)
+    if K:   # a prefix: the oracle stops after the level that crosses max_states; o2 stops right after producing level K
+        o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv, threads=8, max_states=1_500_000))
+        assert len(o.levels) > K
+        o2 = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv, threads=8, max_states=sum(o.levels[:K - 1]) + 1))
+        assert len(o2.levels) == K
+    else:
+        o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv))
     consts = dict(n_replicas=N, log_size=L, max_leader_epoch=E)      # AsyncIsr: (N, MaxOffset, MaxVersion); R is unused
     if model != "AsyncIsr":
         consts["max_records"] = R
-    cfg = CheckerConfig(model=model, **consts, invariants=inv, keep_trace=trace, table_capacity=1 << 20,
-                        frontier_capacity=1 << 18, send_capacity=1 << 16)
+    cfg = CheckerConfig(model=model, **consts, invariants=inv, keep_trace=trace, table_capacity=1 << (22 if K else 20),
+                        frontier_capacity=1 << (20 if K else 18), send_capacity=1 << 16, max_levels=K)
     lib = nat.lib()
     uid = (C.c_uint8 * nat.KMC_COMM_ID_BYTES)()
     nat.check(lib.kmc_comm_unique_id(uid))          # main thread: also the one-time binding of "librccl"
@@ -91,7 +99,7 @@ def main():
     for t in threads:
         t.start()
     for t in threads:
-        t.join(90)
+        t.join(150 if K else 90)
     hung = [r for r, t in enumerate(threads) if t.is_alive()]
     out = dict(model=model, N=N, L=L, R=R, E=E, P=P, trace=trace, errors=errors, hung=hung)
     ok = not hung and not any(errors)
@@ -100,9 +108,14 @@ def main():
         same_everywhere = all((r.verdict, r.distinct, r.generated, r.levels, r.violated_invariant, r.violation_depth) ==
                               (r0.verdict, r0.distinct, r0.generated, r0.levels, r0.violated_invariant, r0.violation_depth)
                               for r in results)
-        matches = (r0.verdict == o.verdict and r0.distinct == o.distinct and r0.generated == o.generated and
-                   r0.levels == o.levels and r0.deadlock_states == o.deadlock_states and r0.violated_invariant == o.viol_inv)
-        if o.viol_inv:
+        if K:
+            matches = (r0.verdict == "level_limit" and r0.levels == o.levels[:K] and r0.generated == o2.generated and
+                       list(r0.action_generated.values()) == o2.action_generated[:len(r0.action_generated)] and
+                       r0.violated_invariant is None)
+        else:
+            matches = (r0.verdict == o.verdict and r0.distinct == o.distinct and r0.generated == o.generated and
+                       r0.levels == o.levels and r0.deadlock_states == o.deadlock_states and r0.violated_invariant == o.viol_inv)
+        if o.viol_inv and not K:
             matches = matches and r0.violation_depth == o.viol_depth and r0.violation_count == o.viol_count
         out.update(verdict=r0.verdict, distinct=r0.distinct, generated=r0.generated, depth=r0.depth,
                    same_on_every_rank=same_everywhere, matches_oracle=matches,

@@ -28,7 +28,7 @@ def _build_mock():
 def _run(*args):
     _build_mock()
     p = subprocess.run([sys.executable, os.path.join(HERE, "native_exchange_threads.py"), *map(str, args)],
-                       capture_output=True, text=True, timeout=150)
+                       capture_output=True, text=True, timeout=240)
     line = next((l for l in p.stdout.splitlines() if l.startswith("RESULT ")), None)
     assert line, (p.stdout[-800:], p.stderr[-1500:])
     out = json.loads(line[7:])
@@ -55,3 +55,12 @@ def test_trace_records_carry_the_predecessor_word_through_the_native_exchange():
 def test_async_isr_constraint_through_the_native_exchange():
     out = _run("AsyncIsr", 3, 2, 0, 2, 2, "ValidHighWatermark")
     assert out["matches_oracle"] and out["verdict"] == "ok"
+
+
+def test_baseline_config5_seven_brokers_through_the_native_exchange_with_eight_ranks():
+    """BASELINE.json config 5 at its own constants (models/Kip320_7brokers.cfg: 7 brokers, LogSize 8, MaxRecords 8,
+    MaxLeaderEpoch 3 — 9-word states, 10-word records because the predecessor fingerprint travels too) over 8 concurrent
+    ranks: the first 7 BFS levels (1.27 M states; nothing exhausts this configuration) equal the oracle's prefix in level
+    sizes and per-action generated counts, identically on every rank."""
+    out = _run("Kip320", 7, 8, 8, 3, 8, "TypeOk", "trace", "levels=7")
+    assert out["matches_oracle"] and out["same_on_every_rank"] and out["verdict"] == "level_limit"

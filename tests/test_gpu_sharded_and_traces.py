@@ -466,3 +466,38 @@ def test_sharded_checkpoint_and_recover(tmp_path, P):
     os.replace(os.path.join(ckpt, "tmp"), os.path.join(ckpt, f"shard1of{P}.ckpt"))
     with pytest.raises(KmcError):
         check_loopback(CheckerConfig(**base), P, resume_dir=ckpt)      # shard files swapped: refused
+
+
+def test_baseline_config5_seven_brokers_on_eight_logical_shards():
+    """BASELINE.json config 5 (Kip320, 7 brokers, LogSize 8, MaxRecords 8, MaxLeaderEpoch 3: W = 9 words, 10-word exchange
+    records with keep_trace) through the exchange under the ABI on P = 8 logical shards of one GPU.  The configuration is
+    not exhaustible (8.8e8 states after 11 levels), so the pin is the oracle's prefix: the sizes of the first 7 levels,
+    per-action generated counts, and the exact state SETS of the levels up to 50 k states, gathered over the shards."""
+    from kafka_specification_amd.sharded import HipShardEngine, NativeLoopbackExchange, run_sharded
+    inv, K, P = ("TypeOk",), 7, 8
+    o = kmo.Run(kmo.make_config("Kip320", N=7, L=8, R=8, E=3, invariants=inv, threads=8, max_states=1_500_000))
+    o2 = kmo.Run(kmo.make_config("Kip320", N=7, L=8, R=8, E=3, invariants=inv, threads=8, max_states=sum(o.levels[:K - 1]) + 1))
+    assert len(o.levels) > K and len(o2.levels) == K
+    cfg = CheckerConfig(model="Kip320", n_replicas=7, log_size=8, max_records=8, max_leader_epoch=3, invariants=inv,
+                        keep_trace=True, max_levels=K, table_capacity=1 << 22, frontier_capacity=1 << 20, send_capacity=1 << 16)
+    engines = [HipShardEngine(cfg, s, P, 0, native=True) for s in range(P)]
+    sets = {}
+    try:
+        assert engines[0].record_words == 10 and engines[0].W == 9
+
+        def level_done(info):      # the shards still hold the level just recorded (its expansion is in flight, not finished)
+            if info["new_states"] <= 50_000:
+                got = set()
+                for e in engines:
+                    got |= {e.mc.unpack(row) for row in e.mc.frontier_states()}
+                sets[info["depth"]] = got
+        res = run_sharded(engines, NativeLoopbackExchange(engines), cfg, engines[0].mc.action_names(), level_done)
+    finally:
+        for e in engines:
+            e.close()
+    assert res.verdict == "level_limit" and res.levels == o.levels[:K]
+    assert res.generated == o2.generated
+    assert list(res.action_generated.values()) == o2.action_generated[:len(res.action_generated)]
+    assert sorted(sets) == [1, 2, 3, 4, 5]
+    for d, got in sets.items():
+        assert got == o.level_states(d - 1), f"level {d}: state sets differ"
