@@ -323,7 +323,7 @@ KMC_HD inline u32 kmc_owner(u64 fp, u32 nshards) { return (u32)((((fp >> 40) & 0
 // ========================================================================================
 template <long long MAXID> struct KmcIdSequence {
     static constexpr int W = 1, NKINDS = 1, NINST = 1;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false;
     struct Pre { u64 nextId; };
     static KMC_DEV void init(u64* w) { w[0] = 0; }  // IdSequence.tla:37
     static KMC_DEV Pre extract(const u64* s) { return Pre{s[0]}; }
@@ -347,7 +347,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
     static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_FINITE_REPLICATED_LOG, N, L, 0, 0, K);
     static_assert(Y.valid, "FiniteReplicatedLog parameters cannot be packed");
     static constexpr int W = Y.W, NKINDS = 3;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false;
     static constexpr int C_APPEND = N * K, C_TRUNC = N * L, C_REPL = N * (N - 1);
     static constexpr int NINST = C_APPEND + C_TRUNC + C_REPL;
     static constexpr u64 MR = (1ull << Y.BR) - 1;
@@ -422,7 +422,7 @@ template <int N, int MO, int V> struct KmcAsyncIsr {
     static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_ASYNC_ISR, N, MO, 0, V, 0);
     static_assert(Y.valid, "AsyncIsr parameters cannot be packed (need N <= 6, MaxVersion <= 7)");
     static constexpr int W = Y.W, NKINDS = 7;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = true;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = true, KIND_MAJOR = false;
     static constexpr int NS = 1 << N;  // isr masks = request bits per version
     // Next (AsyncIsr.tla:152-159) flattened into instances, one per binding of each disjunct's \E
     static constexpr int B0 = 0;             // ControllerShrinkIsr        (replica # Leader)
@@ -552,8 +552,8 @@ template <int N, int MO, int V> struct KmcAsyncIsr {
 // ========================================================================================
 // KafkaReplication.tla and the five modules that give it a Next
 // ========================================================================================
-template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
-    static constexpr KmcLayout Y = kmc_make_layout(MODEL, N, L, R, E, 0);
+template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struct KmcKafka {
+    static constexpr KmcLayout Y = kmc_make_layout(MODEL, N, L, R, E, 0, LM);
     static_assert(Y.valid, "Kafka model parameters cannot be packed (need L*bits(record) <= 64, N <= 8, E <= 7)");
     static constexpr int W = Y.W;
     static constexpr bool FIRST = MODEL == KMC_MODEL_KIP320_FIRST_TRY;
@@ -714,10 +714,11 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
         const u32 o = p.end(f) - 1;
         return o < p.end(l) && rec_epoch(rec_at(p.logv(l), o)) != rec_epoch(rec_at(p.logv(f), o));
     }
-    // FirstNonMatchingOffsetFromTail(leader, follower) (Kip279.tla:27-45)
-    template <int l, int f> static KMC_DEV u32 first_non_matching(const Pre& p) {
-        const LogT x = p.logv(l) ^ p.logv(f);
-        const u32 lim = kmc_min(p.end(l), p.end(f));  // leader empty => no match => 0
+    // FirstNonMatchingOffsetFromTail(leader, follower) (Kip279.tla:27-45), on the two logs and end offsets as values
+    // (shared by the instance-major effects, where leader and follower are compile-time, and the kind-major ones below)
+    static KMC_DEV u32 first_non_matching_v(LogT logl, LogT logf, u32 endl, u32 endf) {
+        const LogT x = logl ^ logf;
+        const u32 lim = kmc_min(endl, endf);  // leader empty => no match => 0
         u32 best = 0;
         kmc_static_for<0, L>([&](auto O) {
             constexpr int o = decltype(O)::value;
@@ -725,18 +726,23 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
         });
         return best;
     }
-    // LookupOffsetForEpoch(leader, follower, epoch) (Kip101.tla:27-39)
-    template <int l, int f> static KMC_DEV u32 lookup_offset_for_epoch(const Pre& p, u32 epoch) {
-        const u32 el = p.end(l);
-        u32 first_larger = p.hw(f);  // offsetWithLargerEpochs = {} -> follower hw
+    template <int l, int f> static KMC_DEV u32 first_non_matching(const Pre& p) {
+        return first_non_matching_v(p.logv(l), p.logv(f), p.end(l), p.end(f));
+    }
+    // LookupOffsetForEpoch(leader, follower, epoch) (Kip101.tla:27-39), on the leader's log / end and the follower's hw
+    static KMC_DEV u32 lookup_offset_for_epoch_v(LogT logl, u32 el, u32 hwf, u32 epoch) {
+        u32 first_larger = hwf;  // offsetWithLargerEpochs = {} -> follower hw
         bool found = false;
         kmc_static_for<0, L>([&](auto O) {
             constexpr int o = decltype(O)::value;
-            if (!found && (u32)o < el && rec_epoch(rec_at(p.logv(l), o)) > epoch) { first_larger = o; found = true; }
+            if (!found && (u32)o < el && rec_epoch(rec_at(logl, o)) > epoch) { first_larger = o; found = true; }
         });
-        if (el == 0) return p.hw(f);
-        if (rec_epoch(rec_at(p.logv(l), el - 1)) == epoch) return el;
+        if (el == 0) return hwf;
+        if (rec_epoch(rec_at(logl, el - 1)) == epoch) return el;
         return first_larger;
+    }
+    template <int l, int f> static KMC_DEV u32 lookup_offset_for_epoch(const Pre& p, u32 epoch) {
+        return lookup_offset_for_epoch_v(p.logv(l), p.end(l), p.hw(f), epoch);
     }
 
     // ---- one action instance: guard + effect ---------------------------------------------
@@ -920,6 +926,217 @@ template <int MODEL, int N, int L, int R, int E> struct KmcKafka {
             g = kmc_and(g, needs_truncation<f, l>(p));
             g = kmc_and(g, off <= p.end(f));
             return g;
+        }
+    }
+
+    // ---- kind-major effects (replica-major layouts; k_expand's pass 2) ---------------------------
+    // inst<I> above fixes the replicas / request of a binding at COMPILE time, so pass 2 must run one leaf per
+    // (kind, binding) some lane enabled: 30 leaves per 64-state tile at the headline, each for ~7 busy lanes.  apply<K>
+    // takes the binding of its kind at RUN time, per lane: every lane applies ITS OWN next enabled binding of kind K in
+    // the same leaf, so a tile needs max-over-lanes(enabled bindings of K) leaves per kind — 12.6 per tile instead of
+    // 30 (tools/locality_sim.cpp).  That needs a field of a run-time replica to be cheap: under the replica-major layout
+    // it is "select word r, extract at a compile-time offset".  Guards are NOT re-evaluated here (pass 1 did, with
+    // inst<I>); tests/host_emu.cpp holds apply<K>(b) to inst<B_K + b> on every enabled binding of every visited state.
+    static constexpr int kind_base(int k) {
+        return k == 0 ? B0 : k == 1 ? B1 : k == 2 ? B2 : k == 3 ? B3 : k == 4 ? B4 : k == 5 ? B5 : k == 6 ? B6
+             : k == 7 ? B7 : k == 8 ? B8 : k == 9 ? B9 : NINST;
+    }
+    static constexpr int kind_count(int k) { return kind_base(k + 1) - kind_base(k); }
+    static constexpr int max_kind_count() {
+        int m = 0;
+        for (int k = 0; k < NKINDS; ++k) m = kind_count(k) > m ? kind_count(k) : m;
+        return m;
+    }
+    // (a kind's enabled bindings are one per-lane bitset of at most 64 bits in pass 2)
+    static constexpr bool KIND_MAJOR = Y.rm != 0 && max_kind_count() <= 64;
+    using KindBits = typename KmcLogWord<(max_kind_count() <= 32)>::type;
+    // bits [kind_base(K), kind_base(K+1)) of the per-lane "enabled instances" bitset en32[] (32-bit words), as one value
+    template <int K> static KMC_DEV KindBits kind_bits(const u32* en32) {
+        constexpr int lo = kind_base(K), cnt = kind_count(K);
+        if constexpr (cnt == 0) {
+            return (KindBits)0;
+        } else {
+            u64 v = 0;
+            kmc_static_for<lo / 32, (lo + cnt + 31) / 32>([&](auto H) {
+                constexpr int h = decltype(H)::value;
+                if constexpr (32 * h >= lo) v |= (u64)en32[h] << (32 * h - lo);
+                else v |= (u64)(en32[h] >> (lo - 32 * h));
+            });
+            constexpr u64 mask = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+            return (KindBits)(v & mask);
+        }
+    }
+
+    // the word of replica r (run-time r): a select chain over registers, never an indexed array (that would be scratch)
+    // (Each step is an opaque v_cndmask per 32-bit half: the plain chain `r == k ? w[k] : v` was recognised as w[r], the
+    // state words went to scratch memory and every leaf loaded them back with a per-lane address — 255 M more vector
+    // memory instructions per run and the headline at 41.9 ms instead of 35, profiles/r03_kind_major.txt.  Halves, so that
+    // a leaf which only reads a replica's small fields does not select its log.)
+    static KMC_DEV u64 rep_word(const u64* w, u32 r) {
+        u32 lo = (u32)w[0], hi = (u32)(w[0] >> 32);
+        kmc_static_for<1, N>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            const bool c = r == (u32)k;
+            lo = c ? (u32)w[k] : lo;
+            hi = c ? (u32)(w[k] >> 32) : hi;
+            KMC_OPAQUE_PURE(lo);
+            KMC_OPAQUE_PURE(hi);
+        });
+        return ((u64)hi << 32) | lo;
+    }
+    static KMC_DEV void put_rep_word(u64* t, u32 r, u64 v) {
+        kmc_static_for<0, N>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            const bool c = r == (u32)k;
+            u32 lo = c ? (u32)v : (u32)t[k], hi = c ? (u32)(v >> 32) : (u32)(t[k] >> 32);
+            KMC_OPAQUE_PURE(lo);
+            KMC_OPAQUE_PURE(hi);
+            t[k] = ((u64)hi << 32) | lo;
+        });
+    }
+    // a replica's fields inside its word (compile-time offsets, the same for every replica)
+    static KMC_DEV u32 w_fld(u64 w, int off, int bits) { return (u32)(w >> off) & ((1u << bits) - 1u); }
+    static KMC_DEV u64 w_set(u64 w, int off, int bits, u32 val) {
+        const u64 m = ((1ull << bits) - 1ull) << off;
+        return (w & ~m) | (((u64)val << off) & m);
+    }
+    static KMC_DEV u32 w_end(u64 w) { return w_fld(w, Y.f_end, Y.BO); }
+    static KMC_DEV u32 w_hw(u64 w) { return w_fld(w, Y.f_hw, Y.BO); }
+    static KMC_DEV u32 w_ep1(u64 w) { return w_fld(w, Y.f_ep, Y.BE); }
+    static KMC_DEV u32 w_isr(u64 w) { return w_fld(w, Y.f_isr, Y.BI); }
+    static constexpr u64 LOGMASK = (Y.BR * L >= 64) ? ~0ull : ((1ull << (Y.BR * L)) - 1ull);
+    static KMC_DEV LogT w_log(u64 w) { return (LogT)(w & LOGMASK); }   // f_log = 0
+    static KMC_DEV u64 w_setlog(u64 w, LogT lv) { return (w & ~LOGMASK) | ((u64)lv & LOGMASK); }
+    // the isr of the request with leader epoch e (run-time e)
+    static KMC_DEV u32 risr_rt(const Pre& p, u32 e) {
+        u32 v = p.risr(0);
+        kmc_static_for<1, E + 1>([&](auto EE) {
+            constexpr int k = decltype(EE)::value;
+            v = e == (u32)k ? p.risr(k) : v;
+        });
+        return v;
+    }
+    // (l, r) of the q-th ordered pair of distinct replicas: the enumeration inst<I> uses for its (leader, other) bindings
+    static KMC_DEV void pair_of(u32 j, u32& l, u32& r) {
+        l = j / (u32)(N - 1);
+        const u32 q = j % (u32)(N - 1);
+        r = q + (q >= l ? 1u : 0u);
+    }
+
+    // The effect of binding b of kind K on s -> t.  The successor and `extra` equal inst<kind_base(K) + b>'s.
+    template <int K> static KMC_DEV void apply(const Pre& p, const u64* s, u64* t, u32 b, u32& extra) {
+        extra = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) t[k] = s[k];
+        // (a replica's word is rebuilt from the PARENT's and put into t before any global field of t is written: the
+        // global fields live in the spare bits of the same words)
+        if constexpr (K == 0) {
+            // ControllerElectLeader (KafkaReplication.tla:176-179)
+            controller_update(t, p, b + 1u, p.qisr());
+        } else if constexpr (K == 1) {
+            // ControllerShrinkIsr (:158-168)
+            const u32 r = b;
+            const bool is_ldr = p.qldr1() == r + 1u;
+            const bool only = p.qisr() == (1u << r);
+            const u32 newLdr1 = is_ldr ? 0u : p.qldr1();
+            const u32 newIsr = (is_ldr && only) ? p.qisr() : (p.qisr() & ~(1u << r));
+            controller_update(t, p, newLdr1, newIsr);
+        } else if constexpr (K == 2) {
+            // BecomeLeader (:186-195): request e names leader l
+            const u32 e = b / (u32)N, l = b % (u32)N;
+            u64 w = rep_word(s, l);
+            w = w_set(w, Y.f_ep, Y.BE, e + 1u);
+            w = w_set(w, Y.f_ldr, Y.BL, l + 1u);
+            w = w_set(w, Y.f_isr, Y.BI, risr_rt(p, e));
+            put_rep_word(t, l, w);
+        } else if constexpr (K == 3) {
+            // Leader*ExpandIsr* (:248-254, Kip320.tla:110-117, Kip320FirstTry.tla:134-141): QuorumUpdateLeaderAndIsr
+            const u32 l = b / (u32)N, r = b % (u32)N;
+            u64 w = rep_word(s, l);
+            const u32 nisr = w_isr(w) | (1u << r);
+            put_rep_word(t, l, w_set(w, Y.f_isr, Y.BI, nisr));
+            kmc_setbits(t, Y.qisr_off, Y.BI, nisr);
+        } else if constexpr (K == 4) {
+            // Leader*ShrinkIsr* (:233-239, Kip320.tla:78-85, Kip320FirstTry.tla:114-120)
+            u32 l, r;
+            pair_of(b, l, r);
+            const u64 w = rep_word(s, l);
+            const u32 nisr = w_isr(w) & ~(1u << r);
+            put_rep_word(t, l, w_set(w, Y.f_isr, Y.BI, nisr));
+            kmc_setbits(t, Y.qisr_off, Y.BI, nisr);
+            if constexpr (K320) {  // both disjuncts of Kip320.tla:82-83
+                const u32 following = (u32)(p.fm >> (l * (u32)N + r)) & 1u;
+                extra = (following == 0u && w_end(rep_word(s, r)) < w_end(w)) ? 1u : 0u;
+            }
+        } else if constexpr (K == 5) {
+            // LeaderWrite (:202-207)
+            const u32 r = b;
+            u64 w = rep_word(s, r);
+            const u32 end = w_end(w);
+            const LogT rec = (LogT)(((p.nextRec() + 1u) << Y.BEr) | (w_ep1(w) - 1u));
+            w = w_setlog(w, (LogT)(w_log(w) | (LogT)(rec << (end * Y.BR))));
+            w = w_set(w, Y.f_end, Y.BO, end + 1u);
+            put_rep_word(t, r, w);
+            kmc_setbits(t, Y.nextrec_off, Y.BNR, p.nextRec() + 1u);
+        } else if constexpr (K == 6) {
+            // *LeaderIncHighWatermark (:264-271, Kip320.tla:63-70, Kip320FirstTry.tla:90-97)
+            const u32 l = b;
+            const u64 w = rep_word(s, l);
+            put_rep_word(t, l, w_set(w, Y.f_hw, Y.BO, w_hw(w) + 1u));
+        } else if constexpr (K == 7) {
+            // BecomeFollower* of leader l at request epoch e (:281-294 and the five truncation rules)
+            const u32 pr = b / (u32)(E + 1), e = b % (u32)(E + 1);
+            u32 l, r;
+            pair_of(pr, l, r);
+            u64 w = rep_word(s, r);
+            const u32 end_r = w_end(w), hw_r = w_hw(w);
+            const LogT log_r = w_log(w);
+            w = w_set(w, Y.f_ep, Y.BE, e + 1u);
+            w = w_set(w, Y.f_ldr, Y.BL, l + 1u);
+            w = w_set(w, Y.f_isr, Y.BI, risr_rt(p, e));
+            if constexpr (!FIRST) {
+                u32 off;
+                if constexpr (MODEL == KMC_MODEL_TRUNCATE_TO_HW) {
+                    off = hw_r;  // KafkaTruncateToHighWatermark.tla:29-31
+                } else {
+                    const u64 wl = rep_word(s, l);
+                    if constexpr (MODEL == KMC_MODEL_KIP101) {  // Kip101.tla:41-47
+                        const u32 last_epoch = rec_epoch(rec_at(log_r, end_r == 0 ? 0u : end_r - 1u));
+                        off = end_r == 0 ? 0u : lookup_offset_for_epoch_v(w_log(wl), w_end(wl), hw_r, last_epoch);
+                    } else {  // Kip279.tla:47-51 / Kip320.tla:134-148
+                        off = first_non_matching_v(w_log(wl), log_r, w_end(wl), end_r);
+                        if constexpr (MODEL == KMC_MODEL_KIP279) extra = end_r == 0 ? 1u : 0u;
+                    }
+                }
+                w = w_setlog(w, (LogT)(log_r & keep_below(off)));   // TruncateTo (FiniteReplicatedLog.tla:105-109)
+                w = w_set(w, Y.f_end, Y.BO, off);
+                w = w_set(w, Y.f_hw, Y.BO, kmc_min(off, hw_r));
+            }
+            put_rep_word(t, r, w);
+        } else if constexpr (K == 8) {
+            // FollowerReplicate / *Fetch (:302-310, Kip320.tla:49-56, Kip320FirstTry.tla:103-111)
+            u32 l, f;
+            pair_of(b, l, f);
+            const u64 wl = rep_word(s, l);
+            u64 w = rep_word(s, f);
+            const u32 ef = w_end(w);
+            const LogT rec = (LogT)rec_at(w_log(wl), ef);
+            w = w_setlog(w, (LogT)(w_log(w) | (LogT)(rec << (ef * Y.BR))));
+            w = w_set(w, Y.f_end, Y.BO, ef + 1u);
+            w = w_set(w, Y.f_hw, Y.BO, kmc_min(w_hw(wl), ef + 1u));
+            put_rep_word(t, f, w);
+        } else {
+            // FollowerTruncate (Kip320FirstTry.tla:75-82)
+            u32 l, f;
+            pair_of(b, l, f);
+            const u64 wl = rep_word(s, l);
+            u64 w = rep_word(s, f);
+            const u32 off = first_non_matching_v(w_log(wl), w_log(w), w_end(wl), w_end(w));
+            const u32 hw_f = w_hw(w);
+            w = w_setlog(w, (LogT)(w_log(w) & keep_below(off)));
+            w = w_set(w, Y.f_end, Y.BO, off);
+            w = w_set(w, Y.f_hw, Y.BO, kmc_min(off, hw_f));
+            put_rep_word(t, f, w);
         }
     }
 
@@ -1555,6 +1772,57 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         // memory system under the flushes' random probes).  Measured and dropped here: a fall-through
         // `switch`, walking only the set bits of the wave-wide OR of en32 (s_ff1), per-kind
         // `generated` counters in scalars (the array lands in scratch) or bumped with v_writelane.
+        if constexpr (M::KIND_MAJOR) {
+        // Kind-major walk (replica-major layouts, KmcKafka::apply<K>): for every action kind, every lane applies ITS OWN
+        // next enabled binding of that kind in the same leaf — replicas and request epoch are run-time values, a field
+        // of replica r is "select word r, extract at a compile-time offset" — until no lane has one left.  A tile costs
+        // sum over kinds of max-over-lanes(enabled bindings) leaves: 12.6 at the headline where the instance-major walk
+        // below dispatches 30 (one per (kind, binding) ANY lane enabled), each with twice the lanes busy.
+#pragma clang loop unroll(disable)
+        for (int k = 0; k < M::NKINDS; ++k) {
+            typename M::KindBits km = 0;
+            kmc_dispatch<0, M::NKINDS>(k, [&](auto KK) { km = M::template kind_bits<decltype(KK)::value>(en32); });
+#pragma clang loop unroll(disable)
+            for (;;) {
+                const bool e = km != 0;
+                const u64 m = __ballot(e);
+                if (m == 0) break;
+#if KMC_PROFILE
+                prof_acc[5] += 1;  // effect leaves dispatched (per wave; prof[6] counts tiles)
+#endif
+                u32 b;
+                if constexpr (sizeof(km) == 8) b = (u32)__builtin_ctzll(km | (1ull << 63));
+                else b = (u32)__builtin_ctz(km | (1u << 31));
+                km &= km - 1;
+                // (opaque redefinition of the state words: the parts of an effect that do not depend on the binding stay
+                // inside the loop.  The guards' shared sub-predicates in `pre` are not touched: they die with pass 1.)
+#pragma unroll
+                for (int q2 = 0; q2 < W; ++q2) kmc_launder(s[q2]);
+                u32 extra = 0;
+                u64 t[W];
+                kmc_dispatch<0, M::NKINDS>(k, [&](auto KK) {
+                    M::template apply<decltype(KK)::value>(pre, s, t, b, extra);
+                });
+                const u32 n = __popcll(m);
+                if constexpr (M::HAS_EXTRA) extra_lane += e ? extra : 0u;
+                gen_lane += (lane == (u32)k) ? n : 0u;
+                if (e) {
+                    const u32 pos = (head + count + kmc_rank_in(m)) & (KMC_RING - 1);
+#pragma unroll
+                    for (int q2 = 0; q2 < W; ++q2) q[q2 * KMC_RING + pos] = t[q2];
+                    if (has_meta)
+                        q[W * KMC_RING + pos] = (a.mode == KMC_MODE_ENUM && !(a.flags & KMC_FLAG_ENUM_MATCH)) ? (u64)k : parent;
+                }
+                count += n;
+                if (count >= KMC_FLUSH_N) {
+                    KMC_T(tf0);
+                    flush(KMC_FLUSH_N);
+                    KMC_T(tf1);
+                    KMC_TADD(3, tf0, tf1);
+                }
+            }
+        }
+        } else {
         u32 cur = 0;
 #pragma clang loop unroll(disable)
         for (int i = 0; i < M::NINST; ++i) {
@@ -1621,6 +1889,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
                 KMC_TADD(3, tf0, tf1);
             }
         }
+        }   // instance-major walk
         KMC_T(tp3);
         KMC_TADD(2, tp2, tp3);
         const u64 dm = __ballot(valid && nsucc == 0);

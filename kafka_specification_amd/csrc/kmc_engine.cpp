@@ -123,16 +123,23 @@ bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::strin
     case KMC_KIP101:
     case KMC_KIP279:
     case KMC_KIP320:
-    case KMC_KIP320_FIRST_TRY:
-        *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, c.max_records, c.max_leader_epoch, 0);
+    case KMC_KIP320_FIRST_TRY: {
+        // KMC_LAYOUT=tight|rm (tests, A/B measurements) overrides the automatic choice between the two arrangements of
+        // the state vector (kmc_layout.h); host and device evaluate the same constexpr function with the same mode
+        const char* lenv = getenv("KMC_LAYOUT");
+        const int lm = !lenv || !*lenv || !strcmp(lenv, "auto") ? KMC_LAYOUT_AUTO
+                       : !strcmp(lenv, "tight") ? KMC_LAYOUT_TIGHT : !strcmp(lenv, "rm") ? KMC_LAYOUT_RM : -1;
+        if (lm < 0) return false;
+        *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, c.max_records, c.max_leader_epoch, 0, lm);
         if (!lay->valid || c.n_replicas < 2) return false;
-        snprintf(buf, sizeof buf, "%s_N%d_L%d_R%d_E%d", MODEL_NAMES[c.model], c.n_replicas, c.log_size,
-                 c.max_records, c.max_leader_epoch);
+        snprintf(buf, sizeof buf, "%s_N%d_L%d_R%d_E%d%s", MODEL_NAMES[c.model], c.n_replicas, c.log_size,
+                 c.max_records, c.max_leader_epoch, lm == KMC_LAYOUT_TIGHT ? "_tight" : lm == KMC_LAYOUT_RM ? "_rm" : "");
         *name = buf;
-        snprintf(buf, sizeof buf, "KmcKafka<%d,%d,%d,%d,%d>", c.model, c.n_replicas, c.log_size, c.max_records,
-                 c.max_leader_epoch);
+        snprintf(buf, sizeof buf, "KmcKafka<%d,%d,%d,%d,%d,%d>", c.model, c.n_replicas, c.log_size, c.max_records,
+                 c.max_leader_epoch, lm);
         *inst = buf;
         return true;
+    }
     default: return false;
     }
 }
@@ -288,7 +295,9 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
             return fail(KMC_E_COMPILE, "kmc_expand_%s spills %ld vector registers even at one wave per SIMD: constants too "
                                        "wide for this kernel shape", name.c_str(), spills);
         // (these kernels take up to minutes to compile: jump by the size of the overflow, do not crawl)
-        const int next = spills > 64 ? 2 : spills > 24 ? 3 : 4;
+        // (a near miss at 6 waves gets 5 — 96 registers: the kind-major headline kernel spills 9 at 80 and 2 at 96 and runs
+        // equally fast at either, profiles/r03_kind_major.txt)
+        const int next = spills > 64 ? 2 : spills > 24 ? 3 : spills > 16 ? 4 : 5;
         waves = next < waves ? next : waves - 1;
     }
     // best-effort cache write (atomic rename)

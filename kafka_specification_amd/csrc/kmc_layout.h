@@ -4,8 +4,9 @@
 // constexpr function evaluated at compile time for one specialised (model,N,L,R,E)), so the
 // two can never disagree.  Self-contained: no includes (it is also fed to hiprtc).
 //
-// Kafka-family state vector (`vars`, KafkaReplication.tla:75), tight sequential packing,
-// least-significant bit first, fields may straddle 64-bit words:
+// Kafka-family state vector (`vars`, KafkaReplication.tla:75).  Two arrangements of the same fields (KMC_LAYOUT_*):
+//
+// TIGHT — sequential packing, least-significant bit first, fields may straddle 64-bit words:
 //   for r in Replicas:  log[r]     L records x BR bits      replicaLog[r].records (FiniteReplicatedLog.tla:42)
 //                                  record = 0 (Nil) | ((id+1) << BEr | epoch)    LogRecords, KafkaReplication.tla:82
 //   for r in Replicas:  end[r] BO  replicaLog[r].endOffset   (FiniteReplicatedLog.tla:41)
@@ -19,6 +20,15 @@
 // only writer and always adds the record whose leaderEpoch equals the old nextLeaderEpoch, so
 // the set is in bijection with this epoch-indexed array.  Unwritten log slots are 0
 // (FiniteReplicatedLog.tla:93,108), so equal states have equal bits.
+//
+// REPLICA-MAJOR (rm = 1) — word r holds everything of replica r at the SAME in-word offsets for every r: the log from
+// bit 0 (alone in the low 32-bit half when it fits there), then end, hw, ep, ldr, isr (from bit 32 when both halves fit);
+// the global fields (nextRecordId ... the requests) go first-fit into the bits the replica words leave free — never
+// straddling a word — and into extra words behind them when those run out.  A field of a replica chosen at RUN TIME is then
+// "select word r, extract at a compile-time offset": what k_expand's kind-major pass 2 needs (kmc_device.h), and no field
+// of any replica straddles a word (or, at the headline's constants, a 32-bit register).  Chosen automatically when a
+// replica's fields fit one word AND the state is no wider than under TIGHT (3 brokers with LogSize 5-6: W = 3 either
+// way); small or many-replica configurations stay TIGHT.  KMC_LAYOUT=tight|rm (host) overrides, for tests.
 //
 // FiniteReplicatedLog standalone: for r: log[r] (L x BK bits, record = 0 Nil | 1..K), then
 // for r: end[r] (BO).   IdSequence standalone: one 64-bit word = nextId.
@@ -63,8 +73,14 @@ KMC_HD constexpr int kmc_bits_for(long long nvalues) {
     return b;
 }
 
+#define KMC_LAYOUT_AUTO 0   // replica-major when it fits and costs no extra word, else tight
+#define KMC_LAYOUT_TIGHT 1
+#define KMC_LAYOUT_RM 2     // replica-major or invalid
+
 struct KmcLayout {
     int model, N, L, R, E, K;
+    int rm;                                           // 1: replica-major (Kafka family only)
+    int f_log, f_end, f_hw, f_ep, f_ldr, f_isr;      // rm: in-word offsets of a replica's fields (word r = replica r)
     int BO, BR, BEr, BId, BE, BL, BI, BNR;  // field widths
     int log_off[KMC_MAXN], end_off[KMC_MAXN], hw_off[KMC_MAXN], ep_off[KMC_MAXN], ldr_off[KMC_MAXN],
         isr_off[KMC_MAXN];
@@ -77,10 +93,10 @@ struct KmcLayout {
     int valid;  // 0 when the parameters cannot be packed (see kmc_make_layout)
 };
 
-KMC_HD constexpr KmcLayout kmc_make_layout(int model, int N, int L, int R, int E, int K) {
+KMC_HD constexpr KmcLayout kmc_make_layout(int model, int N, int L, int R, int E, int K, int lm = KMC_LAYOUT_AUTO) {
     KmcLayout y{};
     y.model = model; y.N = N; y.L = L; y.R = R; y.E = E; y.K = K;
-    y.valid = 0;
+    y.valid = 0; y.rm = 0;
     if (model == KMC_MODEL_IDSEQUENCE) {
         y.bits = 64; y.W = 1; y.valid = 1;
         return y;
@@ -143,7 +159,54 @@ KMC_HD constexpr KmcLayout kmc_make_layout(int model, int N, int L, int R, int E
     }
     y.bits = pos; y.W = (pos + 63) / 64;
     y.valid = y.W >= 1 && y.W <= KMC_MAXW;
-    return y;
+    if (lm == KMC_LAYOUT_TIGHT) return y;
+    // ---- replica-major arrangement of the same fields ----
+    const int logbits = y.BR * L, small = 2 * y.BO + y.BE + y.BL + y.BI;
+    if (logbits + small > 64) {          // a replica does not fit one word
+        if (lm == KMC_LAYOUT_RM) y.valid = 0;
+        return y;
+    }
+    KmcLayout z = y;
+    z.rm = 1;
+    const int small0 = (logbits <= 32 && small <= 32) ? 32 : logbits;
+    z.f_log = 0; z.f_end = small0; z.f_hw = z.f_end + y.BO; z.f_ep = z.f_hw + y.BO; z.f_ldr = z.f_ep + y.BE;
+    z.f_isr = z.f_ldr + y.BL;
+    const int small_end = z.f_isr + y.BI;
+    for (int r = 0; r < N; ++r) {
+        z.log_off[r] = 64 * r + z.f_log; z.end_off[r] = 64 * r + z.f_end; z.hw_off[r] = 64 * r + z.f_hw;
+        z.ep_off[r] = 64 * r + z.f_ep; z.ldr_off[r] = 64 * r + z.f_ldr; z.isr_off[r] = 64 * r + z.f_isr;
+    }
+    // free regions, first the tails of the replica words, then the gaps between a short log and bit 32, then extra words
+    int reg_off[2 * KMC_MAXN + KMC_MAXW] = {}, reg_len[2 * KMC_MAXN + KMC_MAXW] = {};
+    int nreg = 0, words = N;
+    for (int r = 0; r < N; ++r) { reg_off[nreg] = 64 * r + small_end; reg_len[nreg] = 64 - small_end; ++nreg; }
+    if (small0 == 32)
+        for (int r = 0; r < N; ++r) { reg_off[nreg] = 64 * r + logbits; reg_len[nreg] = 32 - logbits; ++nreg; }
+    const int nglob = 5 + 2 * (E + 1);
+    for (int g = 0; g < nglob; ++g) {
+        const int e = (g - 5) / 2;
+        const int bits = g == 0 ? y.BNR : g == 1 ? y.BE : g == 2 ? y.BE : g == 3 ? y.BL : g == 4 ? y.BI
+                         : ((g - 5) % 2 == 0 ? y.BL : y.BI);
+        int at = -1;
+        for (int k = 0; k < nreg && at < 0; ++k)
+            if (reg_len[k] >= bits) { at = reg_off[k]; reg_off[k] += bits; reg_len[k] -= bits; }
+        if (at < 0) {
+            if (words >= KMC_MAXW) { if (lm == KMC_LAYOUT_RM) y.valid = 0; return y; }
+            reg_off[nreg] = 64 * words + bits; reg_len[nreg] = 64 - bits; ++nreg;
+            at = 64 * words; ++words;
+        }
+        if (g == 0) z.nextrec_off = at;
+        else if (g == 1) z.nextep_off = at;
+        else if (g == 2) z.qep_off = at;
+        else if (g == 3) z.qldr_off = at;
+        else if (g == 4) z.qisr_off = at;
+        else if ((g - 5) % 2 == 0) z.reqldr_off[e] = at;
+        else z.reqisr_off[e] = at;
+    }
+    z.W = words;
+    z.valid = z.W >= 1 && z.W <= KMC_MAXW;
+    if (lm == KMC_LAYOUT_AUTO && (z.W > y.W || !z.valid)) return y;
+    return z;
 }
 
 // Generic bit-field access on a packed state.  With compile-time `off`/`bits` (the device

@@ -30,7 +30,38 @@ template <class M> int successors(const u64* s, u64* out, int cap) {
     return n;
 }
 
+// Kind-major effects (KmcKafka::apply<K>, replica-major layouts) against the instance-major ones (inst<I>) on every
+// enabled binding of one state: same successor words, same `extra`, same kind.  -> checked / bad counts; false when the
+// model has no kind-major form.
+template <class M> bool kind_major_check(const u64* s, int* checked, int* bad) {
+    *checked = *bad = 0;
+    if constexpr (!M::KIND_MAJOR) {
+        return false;
+    } else {
+        typename M::Pre pre = M::extract(s);
+        kmc_static_for<0, M::NINST>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            u64 t1[M::W];
+            int kind = 0;
+            u32 extra1 = 0;
+            if (!M::template inst<i>(pre, s, t1, kind, extra1)) return;
+            kmc_static_for<0, M::NKINDS>([&](auto KK) {
+                constexpr int k = decltype(KK)::value;
+                if constexpr (i >= M::kind_base(k) && i < M::kind_base(k + 1)) {
+                    u64 t2[M::W];
+                    u32 extra2 = 77;
+                    M::template apply<k>(pre, s, t2, (u32)(i - M::kind_base(k)), extra2);
+                    ++*checked;
+                    if (memcmp(t1, t2, sizeof t1) != 0 || extra1 != extra2 || kind != k) ++*bad;
+                }
+            });
+        });
+        return true;
+    }
+}
+
 template <class M> struct Ops {
+    static int kmcheck(const u64* s, int* checked, int* bad) { return kind_major_check<M>(s, checked, bad) ? 1 : 0; }
     static int succ(const u64* s, u64* out, int cap) { return successors<M>(s, out, cap); }
     static u32 violated(const u64* s, u32 mask) { return M::violated(s, mask); }
     static void init(u64* w) { M::init(w); }
@@ -42,24 +73,29 @@ template <class M> struct Ops {
 };
 
 struct Entry {
-    int model, N, L, R, E, K;
+    int model, N, L, R, E, K, lm;   // lm: KMC_LAYOUT_* the Kafka instantiation was compiled with (0 = automatic)
     int (*succ)(const u64*, u64*, int);
     u32 (*violated)(const u64*, u32);
     void (*init)(u64*);
     int (*in_model)(const u64*);
     int (*words)();
+    int (*kmcheck)(const u64*, int*, int*);
 };
 
-#define KAFKA(MODEL, N, L, R, E) \
-    {MODEL, N, L, R, E, 0, Ops<KmcKafka<MODEL, N, L, R, E>>::succ, Ops<KmcKafka<MODEL, N, L, R, E>>::violated, \
-     Ops<KmcKafka<MODEL, N, L, R, E>>::init, Ops<KmcKafka<MODEL, N, L, R, E>>::in_model, Ops<KmcKafka<MODEL, N, L, R, E>>::words}
+#define KAFKA_LM(MODEL, N, L, R, E, LM) \
+    {MODEL, N, L, R, E, 0, LM, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::succ, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::violated, \
+     Ops<KmcKafka<MODEL, N, L, R, E, LM>>::init, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::in_model, \
+     Ops<KmcKafka<MODEL, N, L, R, E, LM>>::words, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::kmcheck}
+#define KAFKA(MODEL, N, L, R, E) KAFKA_LM(MODEL, N, L, R, E, KMC_LAYOUT_AUTO)
 #define ASYNC(N, MO, V) \
-    {KMC_MODEL_ASYNC_ISR, N, MO, 0, V, 0, Ops<KmcAsyncIsr<N, MO, V>>::succ, Ops<KmcAsyncIsr<N, MO, V>>::violated, \
-     Ops<KmcAsyncIsr<N, MO, V>>::init, Ops<KmcAsyncIsr<N, MO, V>>::in_model, Ops<KmcAsyncIsr<N, MO, V>>::words}
+    {KMC_MODEL_ASYNC_ISR, N, MO, 0, V, 0, 0, Ops<KmcAsyncIsr<N, MO, V>>::succ, Ops<KmcAsyncIsr<N, MO, V>>::violated, \
+     Ops<KmcAsyncIsr<N, MO, V>>::init, Ops<KmcAsyncIsr<N, MO, V>>::in_model, Ops<KmcAsyncIsr<N, MO, V>>::words, \
+     Ops<KmcAsyncIsr<N, MO, V>>::kmcheck}
 #define FRL(N, L, K) \
-    {KMC_MODEL_FINITE_REPLICATED_LOG, N, L, 0, 0, K, Ops<KmcFiniteReplicatedLog<N, L, K>>::succ, \
+    {KMC_MODEL_FINITE_REPLICATED_LOG, N, L, 0, 0, K, 0, Ops<KmcFiniteReplicatedLog<N, L, K>>::succ, \
      Ops<KmcFiniteReplicatedLog<N, L, K>>::violated, Ops<KmcFiniteReplicatedLog<N, L, K>>::init, \
-     Ops<KmcFiniteReplicatedLog<N, L, K>>::in_model, Ops<KmcFiniteReplicatedLog<N, L, K>>::words}
+     Ops<KmcFiniteReplicatedLog<N, L, K>>::in_model, Ops<KmcFiniteReplicatedLog<N, L, K>>::words, \
+     Ops<KmcFiniteReplicatedLog<N, L, K>>::kmcheck}
 
 const Entry TABLE[] = {
     KAFKA(KMC_MODEL_TRUNCATE_TO_HW, 3, 2, 2, 2), KAFKA(KMC_MODEL_KIP101, 3, 2, 2, 2), KAFKA(KMC_MODEL_KIP279, 3, 2, 2, 2),
@@ -76,6 +112,15 @@ const Entry TABLE[] = {
     KAFKA(KMC_MODEL_TRUNCATE_TO_HW, 3, 6, 6, 2), KAFKA(KMC_MODEL_TRUNCATE_TO_HW, 3, 5, 5, 2), KAFKA(KMC_MODEL_KIP101, 3, 5, 5, 2),
     KAFKA(KMC_MODEL_KIP279, 3, 5, 5, 2), KAFKA(KMC_MODEL_KIP320_FIRST_TRY, 3, 5, 5, 2),
     KAFKA(KMC_MODEL_KIP101, 3, 6, 6, 2), KAFKA(KMC_MODEL_KIP279, 3, 6, 6, 2), KAFKA(KMC_MODEL_KIP320_FIRST_TRY, 3, 6, 6, 2),
+    // the two arrangements of the state vector (kmc_layout.h): the automatic choice is replica-major at the 3-broker
+    // LogSize 5-6 constants above and tight at the small ones; here each is forced the other way
+    KAFKA_LM(KMC_MODEL_KIP320, 3, 6, 6, 2, KMC_LAYOUT_TIGHT), KAFKA_LM(KMC_MODEL_KIP279, 3, 5, 5, 2, KMC_LAYOUT_TIGHT),
+    KAFKA_LM(KMC_MODEL_TRUNCATE_TO_HW, 3, 2, 2, 2, KMC_LAYOUT_RM), KAFKA_LM(KMC_MODEL_KIP101, 3, 2, 2, 2, KMC_LAYOUT_RM),
+    KAFKA_LM(KMC_MODEL_KIP279, 3, 2, 2, 2, KMC_LAYOUT_RM), KAFKA_LM(KMC_MODEL_KIP320, 3, 2, 2, 2, KMC_LAYOUT_RM),
+    KAFKA_LM(KMC_MODEL_KIP320_FIRST_TRY, 3, 2, 2, 2, KMC_LAYOUT_RM), KAFKA_LM(KMC_MODEL_KIP101, 3, 3, 2, 2, KMC_LAYOUT_RM),
+    KAFKA_LM(KMC_MODEL_KIP320, 4, 2, 2, 1, KMC_LAYOUT_RM), KAFKA_LM(KMC_MODEL_KIP279, 5, 1, 1, 1, KMC_LAYOUT_RM),
+    KAFKA_LM(KMC_MODEL_KIP101, 4, 2, 1, 2, KMC_LAYOUT_RM), KAFKA_LM(KMC_MODEL_KIP320, 7, 1, 1, 0, KMC_LAYOUT_RM),
+    KAFKA_LM(KMC_MODEL_KIP320_FIRST_TRY, 8, 1, 1, 0, KMC_LAYOUT_RM), KAFKA_LM(KMC_MODEL_KIP320, 2, 3, 2, 3, KMC_LAYOUT_RM),
     ASYNC(3, 2, 2), ASYNC(4, 2, 2), ASYNC(2, 3, 7), ASYNC(1, 4, 0),
     FRL(2, 4, 2), FRL(3, 2, 2),
 };
@@ -86,8 +131,8 @@ const Entry TABLE[] = {
 // fails on a reachable state, so reachable states alone cannot tell a TypeOk that is always true from a right one).
 // Returns -1 for WeakIsr / StrongIsr when an endOffset or hw lies beyond LogSize (offsets past the log are not
 // representable, the comparison is undefined there).
-int kafka_reference(int model, int N, int L, int R, int E, const u64* w, unsigned mask) {
-    const KmcLayout y = kmc_make_layout(model, N, L, R, E, 0);
+int kafka_reference(int model, int N, int L, int R, int E, int lm, const u64* w, unsigned mask) {
+    const KmcLayout y = kmc_make_layout(model, N, L, R, E, 0, lm);
     auto rec = [&](int r, int o) { return (unsigned)kmc_getbits(w, y.log_off[r] + o * y.BR, y.BR); };
     auto end = [&](int r) { return (unsigned)kmc_getbits(w, y.end_off[r], y.BO); };
     auto hw = [&](int r) { return (unsigned)kmc_getbits(w, y.hw_off[r], y.BO); };
@@ -135,24 +180,29 @@ int kafka_reference(int model, int N, int L, int R, int E, const u64* w, unsigne
     return (int)bad;
 }
 
+int g_lm = 0;   // the layout mode the following calls refer to (emu_layout)
 const Entry* find(int model, int N, int L, int R, int E, int K) {
     for (const Entry& e : TABLE)
-        if (e.model == model && e.N == N && e.L == L && e.R == R && e.E == E && e.K == K) return &e;
+        if (e.model == model && e.N == N && e.L == L && e.R == R && e.E == E && e.K == K && e.lm == g_lm) return &e;
     return nullptr;
 }
 
 }  // namespace
 
 extern "C" {
-// number of configurations compiled in; fills (model, N, L, R, E, K) of entry i
-int emu_configs(int i, int* out6) {
+// number of configurations compiled in; fills (model, N, L, R, E, K, layout mode) of entry i
+int emu_configs(int i, int* out7) {
     const int n = (int)(sizeof TABLE / sizeof TABLE[0]);
     if (i >= 0 && i < n) {
         const Entry& e = TABLE[i];
-        out6[0] = e.model; out6[1] = e.N; out6[2] = e.L; out6[3] = e.R; out6[4] = e.E; out6[5] = e.K;
+        out7[0] = e.model; out7[1] = e.N; out7[2] = e.L; out7[3] = e.R; out7[4] = e.E; out7[5] = e.K; out7[6] = e.lm;
     }
     return n;
 }
+// selects which compiled arrangement (KMC_LAYOUT_*) of a Kafka configuration the calls below mean
+void emu_layout(int lm) { g_lm = lm; }
+// 1 when the configuration's state vector is replica-major under the selected mode
+int emu_is_rm(int model, int N, int L, int R, int E) { return kmc_make_layout(model, N, L, R, E, 0, g_lm).rm; }
 int emu_words(int model, int N, int L, int R, int E, int K) {
     const Entry* e = find(model, N, L, R, E, K);
     return e ? e->words() : -1;
@@ -168,14 +218,19 @@ int emu_violated(int model, int N, int L, int R, int E, int K, const u64* state,
 }
 // the literal reference above (Kafka family only)
 int emu_kafka_reference(int model, int N, int L, int R, int E, const u64* state, unsigned mask) {
-    return kafka_reference(model, N, L, R, E, state, mask);
+    return kafka_reference(model, N, L, R, E, g_lm, state, mask);
 }
-int emu_state_bits(int model, int N, int L, int R, int E, int K) { return kmc_make_layout(model, N, L, R, E, K).bits; }
+int emu_state_bits(int model, int N, int L, int R, int E, int K) { return kmc_make_layout(model, N, L, R, E, K, g_lm).bits; }
 int emu_init(int model, int N, int L, int R, int E, int K, u64* words) {
     const Entry* e = find(model, N, L, R, E, K);
     if (!e) return -1;
     e->init(words);
     return 0;
+}
+// 1: the state's enabled bindings were checked (counts in checked / bad), 0: the configuration has no kind-major form, -1: unknown
+int emu_kind_major_check(int model, int N, int L, int R, int E, int K, const u64* state, int* checked, int* bad) {
+    const Entry* e = find(model, N, L, R, E, K);
+    return e ? e->kmcheck(state, checked, bad) : -1;
 }
 int emu_in_model(int model, int N, int L, int R, int E, int K, const u64* state) {
     const Entry* e = find(model, N, L, R, E, K);

@@ -13,12 +13,23 @@ CONFIGS = host_emu.configs()
 
 
 def _ids(c):
-    return f"{MODEL_NAMES[c[0]]}-{c[1]}-{c[2]}-{c[3]}-{c[4]}-{c[5]}"
+    return f"{MODEL_NAMES[c[0]]}-{c[1]}-{c[2]}-{c[3]}-{c[4]}-{c[5]}" + ("", "-tight", "-rm")[c[6]]
+
+
+@pytest.fixture(autouse=True)
+def _layout_of_the_entry(request):
+    """Every test here runs with the emulation and the host library on the arrangement its entry was compiled with."""
+    cfg = request.node.callspec.params.get("cfg6") if hasattr(request.node, "callspec") else None
+    if cfg is None:
+        yield
+        return
+    with host_emu.layout(cfg):
+        yield
 
 
 @pytest.mark.parametrize("cfg6", CONFIGS, ids=_ids)
 def test_device_model_matches_oracle_state_by_state(cfg6):
-    model, N, L, R, E, K = cfg6
+    model, N, L, R, E, K = cfg6[:6]
     name = MODEL_NAMES[model]
     consts = dict(n_replicas=N, log_size=L, max_records=max(R, 1), max_leader_epoch=E, n_log_records=max(K, 1))
     ocfg = kmo.make_config(name, N=N, L=L, R=max(R, 1), E=E, K=max(K, 1), invariants=(), max_states=30000, threads=2)
@@ -26,7 +37,7 @@ def test_device_model_matches_oracle_state_by_state(cfg6):
     n = min(o.distinct, 30000)
     n_inv = 3 if name == "AsyncIsr" else 1 if name == "FiniteReplicatedLog" else 4
     with ModelChecker(CheckerConfig(model=name, device=-1, **consts)) as mc:   # host-only handle: pack / unpack
-        assert mc.state_words == host_emu.lib().emu_words(*cfg6)
+        assert mc.state_words == host_emu.lib().emu_words(*cfg6[:6])
         assert mc.unpack(host_emu.init(cfg6)) == o.state(0)
         step = max(1, n // 300)
         for idx in range(0, n, step):
@@ -52,7 +63,7 @@ def test_device_model_matches_oracle_along_random_walks(cfg6):
     """The breadth-first prefix above only reaches shallow states; random walks through the oracle's
     Next relation reach full logs, exhausted epochs / versions and long request histories."""
     import random
-    model, N, L, R, E, K = cfg6
+    model, N, L, R, E, K = cfg6[:6]
     name = MODEL_NAMES[model]
     ocfg = kmo.make_config(name, N=N, L=L, R=max(R, 1), E=E, K=max(K, 1), invariants=(), max_states=1, threads=1)
     o = kmo.Run(ocfg)
@@ -83,9 +94,10 @@ def test_invariants_on_arbitrary_bit_patterns(cfg6):
     Here the device's integer-domain invariants (whole-log folds, membership map) meet a literal loop-per-slot
     evaluation of the definitions on random packed words and on reachable states with a few flipped bits."""
     import random
-    model, N, L, R, E, K = cfg6
+    model, N, L, R, E, K = cfg6[:6]
     name = MODEL_NAMES[model]
-    W, bits = host_emu.lib().emu_words(*cfg6), host_emu.state_bits(cfg6)
+    W = host_emu.lib().emu_words(*cfg6[:6])
+    bits = 64 * W   # (the replica-major arrangement leaves gaps: patterns over all the words, whichever bits are fields)
     rng = random.Random(99 + model * 1000 + N * 100 + L * 10 + E)
     ocfg = kmo.make_config(name, N=N, L=L, R=max(R, 1), E=E, invariants=(), max_states=3000, threads=1)
     o = kmo.Run(ocfg)
@@ -118,3 +130,53 @@ def test_invariants_on_arbitrary_bit_patterns(cfg6):
             assert got == want, f"invariant mask {m} on words {[hex(v) for v in w]}: device {got}, reference {want}"
             (seen_bad if want else seen_ok)[m] += 1
     assert all(seen_bad[m] > 0 and seen_ok[m] > 0 for m in (1, 2, 4, 8)), (seen_bad, seen_ok)
+
+
+RM_CONFIGS = []
+for _c in CONFIGS:
+    if 2 <= _c[0] <= 6:
+        with host_emu.layout(_c):
+            if host_emu.lib().emu_is_rm(*_c[:5]):
+                RM_CONFIGS.append(_c)
+
+
+@pytest.mark.parametrize("cfg6", RM_CONFIGS, ids=_ids)
+def test_kind_major_effects_equal_the_instance_major_ones(cfg6):
+    """k_expand's pass 2 on replica-major layouts applies KmcKafka::apply<K>(binding chosen per lane at run time) where
+    the tight layouts run inst<I> (binding fixed at compile time).  On every enabled binding of every visited state — a
+    breadth-first prefix and random walks into full logs and exhausted epochs — the two must produce the same successor
+    words, the same `extra` (bindings TLC counts twice) and the same action kind.  inst<I> itself is held to the oracle
+    by the tests above, with the same entries."""
+    import random
+    model, N, L, R, E, K = cfg6[:6]
+    name = MODEL_NAMES[model]
+    ocfg = kmo.make_config(name, N=N, L=L, R=max(R, 1), E=E, invariants=(), max_states=20000, threads=2)
+    o = kmo.Run(ocfg)
+    n = min(o.distinct, 20000)
+    rng = random.Random(4242 + model * 1000 + N * 100 + L * 10 + E)
+    total = 0
+    with ModelChecker(CheckerConfig(model=name, device=-1, n_replicas=N, log_size=L, max_records=max(R, 1),
+                                    max_leader_epoch=E)) as mc:
+        def check(s):
+            has, checked, bad = host_emu.kind_major_check(cfg6, mc.pack(s))
+            assert has and bad == 0, f"{bad} of {checked} enabled bindings differ at state {s}"
+            return checked
+        for idx in range(0, n, max(1, n // 400)):
+            total += check(o.state(idx))
+        init, sb = o.state(0), o.sb
+        for _walk in range(10):
+            s = init
+            for _step in range(100):
+                total += check(s)
+                nxt = [t for (_a, t) in kmo.successors(ocfg, s, sb)]
+                if not nxt:
+                    break
+                s = rng.choice(nxt)
+    assert total > 500
+
+
+def test_the_headline_is_replica_major_and_small_configurations_stay_tight():
+    """The automatic choice (kmc_layout.h): replica-major where a replica's fields fill most of a word anyway."""
+    rm = {(_c[0], _c[1], _c[2], _c[3], _c[4]) for _c in RM_CONFIGS if _c[6] == 0}
+    assert (kmo.MODELS["Kip320"], 3, 6, 6, 2) in rm
+    assert (kmo.MODELS["Kip320"], 3, 2, 2, 2) not in rm and (kmo.MODELS["Kip320"], 7, 1, 1, 0) not in rm

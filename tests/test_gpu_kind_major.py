@@ -1,0 +1,105 @@
+"""The two walks of k_expand's pass 2 (csrc/kmc_device.h), each forced onto the configurations the other one gets by
+default: the KIND-MAJOR walk (replica-major layout, KmcKafka::apply<K> with the binding chosen per lane at run time; the
+automatic choice at the headline's constants) on the small configurations whose every level the oracle holds as an exact
+set, and the INSTANCE-MAJOR walk (tight layout, inst<I>) on two of the large golden counts.  KMC_LAYOUT=rm / tight, read
+when a handle is opened."""
+import json
+import os
+
+import pytest
+
+import kmo
+from kafka_specification_amd import CheckerConfig, ModelChecker
+from kafka_specification_amd.sharded import check_loopback
+from kafka_specification_amd.configs import INSTANCE_MAJOR_LARGE, KAFKA, KIND_MAJOR_SMALL
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture
+def layout(monkeypatch):
+    def set_layout(mode):
+        monkeypatch.setenv("KMC_LAYOUT", mode)
+    return set_layout
+
+
+def run(model, N, L, R, E, invariants=("TypeOk",), keep_levels=False, **kw):
+    cfg = CheckerConfig(model=model, invariants=invariants, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E,
+                        table_capacity=kw.pop("table_capacity", 1 << 22), frontier_capacity=kw.pop("frontier_capacity", 1 << 20), **kw)
+    level_sets = []
+    with ModelChecker(cfg) as mc:
+        if keep_levels:
+            res = mc.run(progress=lambda info: level_sets.append({mc.unpack(row) for row in mc.frontier_states()}))
+        else:
+            res = mc.run()
+        trace = mc.trace() if kw.get("keep_trace") and res.verdict == "invariant" else None
+    return res, level_sets, trace
+
+
+@pytest.mark.parametrize("model,N,L,R,E", KIND_MAJOR_SMALL)
+def test_kind_major_walk_levels_are_the_oracles_sets(layout, model, N, L, R, E):
+    layout("rm")
+    inv = ("TypeOk", "WeakIsr", "StrongIsr")
+    o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=(), threads=4))
+    res, level_sets, _ = run(model, N, L, R, E, invariants=(), keep_levels=True, table_capacity=1 << 24, frontier_capacity=1 << 22)
+    assert (res.verdict, res.distinct, res.generated, res.depth, res.levels) == (o.verdict, o.distinct, o.generated, o.depth, o.levels)
+    assert list(res.action_generated.values()) == o.action_generated[:len(res.action_generated)]
+    assert res.deadlock_states == o.deadlock_states
+    for k in range(len(o.levels)):
+        assert level_sets[k] == o.level_states(k), f"level {k} state sets differ"
+    ov = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv, threads=4))
+    rv, _, _ = run(model, N, L, R, E, invariants=inv, table_capacity=1 << 24, frontier_capacity=1 << 22)
+    assert (rv.verdict, rv.violated_invariant) == (ov.verdict, ov.viol_inv)
+    if ov.viol_inv:
+        assert (rv.violation_depth, rv.violation_count) == (ov.viol_depth, ov.viol_count)
+
+
+def test_kind_major_walk_is_what_the_headline_constants_get(layout):
+    """No override: 3 brokers with LogSize 6 is replica-major — forcing `rm` changes nothing there — while forcing `tight`
+    packs the same fields differently; both are 3 words."""
+    consts = dict(model="Kip320", device=-1, n_replicas=3, log_size=6, max_records=6, max_leader_epoch=2)
+    s = kmo.Run(kmo.make_config("Kip320", N=3, L=6, R=6, E=2, invariants=(), max_states=2000, threads=1)).state(1500)
+    packed = {}
+    for mode in ("auto", "rm", "tight"):
+        layout(mode)
+        with ModelChecker(CheckerConfig(**consts)) as mc:
+            assert mc.state_words == 3 and mc.unpack(mc.pack(s)) == s
+            packed[mode] = tuple(mc.pack(s))
+    assert packed["auto"] == packed["rm"] != packed["tight"]
+
+
+@pytest.mark.parametrize("model", ["Kip279", "KafkaTruncateToHighWatermark"])
+def test_kind_major_walk_traces_and_sharding(layout, model):
+    """The meta plane of the ring (predecessor fingerprints) and the SHARDED sink behind the kind-major walk."""
+    layout("rm")
+    N, L, R, E = 3, 2, 2, 2
+    inv = ("TypeOk", "StrongIsr")
+    o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv))
+    assert o.verdict == "invariant"
+    cfg = CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, invariants=inv,
+                        keep_trace=True, table_capacity=1 << 22, frontier_capacity=1 << 20)
+    with ModelChecker(cfg) as mc:
+        r = mc.run()
+        assert (r.verdict, r.violated_invariant, r.violation_depth) == ("invariant", o.viol_inv, o.viol_depth)
+        trace = mc.trace()
+        names = mc.action_names()
+        witness = mc.unpack(mc.witness())
+    assert len(trace) == r.violation_depth and trace[0] == (None, o.state(0)) and trace[-1][1] == witness
+    for (_, prev), (act, cur) in zip(trace, trace[1:]):
+        assert (names.index(act), cur) in kmo.successors(o.cfg, prev, o.sb)   # each step is a Next step of that action
+    of = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=(), threads=4))
+    rs = check_loopback(CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, invariants=(),
+                                      table_capacity=1 << 22, frontier_capacity=1 << 20, send_capacity=1 << 18), 3)
+    assert (rs.distinct, rs.generated, rs.levels) == (of.distinct, of.generated, of.levels)
+
+
+@pytest.mark.parametrize("model,N,L,R,E", INSTANCE_MAJOR_LARGE)
+def test_instance_major_walk_on_a_large_golden_count(layout, model, N, L, R, E):
+    layout("tight")
+    name = {"Kip320": "oracle_kip320_3_5_5_2.json", "Kip279": "oracle_kip279_3_5_5_2.json"}[model]
+    g = json.load(open(os.path.join(HERE, "golden", name)))
+    inv = ("TypeOk", "WeakIsr", "StrongIsr") if model == "Kip320" else ("TypeOk",)
+    res, _, _ = run(model, N, L, R, E, invariants=inv, table_capacity=1 << 29, frontier_capacity=1 << 26)
+    assert (res.distinct, res.generated, res.depth) == (g["distinct"], g["generated"], g["depth"])
+    assert res.levels == g["levels"]
