@@ -88,6 +88,19 @@ def calibrated_bytes_per_access(mode):
     return (tot, os.path.relpath(path, ROOT)) if len(seen) == 3 else None
 
 
+def claims_per_distinct_state():
+    """(atomic requests per distinct state of the headline run, file) from the newest profiles/rNN_summary.json
+    (tools/summarize_profile.py: TCC_EA0_ATOMIC_sum over the states the profiled run found), or (None, None)."""
+    path = newest_profile("summary.json")
+    if not path:
+        return None, None
+    try:
+        v = json.load(open(path)).get("derived", {}).get("claims_per_distinct_state")
+    except Exception:
+        return None, None
+    return (float(v), os.path.relpath(path, ROOT)) if v else (None, None)
+
+
 def measured_traffic():
     """HBM bytes per k_expand launch from the newest committed PMC summary — only when it was measured on THIS
     device code (the summary carries the sha256 of the device sources); otherwise null, with the reason."""
@@ -210,6 +223,9 @@ def main():
     ap.add_argument("--small", action="store_true", help="debug: a small configuration instead of the headline")
     ap.add_argument("--workload", default=None, metavar="MODEL,N,L,R,E",
                     help="debug / tests: another Kafka-family binding instead of the headline (never a bench line)")
+    ap.add_argument("--level-budget", type=int, default=0, metavar="LEVELS",
+                    help="stop after LEVELS BFS levels and report states/s over that budget with \"exhausted\": false "
+                         "(SURVEY section 8d for configurations nobody can exhaust: BASELINE config 5 = --workload Kip320,7,8,8,3)")
     ap.add_argument("--backend", default=os.environ.get("KMC_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
                     help="process-group backend of the N>1 leg: nccl (= RCCL, the product) or gloo (CPU launch-path test)")
     a = ap.parse_args()
@@ -227,6 +243,8 @@ def main():
         c.update(model=m, n_replicas=int(n), log_size=int(l), max_records=int(r), max_leader_epoch=int(e))
         if m != "Kip320":
             c["invariants"] = ("TypeOk",)
+    if a.level_budget:
+        c["max_levels"] = a.level_budget
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
 
@@ -267,15 +285,16 @@ def main():
     # The two streams overlap in the kernel, so the bound is the larger of the two times, not their sum (round 1
     # quoted the sum with a constant the profile contradicted; it exceeded the kernel's own time).
     rates, rates_file = randbench_rates()
-    claims = 1.115 * distinct   # one CAS per new state plus the lost races (TCC_EA0_ATOMIC / distinct in profiles/)
+    cpd, cpd_file = claims_per_distinct_state()   # one CAS per new state plus the lost races, as the counters saw them
+    claims = (cpd or 0.0) * distinct
     random_access = None
-    if rates.get(1) and rates.get(3):
+    if rates.get(1) and rates.get(3) and cpd:
         lb = max(probes / rates[1], claims / rates[3])
         random_access = {
             "probe_loads_per_s": probes / max(kernel_s, 1e-12), "probe_loads_per_s_ceiling": rates[1],
             "claims_per_s": claims / max(kernel_s, 1e-12), "claims_per_s_ceiling": rates[3],
             "lower_bound_s": lb, "frac_of_lower_bound": min(1.0, lb / max(kernel_s, 1e-12)),
-            "source": rates_file + " (modes 1 and 3)"}
+            "source": rates_file + " (modes 1 and 3); claims per distinct state " + f"{cpd:.4f} from {cpd_file}"}
         # What actually bounds the kernel: HBM traffic of random accesses.  Every random 8-byte probe fills a whole
         # 128-byte line from DRAM (profiles/r02_request_size.txt).  The measured DRAM bytes of the run (PMC, same device
         # code) over the kernel time, against what the memory system sustains for the seen-set's own access mix —
@@ -308,6 +327,7 @@ def main():
         "config": {"workload": workload_name(c), "parallelism": parallelism, "state_bytes": S,
                    "distinct_states": distinct, "states_generated": generated, "seen_set_probes": probes, "depth": r.depth,
                    "verdict": r.verdict, "matches_oracle_golden": counts_match,
+                   "exhausted": r.verdict != "level_limit", "level_budget": a.level_budget or None,
                    "time_to_exhaustive_s": dt / a.steps, **extra},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_BPS, "traffic": traffic,
@@ -317,8 +337,8 @@ def main():
                      # SURVEY §8d asks for the granular figure beside the algorithmic one: what the same accesses cost
                      # at the memory's granularity — a 128-byte line fill per probe (not the 64-byte sector the survey
                      # assumed: profiles/r02_request_size.txt), a 64-byte atomic request per claim attempt
-                     "line_granular_bytes_per_distinct_state": 2 * S + 128 * g + 64 * claims / max(distinct, 1),
-                     "line_granular_GBps": (2 * S + 128 * g + 64 * claims / max(distinct, 1)) * distinct / max(kernel_s, 1e-12) / 1e9,
+                     "line_granular_bytes_per_distinct_state": (2 * S + 128 * g + 64 * cpd) if cpd else None,
+                     "line_granular_GBps": ((2 * S + 128 * g + 64 * cpd) * distinct / max(kernel_s, 1e-12) / 1e9) if cpd else None,
                      "useful_fraction_ceiling_of_a_probe": 8.0 / 128.0,
                      "traffic_source": traffic_source, "random_access": random_access, "per_rank": per_rank,
                      "device_source_sha256": device_source_sha256()[:16],

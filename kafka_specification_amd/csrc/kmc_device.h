@@ -12,10 +12,14 @@
 //     field is extracted once; the invariants of the state being expanded are checked here;
 //   * pass 1: the guards of all action instances of `Next` (every binding of the specs' \E over
 //     replicas / requests) in one straight-line VALU-domain block -> per-lane "enabled" bitset;
-//   * pass 2: a wave-uniform walk over the instances; a scalar binary dispatch jumps to the
-//     statically specialised effect of each instance some lane enabled, so lanes never diverge
-//     on *which* action they apply; enabled successors are compacted with __ballot + mbcnt
-//     prefix ranks into a per-wave LDS ring (SoA, conflict-free): the write-combining stage;
+//   * pass 2, two forms.  KIND-MAJOR (Kafka models on the replica-major layout of kmc_layout.h: the headline): a
+//     wave-uniform walk over the action KINDS; in every leaf each lane applies ITS OWN next enabled binding of that kind
+//     (KmcKafka::apply<K>: replicas / request epoch are per-lane run-time values, a field of replica r is "select word r,
+//     extract at a compile-time offset") until no lane has one left — 12 leaves per 64-state tile at the headline.
+//     INSTANCE-MAJOR (every other model and layout): a walk over the instances; a scalar binary dispatch jumps to the
+//     statically specialised effect of each instance some lane enabled (30 leaves per tile at the headline's constants).
+//     Either way lanes never diverge on *which* action they apply, and enabled successors are compacted with
+//     __ballot + mbcnt prefix ranks into a per-wave LDS ring (SoA, conflict-free): the write-combining stage;
 //   * a flush drains exactly 64 successors, one per lane, so the random HBM probes of the
 //     fingerprint table always run with a full wave of independent requests in flight:
 //     64-bit mix hash -> open-addressed linear probe -> atomicCAS(0 -> fp) claim;
@@ -589,7 +593,7 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
 
     // A lazy view over the packed state: fields are re-extracted on demand (one or two VALU ops
     // with compile-time offsets) instead of living in ~35 registers across the whole instance
-    // loop: 80 VGPRs = 6 waves/SIMD (with 95 VGPRs and 5 waves the kernel is 1.8 ms slower).
+    // loop (the instance-major kernel: 80 VGPRs = 6 waves/SIMD; with 95 VGPRs and 5 waves it was 1.8 ms slower).
     struct Pre {
         const u64* w;  // the packed state words (the caller's registers)
         KMC_DEV u32 end(int r) const { return (u32)kmc_getbits(w, Y.end_off[r], Y.BO); }
@@ -1765,13 +1769,8 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 
         KMC_T(tp2);
         KMC_TADD(1, tp1, tp2);
-        // Pass 2 — wave-uniform walk over the instances; only those some lane enabled dispatch
-        // to their (statically specialised) effect.  This loop is the arithmetic half of the kernel
-        // (30.1 leaves are dispatched per 64-state tile at the headline and an effect
-        // leaf runs for the whole wave although ~6.7 of 64 lanes enabled it; the other half is the
-        // memory system under the flushes' random probes).  Measured and dropped here: a fall-through
-        // `switch`, walking only the set bits of the wave-wide OR of en32 (s_ff1), per-kind
-        // `generated` counters in scalars (the array lands in scratch) or bumped with v_writelane.
+        // Pass 2 — the effects.  (with the table untouched the kernel takes 20 ms in the kind-major form and
+        // 26 ms in the instance-major one; the memory system needs ~31 ms for the run's probes and claims.)
         if constexpr (M::KIND_MAJOR) {
         // Kind-major walk (replica-major layouts, KmcKafka::apply<K>): for every action kind, every lane applies ITS OWN
         // next enabled binding of that kind in the same leaf — replicas and request epoch are run-time values, a field
@@ -1823,6 +1822,11 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             }
         }
         } else {
+        // Instance-major walk: only the instances some lane enabled dispatch to their (statically specialised) effect;
+        // a leaf runs for the whole wave although few lanes enabled it (30.1 leaves per tile and ~6.7 of 64 lanes at the
+        // headline's constants on the tight layout).  Measured and dropped here: a fall-through `switch`, walking only
+        // the set bits of the wave-wide OR of en32 (s_ff1), per-kind `generated` counters in scalars (the array lands in
+        // scratch) or bumped with v_writelane.
         u32 cur = 0;
 #pragma clang loop unroll(disable)
         for (int i = 0; i < M::NINST; ++i) {

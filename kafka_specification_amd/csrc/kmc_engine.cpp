@@ -27,7 +27,7 @@
 #include "kmc_sources.inc"  // generated: KMC_SRC_LAYOUT, KMC_SRC_DEVICE (the same two headers as text)
 
 // Levels kmc_run queues back to back before it waits (no progress callback): see run_levels.
-#define KMC_CHAIN 8
+#define KMC_CHAIN 32
 #define KMC_CTL_SLOTS (3 + KMC_CHAIN)   // two alternating levels + one auxiliary + one per chained level
 
 // KMC_VERIFY: both builds carry the fingerprint checksum (KMC_CHECKSUM, kmc_device.h); the second one differs in how it is
@@ -145,10 +145,20 @@ bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::strin
 }
 
 std::string strip_for_concat(const char* src) {
-    // drop '#pragma once' and the local include so the two headers can be fed to hiprtc as one file
+    // drop '#pragma once' and the local include so the two headers can be fed to hiprtc as one file; drop `//` comments
+    // (line structure kept) so that the text — and with it the key of the code-object cache — only changes with the code
     std::string out, line;
     for (const char* p = src;; ++p) {
         if (*p == '\n' || *p == 0) {
+            bool in_str = false;
+            for (size_t k = 0; k + 1 < line.size(); ++k) {
+                if (line[k] == '"' && (k == 0 || line[k - 1] != '\\')) in_str = !in_str;
+                if (!in_str && line[k] == '/' && line[k + 1] == '/') {
+                    line.erase(k);
+                    while (!line.empty() && (line.back() == ' ' || line.back() == '\t')) line.pop_back();
+                    break;
+                }
+            }
             if (line.rfind("#pragma once", 0) != 0 && line.rfind("#include \"kmc_layout.h\"", 0) != 0) {
                 out += line;
             }
@@ -528,6 +538,9 @@ int find_outside_witness(kmc_handle* h, const u64* frontier, const uint64_t seg[
 }
 
 int reset_run(kmc_handle* h) {
+    // (Clearing a second table on a side stream in the shadow of the run — a double-buffered seen-set — was measured in
+    // round 3: the step got 0.4 ms shorter, but the memset's own kernel competes with the first, small levels and their
+    // launches got 0.9 ms longer in total; dropped, profiles/r03_step_overhead.txt.)
     HIP_TRY(hipMemsetAsync(h->table, 0, h->table_cap * h->slot_words * 8, h->stream));
     if (h->pred) HIP_TRY(hipMemsetAsync(h->pred, 0, h->table_cap * 8, h->stream));
     if (h->sent) HIP_TRY(hipMemsetAsync(h->sent, 0, h->sent_cap * 8, h->stream));
@@ -1128,7 +1141,9 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             // this leaves a launch and two event records on the host instead of memset + launch + copy + wait
             // (46 levels, 7 of them under 1024 states: 2.4 ms of a 38 ms check in round 1).
             uint64_t B = max_levels - h->level;
+            static const uint64_t chain_max = getenv("KMC_CHAIN_MAX") ? (uint64_t)atoi(getenv("KMC_CHAIN_MAX")) : 16;
             if (B > KMC_CHAIN) B = KMC_CHAIN;
+            if (chain_max >= 1 && B > chain_max) B = chain_max;
             const uint64_t fan = max_fanout(h) ? max_fanout(h) : 1;
             {
                 // The load limit of the table (0.92, below) is a HOST decision, taken after a level: a batch is therefore

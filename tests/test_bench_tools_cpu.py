@@ -30,9 +30,10 @@ def test_dram_bytes_per_access_are_read_from_the_committed_calibration(bench):
 
 def test_traffic_is_quoted_only_for_the_device_code_it_was_measured_on(bench, monkeypatch):
     t, src = bench.measured_traffic()
-    pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+    newest = bench.newest_profile("pmc_summary.json")
+    pm = json.load(open(newest))
     if pm["device_source_sha256"] == bench.device_source_sha256():
-        assert t == pm["hbm_bytes_per_launch"] and src == "profiles/r02_pmc_summary.json"
+        assert t == pm["hbm_bytes_per_launch"] and src == os.path.relpath(newest, ROOT)
         # the DRAM-unit counters, not FETCH_SIZE: reads are twice what FETCH_SIZE reports on gfx950
         assert abs(pm["read_bytes"] / pm["FETCH_SIZE_bytes_as_reported"] - 2.0) < 0.01
         assert abs(pm["hbm_bytes"] - (pm["read_bytes"] + pm["write_bytes"] + pm["atomic_bytes"])) < 1.0
@@ -41,8 +42,12 @@ def test_traffic_is_quoted_only_for_the_device_code_it_was_measured_on(bench, mo
     assert t2 is None and "other device code" in why
 
 
-def test_committed_bench_line_keeps_the_contract_and_is_self_consistent():
-    j = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+NEWEST_ROUND = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench.json"))[-1][:3]
+
+
+@pytest.mark.parametrize("rnd", sorted({"r02", NEWEST_ROUND}))
+def test_committed_bench_line_keeps_the_contract_and_is_self_consistent(rnd):
+    j = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
@@ -70,9 +75,10 @@ def test_committed_bench_line_keeps_the_contract_and_is_self_consistent():
     assert c["kind"] == "port" and c["unit"] == j["unit"] and c["cores"] >= 1
 
 
-def test_rocprof_kernel_stats_agree_with_the_bench_line():
-    j = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv"))))
+@pytest.mark.parametrize("rnd", sorted({"r02", NEWEST_ROUND}))
+def test_rocprof_kernel_stats_agree_with_the_bench_line(rnd):
+    j = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_bench.json")))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats.csv"))))
     top = rows[0]
     assert top["Name"].startswith("kmc_expand_") and float(top["Percentage"]) > 90.0        # the dominant kernel
     assert int(top["Calls"]) == j["roofline"]["launches_per_step"]
@@ -113,6 +119,26 @@ def test_summarize_profile_derives_dram_bytes_from_the_32_byte_unit_counters(tmp
     assert p["hbm_bytes"] == 32 * 1030 and p["hbm_bytes_per_launch"] == 32 * 1030 / 2
     assert p["read_bytes"] == 2 * p["FETCH_SIZE_bytes_as_reported"]
     assert len(p["device_source_sha256"]) == 64
+
+
+def test_claims_per_state_come_from_the_profile_not_from_a_literal(bench):
+    """the claim stream of the roofline block was priced with a typed-in 1.115 x distinct.  It is the
+    ratio of the atomic requests the memory side counted to the states the profiled run found, read from the newest
+    committed summary; and no other unexplained number feeds the bench line."""
+    import ast
+    cpd, src = bench.claims_per_distinct_state()
+    s = json.load(open(os.path.join(ROOT, src)))
+    assert abs(cpd - s["counters_sum_over_launches"]["TCC_EA0_ATOMIC_sum"] / s["run"]["distinct_states"]) < 1e-12
+    assert 1.0 <= cpd < 1.3                                  # one claim per new state plus the lost races
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    # structural constants only: 0 / 1 / 2 / 4, unit conversions, bytes per word, the 128-byte line and 64-byte atomic
+    # request of profiles/r02_request_size.txt, the smallest cpu_baseline sample; everything measured is read from profiles/
+    # (3 and 7 are randbench MODE numbers — which line of the committed file to read —, 16 the length of the sha prefix)
+    allowed = {0, 1, 2, 3, 4, 7, 8, 16, 64, 128, 8.0, 128.0, 1e3, 1e9, 1e-12, 1.0, 1_000_000}
+    odd = sorted({n.value for n in ast.walk(main) if isinstance(n, ast.Constant) and isinstance(n.value, (int, float))
+                  and not isinstance(n.value, bool)} - allowed)
+    assert odd == [], f"numeric literals in bench.main(): {odd}"
 
 
 def test_ladder_tool_configurations_are_valid_bindings():

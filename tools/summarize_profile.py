@@ -66,6 +66,17 @@ if "SQ_WAVE_CYCLES" in ctr:
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if k in ctr:
             der[k + "_frac_of_wave_cycles"] = ctr[k] / wc
+# the run the counters belong to (the bench line rocprofv3's first pass printed): claims per distinct state = the atomic
+# requests the memory side saw over the states the run found — bench.py prices the claim stream with this ratio
+try:
+    for line in open(os.path.join(d, "trace.log")):
+        if line.startswith('{"metric"'):
+            run = json.loads(line)
+            out["run"] = {k: run["config"].get(k) for k in ("workload", "distinct_states", "states_generated", "seen_set_probes")}
+            if "TCC_EA0_ATOMIC_sum" in ctr and run["config"].get("distinct_states"):
+                der["claims_per_distinct_state"] = ctr["TCC_EA0_ATOMIC_sum"] / run["config"]["distinct_states"]
+except OSError:
+    pass
 out["derived"] = der
 out["kernel_seconds_total"] = t
 out["launches"] = n
