@@ -91,19 +91,25 @@ def precompile_variants():
             (small, {"KMC_JIT_DEFINES": "-DKMC_TEST_FP_BITS=10"})] + layout_variants()   # (collisions on demand for the wide-fingerprint test)
 
 
-# The two arrangements of the Kafka state vector (csrc/kmc_layout.h) and the two walks of k_expand's pass 2 that go with
-# them: replica-major + kind-major where a replica fills most of a word (the headline), tight + instance-major elsewhere.
-# tests/test_gpu_kind_major.py forces each onto the other's configurations (KMC_LAYOUT=rm / tight).
+# The arrangements of the Kafka state vector (csrc/kmc_layout.h) and the two walks of k_expand's pass 2 that go with them:
+# replica-major (one replica per word at the headline's constants, grouped elsewhere) + kind-major by default, tight +
+# instance-major only on request.  tests/test_gpu_kind_major.py forces each form onto configurations that get another by
+# default (KMC_LAYOUT=rm / rmg / tight).
 KIND_MAJOR_SMALL = [(m, N, L, R, E) for m in KAFKA for (N, L, R, E) in [(3, 2, 2, 1), (2, 3, 3, 2)]] + [
     ("Kip320", 4, 2, 2, 1), ("Kip279", 5, 1, 1, 1), ("Kip101", 4, 2, 1, 1), ("Kip320", 3, 2, 2, 2),
     ("KafkaTruncateToHighWatermark", 3, 2, 2, 2), ("Kip101", 3, 2, 2, 2), ("Kip279", 3, 2, 2, 2), ("Kip320FirstTry", 3, 2, 2, 2)]
+INSTANCE_MAJOR_SMALL = [(m, 3, 2, 2, 1) for m in KAFKA] + [("Kip320", 4, 2, 2, 1), ("Kip279", 5, 1, 1, 1), ("Kip320", 3, 2, 2, 2),
+                                                              ("Kip279", 3, 2, 2, 2)]
 INSTANCE_MAJOR_LARGE = [("Kip320", 3, 5, 5, 2), ("Kip279", 3, 5, 5, 2)]
+GROUPED_LARGE = [("Kip320", 3, 5, 5, 2)]
 
 
 def layout_variants():
     def c(t):
         return dict(model=t[0], n_replicas=t[1], log_size=t[2], max_records=t[3], max_leader_epoch=t[4])
-    return [(c(t), {"KMC_LAYOUT": "rm"}) for t in KIND_MAJOR_SMALL] + [(c(t), {"KMC_LAYOUT": "tight"}) for t in INSTANCE_MAJOR_LARGE]
+    return ([(c(t), {"KMC_LAYOUT": "rm"}) for t in KIND_MAJOR_SMALL] +
+            [(c(t), {"KMC_LAYOUT": "tight"}) for t in INSTANCE_MAJOR_SMALL + INSTANCE_MAJOR_LARGE] +
+            [(c(t), {"KMC_LAYOUT": "rmg"}) for t in GROUPED_LARGE])
 
 
 def all_precompile_configs():

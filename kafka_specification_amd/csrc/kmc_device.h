@@ -938,8 +938,9 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
     // (kind, binding) some lane enabled: 30 leaves per 64-state tile at the headline, each for ~7 busy lanes.  apply<K>
     // takes the binding of its kind at RUN time, per lane: every lane applies ITS OWN next enabled binding of kind K in
     // the same leaf, so a tile needs max-over-lanes(enabled bindings of K) leaves per kind — 12.6 per tile instead of
-    // 30 (tools/locality_sim.cpp).  That needs a field of a run-time replica to be cheap: under the replica-major layout
-    // it is "select word r, extract at a compile-time offset".  Guards are NOT re-evaluated here (pass 1 did, with
+    // 30 (tools/locality_sim.cpp).  That needs a field of a run-time replica to be cheap: under the replica-major layouts
+    // it is "select a word, shift by a multiple of a stride, extract at a compile-time offset" (no shift with one replica
+    // per word, the headline's layout).  Guards are NOT re-evaluated here (pass 1 did, with
     // inst<I>); tests/host_emu.cpp holds apply<K>(b) to inst<B_K + b> on every enabled binding of every visited state.
     static constexpr int kind_base(int k) {
         return k == 0 ? B0 : k == 1 ? B1 : k == 2 ? B2 : k == 3 ? B3 : k == 4 ? B4 : k == 5 ? B5 : k == 6 ? B6
@@ -951,36 +952,56 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         for (int k = 0; k < NKINDS; ++k) m = kind_count(k) > m ? kind_count(k) : m;
         return m;
     }
-    // (a kind's enabled bindings are one per-lane bitset of at most 64 bits in pass 2)
-    static constexpr bool KIND_MAJOR = Y.rm != 0 && max_kind_count() <= 64;
-    using KindBits = typename KmcLogWord<(max_kind_count() <= 32)>::type;
-    // bits [kind_base(K), kind_base(K+1)) of the per-lane "enabled instances" bitset en32[] (32-bit words), as one value
-    template <int K> static KMC_DEV KindBits kind_bits(const u32* en32) {
-        constexpr int lo = kind_base(K), cnt = kind_count(K);
-        if constexpr (cnt == 0) {
-            return (KindBits)0;
-        } else {
-            u64 v = 0;
-            kmc_static_for<lo / 32, (lo + cnt + 31) / 32>([&](auto H) {
-                constexpr int h = decltype(H)::value;
-                if constexpr (32 * h >= lo) v |= (u64)en32[h] << (32 * h - lo);
-                else v |= (u64)(en32[h] >> (lo - 32 * h));
-            });
-            constexpr u64 mask = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
-            return (KindBits)(v & mask);
-        }
+    static constexpr bool KIND_MAJOR = Y.rm != 0;
+    // Pass 2 walks SEGMENTS: a kind's bindings in windows of at most WINBITS consecutive ones (one per-lane bitset each;
+    // only 6 or more replicas have kinds with more bindings than one window).
+    static constexpr int WINBITS = max_kind_count() <= 32 ? 32 : 64;
+    using KindBits = typename KmcLogWord<(WINBITS == 32)>::type;
+    static constexpr int kind_windows(int k) { return (kind_count(k) + WINBITS - 1) / WINBITS; }
+    static constexpr int n_segments() {
+        int n = 0;
+        for (int k = 0; k < NKINDS; ++k) n += kind_windows(k);
+        return n;
     }
-
-    // the word of replica r (run-time r): a select chain over registers, never an indexed array (that would be scratch)
-    // (Each step is an opaque v_cndmask per 32-bit half: the plain chain `r == k ? w[k] : v` was recognised as w[r], the
+    static constexpr int NSEGS = n_segments();
+    static constexpr int seg_kind(int sg) {
+        for (int k = 0; k < NKINDS; ++k) {
+            if (sg < kind_windows(k)) return k;
+            sg -= kind_windows(k);
+        }
+        return 0;
+    }
+    static constexpr int seg_first(int sg) {   // first binding (within its kind) of segment sg
+        for (int k = 0; k < NKINDS; ++k) {
+            if (sg < kind_windows(k)) return sg * WINBITS;
+            sg -= kind_windows(k);
+        }
+        return 0;
+    }
+    // the segment's bits of the per-lane "enabled instances" bitset en32[] (32-bit words), as one value
+    template <int SG> static KMC_DEV KindBits seg_bits(const u32* en32) {
+        constexpr int K = seg_kind(SG), first = seg_first(SG);
+        constexpr int lo = kind_base(K) + first;
+        constexpr int cnt = kind_count(K) - first < WINBITS ? kind_count(K) - first : WINBITS;
+        u64 v = 0;
+        kmc_static_for<lo / 32, (lo + cnt + 31) / 32>([&](auto H) {
+            constexpr int h = decltype(H)::value;
+            if constexpr (32 * h >= lo) v |= (u64)en32[h] << (32 * h - lo);
+            else v |= (u64)(en32[h] >> (lo - 32 * h));
+        });
+        constexpr u64 mask = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        return (KindBits)(v & mask);
+    }
+    // One of `count` consecutive state words, chosen at run time: a select chain over registers, never an indexed array.
+    // (Each step is an opaque v_cndmask per 32-bit half: the plain chain `i == k ? w[k] : v` was recognised as w[i], the
     // state words went to scratch memory and every leaf loaded them back with a per-lane address — 255 M more vector
     // memory instructions per run and the headline at 41.9 ms instead of 35, profiles/r03_kind_major.txt.  Halves, so that
     // a leaf which only reads a replica's small fields does not select its log.)
-    static KMC_DEV u64 rep_word(const u64* w, u32 r) {
+    template <int COUNT> static KMC_DEV u64 sel_word(const u64* w, u32 i) {
         u32 lo = (u32)w[0], hi = (u32)(w[0] >> 32);
-        kmc_static_for<1, N>([&](auto KK) {
+        kmc_static_for<1, COUNT>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
-            const bool c = r == (u32)k;
+            const bool c = i == (u32)k;
             lo = c ? (u32)w[k] : lo;
             hi = c ? (u32)(w[k] >> 32) : hi;
             KMC_OPAQUE_PURE(lo);
@@ -988,29 +1009,85 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         });
         return ((u64)hi << 32) | lo;
     }
-    static KMC_DEV void put_rep_word(u64* t, u32 r, u64 v) {
-        kmc_static_for<0, N>([&](auto KK) {
+    template <int COUNT> static KMC_DEV void put_word(u64* t, u32 i, u64 v) {
+        kmc_static_for<0, COUNT>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
-            const bool c = r == (u32)k;
+            const bool c = i == (u32)k;
             u32 lo = c ? (u32)v : (u32)t[k], hi = c ? (u32)(v >> 32) : (u32)(t[k] >> 32);
             KMC_OPAQUE_PURE(lo);
             KMC_OPAQUE_PURE(hi);
             t[k] = ((u64)hi << 32) | lo;
         });
     }
-    // a replica's fields inside its word (compile-time offsets, the same for every replica)
-    static KMC_DEV u32 w_fld(u64 w, int off, int bits) { return (u32)(w >> off) & ((1u << bits) - 1u); }
-    static KMC_DEV u64 w_set(u64 w, int off, int bits, u32 val) {
-        const u64 m = ((1ull << bits) - 1ull) << off;
-        return (w & ~m) | (((u64)val << off) & m);
+    // A replica chosen at run time: its log and its group of small fields (end | hw | ep | ldr | isr from bit 0), taken from
+    // the words kmc_layout.h put them in.  `raw` (one replica per word only) is the replica's whole word as the PARENT has it.
+    static constexpr bool ONE_PER_WORD = Y.rm == 1;
+    static constexpr u64 LOGMASK = (Y.LB >= 64) ? ~0ull : ((1ull << Y.LB) - 1ull);
+    static constexpr u32 SMMASK = (Y.SB >= 32) ? ~0u : ((1u << Y.SB) - 1u);
+    static constexpr int O_END = 0, O_HW = Y.BO, O_EP = 2 * Y.BO, O_LDR = 2 * Y.BO + Y.BE, O_ISR = 2 * Y.BO + Y.BE + Y.BL;
+    struct Rep {
+        LogT log;
+        u32 sm;
+        u64 raw;
+        KMC_DEV u32 end() const { return (sm >> O_END) & ((1u << Y.BO) - 1u); }
+        KMC_DEV u32 hw() const { return (sm >> O_HW) & ((1u << Y.BO) - 1u); }
+        KMC_DEV u32 ep1() const { return (sm >> O_EP) & ((1u << Y.BE) - 1u); }
+        KMC_DEV u32 isr() const { return (sm >> O_ISR) & ((1u << Y.BI) - 1u); }
+        KMC_DEV void set(int off, int bits, u32 val) {
+            const u32 m = ((1u << bits) - 1u) << off;
+            sm = (sm & ~m) | ((val << off) & m);
+        }
+    };
+    static KMC_DEV LogT get_log(const u64* w, u32 r) {
+        if constexpr (Y.lg_q == 1) {
+            return (LogT)((sel_word<Y.lg_words>(w + Y.lg_word0, r) >> Y.lg_base) & LOGMASK);
+        } else {
+            const u32 sh = (r % (u32)Y.lg_q) * (u32)Y.lg_stride + (u32)Y.lg_base;
+            return (LogT)((sel_word<Y.lg_words>(w + Y.lg_word0, r / (u32)Y.lg_q) >> sh) & LOGMASK);
+        }
     }
-    static KMC_DEV u32 w_end(u64 w) { return w_fld(w, Y.f_end, Y.BO); }
-    static KMC_DEV u32 w_hw(u64 w) { return w_fld(w, Y.f_hw, Y.BO); }
-    static KMC_DEV u32 w_ep1(u64 w) { return w_fld(w, Y.f_ep, Y.BE); }
-    static KMC_DEV u32 w_isr(u64 w) { return w_fld(w, Y.f_isr, Y.BI); }
-    static constexpr u64 LOGMASK = (Y.BR * L >= 64) ? ~0ull : ((1ull << (Y.BR * L)) - 1ull);
-    static KMC_DEV LogT w_log(u64 w) { return (LogT)(w & LOGMASK); }   // f_log = 0
-    static KMC_DEV u64 w_setlog(u64 w, LogT lv) { return (w & ~LOGMASK) | ((u64)lv & LOGMASK); }
+    static KMC_DEV u32 get_small(const u64* w, u32 r) {
+        if constexpr (Y.sm_q == 1) {
+            return (u32)(sel_word<Y.sm_words>(w + Y.sm_word0, r) >> Y.sm_base) & SMMASK;
+        } else {
+            const u32 sh = (r % (u32)Y.sm_q) * (u32)Y.sm_stride + (u32)Y.sm_base;
+            return (u32)(sel_word<Y.sm_words>(w + Y.sm_word0, r / (u32)Y.sm_q) >> sh) & SMMASK;
+        }
+    }
+    static KMC_DEV Rep get_rep(const u64* w, u32 r) {
+        if constexpr (ONE_PER_WORD) {
+            const u64 x = sel_word<N>(w, r);
+            return Rep{(LogT)(x & LOGMASK), (u32)(x >> Y.sm_base) & SMMASK, x};
+        } else {
+            return Rep{get_log(w, r), get_small(w, r), 0ull};
+        }
+    }
+    // Writes replica r back into t.  WLOG / WSM say which part changed.  One replica per word: its word is rebuilt from the
+    // PARENT's (v.raw) — so a replica is put into t BEFORE any global field of t is written (they live in the spare bits of
+    // the same words).  Grouped: a read-modify-write of t's own words, in any order.
+    template <bool WLOG, bool WSM> static KMC_DEV void put_rep(u64* t, u32 r, const Rep& v) {
+        if constexpr (ONE_PER_WORD) {
+            u64 x = v.raw;
+            if constexpr (WLOG) x = (x & ~LOGMASK) | ((u64)v.log & LOGMASK);
+            if constexpr (WSM) x = (x & ~((u64)SMMASK << Y.sm_base)) | ((u64)(v.sm & SMMASK) << Y.sm_base);
+            put_word<N>(t, r, x);
+        } else {
+            if constexpr (WLOG) {
+                const u32 wi = Y.lg_q == 1 ? r : r / (u32)Y.lg_q;
+                const u32 sh = Y.lg_q == 1 ? (u32)Y.lg_base : (r % (u32)Y.lg_q) * (u32)Y.lg_stride + (u32)Y.lg_base;
+                u64 x = sel_word<Y.lg_words>(t + Y.lg_word0, wi);
+                x = (x & ~(LOGMASK << sh)) | (((u64)v.log & LOGMASK) << sh);
+                put_word<Y.lg_words>(t + Y.lg_word0, wi, x);
+            }
+            if constexpr (WSM) {
+                const u32 wi = Y.sm_q == 1 ? r : r / (u32)Y.sm_q;
+                const u32 sh = Y.sm_q == 1 ? (u32)Y.sm_base : (r % (u32)Y.sm_q) * (u32)Y.sm_stride + (u32)Y.sm_base;
+                u64 x = sel_word<Y.sm_words>(t + Y.sm_word0, wi);
+                x = (x & ~((u64)SMMASK << sh)) | ((u64)(v.sm & SMMASK) << sh);
+                put_word<Y.sm_words>(t + Y.sm_word0, wi, x);
+            }
+        }
+    }
     // the isr of the request with leader epoch e (run-time e)
     static KMC_DEV u32 risr_rt(const Pre& p, u32 e) {
         u32 v = p.risr(0);
@@ -1020,7 +1097,7 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         });
         return v;
     }
-    // (l, r) of the q-th ordered pair of distinct replicas: the enumeration inst<I> uses for its (leader, other) bindings
+    // (l, r) of the j-th ordered pair of distinct replicas: the enumeration inst<I> uses for its (leader, other) bindings
     static KMC_DEV void pair_of(u32 j, u32& l, u32& r) {
         l = j / (u32)(N - 1);
         const u32 q = j % (u32)(N - 1);
@@ -1032,8 +1109,6 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         extra = 0;
 #pragma unroll
         for (int k = 0; k < W; ++k) t[k] = s[k];
-        // (a replica's word is rebuilt from the PARENT's and put into t before any global field of t is written: the
-        // global fields live in the spare bits of the same words)
         if constexpr (K == 0) {
             // ControllerElectLeader (KafkaReplication.tla:176-179)
             controller_update(t, p, b + 1u, p.qisr());
@@ -1048,99 +1123,106 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         } else if constexpr (K == 2) {
             // BecomeLeader (:186-195): request e names leader l
             const u32 e = b / (u32)N, l = b % (u32)N;
-            u64 w = rep_word(s, l);
-            w = w_set(w, Y.f_ep, Y.BE, e + 1u);
-            w = w_set(w, Y.f_ldr, Y.BL, l + 1u);
-            w = w_set(w, Y.f_isr, Y.BI, risr_rt(p, e));
-            put_rep_word(t, l, w);
+            Rep v = get_rep(s, l);
+            v.set(O_EP, Y.BE, e + 1u);
+            v.set(O_LDR, Y.BL, l + 1u);
+            v.set(O_ISR, Y.BI, risr_rt(p, e));
+            put_rep<false, true>(t, l, v);
         } else if constexpr (K == 3) {
             // Leader*ExpandIsr* (:248-254, Kip320.tla:110-117, Kip320FirstTry.tla:134-141): QuorumUpdateLeaderAndIsr
             const u32 l = b / (u32)N, r = b % (u32)N;
-            u64 w = rep_word(s, l);
-            const u32 nisr = w_isr(w) | (1u << r);
-            put_rep_word(t, l, w_set(w, Y.f_isr, Y.BI, nisr));
+            Rep v = get_rep(s, l);
+            const u32 nisr = v.isr() | (1u << r);
+            v.set(O_ISR, Y.BI, nisr);
+            put_rep<false, true>(t, l, v);
             kmc_setbits(t, Y.qisr_off, Y.BI, nisr);
         } else if constexpr (K == 4) {
             // Leader*ShrinkIsr* (:233-239, Kip320.tla:78-85, Kip320FirstTry.tla:114-120)
             u32 l, r;
             pair_of(b, l, r);
-            const u64 w = rep_word(s, l);
-            const u32 nisr = w_isr(w) & ~(1u << r);
-            put_rep_word(t, l, w_set(w, Y.f_isr, Y.BI, nisr));
+            Rep v = get_rep(s, l);
+            const u32 end_l = v.end();
+            const u32 nisr = v.isr() & ~(1u << r);
+            v.set(O_ISR, Y.BI, nisr);
+            put_rep<false, true>(t, l, v);
             kmc_setbits(t, Y.qisr_off, Y.BI, nisr);
             if constexpr (K320) {  // both disjuncts of Kip320.tla:82-83
                 const u32 following = (u32)(p.fm >> (l * (u32)N + r)) & 1u;
-                extra = (following == 0u && w_end(rep_word(s, r)) < w_end(w)) ? 1u : 0u;
+                const u32 end_r = get_small(s, r) & ((1u << Y.BO) - 1u);
+                extra = (following == 0u && end_r < end_l) ? 1u : 0u;
             }
         } else if constexpr (K == 5) {
             // LeaderWrite (:202-207)
             const u32 r = b;
-            u64 w = rep_word(s, r);
-            const u32 end = w_end(w);
-            const LogT rec = (LogT)(((p.nextRec() + 1u) << Y.BEr) | (w_ep1(w) - 1u));
-            w = w_setlog(w, (LogT)(w_log(w) | (LogT)(rec << (end * Y.BR))));
-            w = w_set(w, Y.f_end, Y.BO, end + 1u);
-            put_rep_word(t, r, w);
+            Rep v = get_rep(s, r);
+            const u32 end = v.end();
+            const LogT rec = (LogT)(((p.nextRec() + 1u) << Y.BEr) | (v.ep1() - 1u));
+            v.log = (LogT)(v.log | (LogT)(rec << (end * Y.BR)));
+            v.set(O_END, Y.BO, end + 1u);
+            put_rep<true, true>(t, r, v);
             kmc_setbits(t, Y.nextrec_off, Y.BNR, p.nextRec() + 1u);
         } else if constexpr (K == 6) {
             // *LeaderIncHighWatermark (:264-271, Kip320.tla:63-70, Kip320FirstTry.tla:90-97)
             const u32 l = b;
-            const u64 w = rep_word(s, l);
-            put_rep_word(t, l, w_set(w, Y.f_hw, Y.BO, w_hw(w) + 1u));
+            Rep v = get_rep(s, l);
+            v.set(O_HW, Y.BO, v.hw() + 1u);
+            put_rep<false, true>(t, l, v);
         } else if constexpr (K == 7) {
             // BecomeFollower* of leader l at request epoch e (:281-294 and the five truncation rules)
             const u32 pr = b / (u32)(E + 1), e = b % (u32)(E + 1);
             u32 l, r;
             pair_of(pr, l, r);
-            u64 w = rep_word(s, r);
-            const u32 end_r = w_end(w), hw_r = w_hw(w);
-            const LogT log_r = w_log(w);
-            w = w_set(w, Y.f_ep, Y.BE, e + 1u);
-            w = w_set(w, Y.f_ldr, Y.BL, l + 1u);
-            w = w_set(w, Y.f_isr, Y.BI, risr_rt(p, e));
-            if constexpr (!FIRST) {
+            Rep v = get_rep(s, r);
+            const u32 end_r = v.end(), hw_r = v.hw();
+            v.set(O_EP, Y.BE, e + 1u);
+            v.set(O_LDR, Y.BL, l + 1u);
+            v.set(O_ISR, Y.BI, risr_rt(p, e));
+            if constexpr (FIRST) {
+                put_rep<false, true>(t, r, v);   // BecomeFollower (Kip320FirstTry.tla:148-157): no truncation, hw unchanged
+            } else {
                 u32 off;
                 if constexpr (MODEL == KMC_MODEL_TRUNCATE_TO_HW) {
                     off = hw_r;  // KafkaTruncateToHighWatermark.tla:29-31
                 } else {
-                    const u64 wl = rep_word(s, l);
+                    const LogT log_l = get_log(s, l);
+                    const u32 end_l = get_small(s, l) & ((1u << Y.BO) - 1u);
                     if constexpr (MODEL == KMC_MODEL_KIP101) {  // Kip101.tla:41-47
-                        const u32 last_epoch = rec_epoch(rec_at(log_r, end_r == 0 ? 0u : end_r - 1u));
-                        off = end_r == 0 ? 0u : lookup_offset_for_epoch_v(w_log(wl), w_end(wl), hw_r, last_epoch);
+                        const u32 last_epoch = rec_epoch(rec_at(v.log, end_r == 0 ? 0u : end_r - 1u));
+                        off = end_r == 0 ? 0u : lookup_offset_for_epoch_v(log_l, end_l, hw_r, last_epoch);
                     } else {  // Kip279.tla:47-51 / Kip320.tla:134-148
-                        off = first_non_matching_v(w_log(wl), log_r, w_end(wl), end_r);
+                        off = first_non_matching_v(log_l, v.log, end_l, end_r);
                         if constexpr (MODEL == KMC_MODEL_KIP279) extra = end_r == 0 ? 1u : 0u;
                     }
                 }
-                w = w_setlog(w, (LogT)(log_r & keep_below(off)));   // TruncateTo (FiniteReplicatedLog.tla:105-109)
-                w = w_set(w, Y.f_end, Y.BO, off);
-                w = w_set(w, Y.f_hw, Y.BO, kmc_min(off, hw_r));
+                v.log = (LogT)(v.log & keep_below(off));   // TruncateTo (FiniteReplicatedLog.tla:105-109)
+                v.set(O_END, Y.BO, off);
+                v.set(O_HW, Y.BO, kmc_min(off, hw_r));
+                put_rep<true, true>(t, r, v);
             }
-            put_rep_word(t, r, w);
         } else if constexpr (K == 8) {
             // FollowerReplicate / *Fetch (:302-310, Kip320.tla:49-56, Kip320FirstTry.tla:103-111)
             u32 l, f;
             pair_of(b, l, f);
-            const u64 wl = rep_word(s, l);
-            u64 w = rep_word(s, f);
-            const u32 ef = w_end(w);
-            const LogT rec = (LogT)rec_at(w_log(wl), ef);
-            w = w_setlog(w, (LogT)(w_log(w) | (LogT)(rec << (ef * Y.BR))));
-            w = w_set(w, Y.f_end, Y.BO, ef + 1u);
-            w = w_set(w, Y.f_hw, Y.BO, kmc_min(w_hw(wl), ef + 1u));
-            put_rep_word(t, f, w);
+            const Rep vl = get_rep(s, l);
+            Rep v = get_rep(s, f);
+            const u32 ef = v.end();
+            const LogT rec = (LogT)rec_at(vl.log, ef);
+            v.log = (LogT)(v.log | (LogT)(rec << (ef * Y.BR)));
+            v.set(O_END, Y.BO, ef + 1u);
+            v.set(O_HW, Y.BO, kmc_min(vl.hw(), ef + 1u));
+            put_rep<true, true>(t, f, v);
         } else {
             // FollowerTruncate (Kip320FirstTry.tla:75-82)
             u32 l, f;
             pair_of(b, l, f);
-            const u64 wl = rep_word(s, l);
-            u64 w = rep_word(s, f);
-            const u32 off = first_non_matching_v(w_log(wl), w_log(w), w_end(wl), w_end(w));
-            const u32 hw_f = w_hw(w);
-            w = w_setlog(w, (LogT)(w_log(w) & keep_below(off)));
-            w = w_set(w, Y.f_end, Y.BO, off);
-            w = w_set(w, Y.f_hw, Y.BO, kmc_min(off, hw_f));
-            put_rep_word(t, f, w);
+            const Rep vl = get_rep(s, l);
+            Rep v = get_rep(s, f);
+            const u32 off = first_non_matching_v(vl.log, v.log, vl.end(), v.end());
+            const u32 hw_f = v.hw();
+            v.log = (LogT)(v.log & keep_below(off));
+            v.set(O_END, Y.BO, off);
+            v.set(O_HW, Y.BO, kmc_min(off, hw_f));
+            put_rep<true, true>(t, f, v);
         }
     }
 
@@ -1777,10 +1859,16 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         // of replica r is "select word r, extract at a compile-time offset" — until no lane has one left.  A tile costs
         // sum over kinds of max-over-lanes(enabled bindings) leaves: 12.6 at the headline where the instance-major walk
         // below dispatches 30 (one per (kind, binding) ANY lane enabled), each with twice the lanes busy.
+        // (The walk is over SEGMENTS: a kind's bindings in windows of at most 32 / 64, one per-lane bitset each — more than
+        // one window per kind only from 6 replicas on.)
 #pragma clang loop unroll(disable)
-        for (int k = 0; k < M::NKINDS; ++k) {
+        for (int sgi = 0; sgi < M::NSEGS; ++sgi) {
             typename M::KindBits km = 0;
-            kmc_dispatch<0, M::NKINDS>(k, [&](auto KK) { km = M::template kind_bits<decltype(KK)::value>(en32); });
+            int k = 0;   // the segment's action kind (wave-uniform)
+            kmc_dispatch<0, M::NSEGS>(sgi, [&](auto SS) {
+                km = M::template seg_bits<decltype(SS)::value>(en32);
+                k = M::seg_kind(decltype(SS)::value);
+            });
 #pragma clang loop unroll(disable)
             for (;;) {
                 const bool e = km != 0;
@@ -1799,8 +1887,9 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
                 for (int q2 = 0; q2 < W; ++q2) kmc_launder(s[q2]);
                 u32 extra = 0;
                 u64 t[W];
-                kmc_dispatch<0, M::NKINDS>(k, [&](auto KK) {
-                    M::template apply<decltype(KK)::value>(pre, s, t, b, extra);
+                kmc_dispatch<0, M::NSEGS>(sgi, [&](auto SS) {
+                    constexpr int sg = decltype(SS)::value;
+                    M::template apply<M::seg_kind(sg)>(pre, s, t, b + (u32)M::seg_first(sg), extra);
                 });
                 const u32 n = __popcll(m);
                 if constexpr (M::HAS_EXTRA) extra_lane += e ? extra : 0u;

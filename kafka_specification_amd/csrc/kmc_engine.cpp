@@ -128,12 +128,14 @@ bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::strin
         // the state vector (kmc_layout.h); host and device evaluate the same constexpr function with the same mode
         const char* lenv = getenv("KMC_LAYOUT");
         const int lm = !lenv || !*lenv || !strcmp(lenv, "auto") ? KMC_LAYOUT_AUTO
-                       : !strcmp(lenv, "tight") ? KMC_LAYOUT_TIGHT : !strcmp(lenv, "rm") ? KMC_LAYOUT_RM : -1;
+                       : !strcmp(lenv, "tight") ? KMC_LAYOUT_TIGHT : !strcmp(lenv, "rm") ? KMC_LAYOUT_RM
+                       : !strcmp(lenv, "rmg") ? KMC_LAYOUT_RMG : -1;
         if (lm < 0) return false;
         *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, c.max_records, c.max_leader_epoch, 0, lm);
         if (!lay->valid || c.n_replicas < 2) return false;
         snprintf(buf, sizeof buf, "%s_N%d_L%d_R%d_E%d%s", MODEL_NAMES[c.model], c.n_replicas, c.log_size,
-                 c.max_records, c.max_leader_epoch, lm == KMC_LAYOUT_TIGHT ? "_tight" : lm == KMC_LAYOUT_RM ? "_rm" : "");
+                 c.max_records, c.max_leader_epoch,
+                 lm == KMC_LAYOUT_TIGHT ? "_tight" : lm == KMC_LAYOUT_RM ? "_rm" : lm == KMC_LAYOUT_RMG ? "_rmg" : "");
         *name = buf;
         snprintf(buf, sizeof buf, "KmcKafka<%d,%d,%d,%d,%d,%d>", c.model, c.n_replicas, c.log_size, c.max_records,
                  c.max_leader_epoch, lm);

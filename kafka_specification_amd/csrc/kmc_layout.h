@@ -21,14 +21,19 @@
 // the set is in bijection with this epoch-indexed array.  Unwritten log slots are 0
 // (FiniteReplicatedLog.tla:93,108), so equal states have equal bits.
 //
-// REPLICA-MAJOR (rm = 1) — word r holds everything of replica r at the SAME in-word offsets for every r: the log from
-// bit 0 (alone in the low 32-bit half when it fits there), then end, hw, ep, ldr, isr (from bit 32 when both halves fit);
-// the global fields (nextRecordId ... the requests) go first-fit into the bits the replica words leave free — never
-// straddling a word — and into extra words behind them when those run out.  A field of a replica chosen at RUN TIME is then
-// "select word r, extract at a compile-time offset": what k_expand's kind-major pass 2 needs (kmc_device.h), and no field
-// of any replica straddles a word (or, at the headline's constants, a 32-bit register).  Chosen automatically when a
-// replica's fields fit one word AND the state is no wider than under TIGHT (3 brokers with LogSize 5-6: W = 3 either
-// way); small or many-replica configurations stay TIGHT.  KMC_LAYOUT=tight|rm (host) overrides, for tests.
+// REPLICA-MAJOR (rm = 1, 2) — a replica's log and its small fields (end, hw, ep, ldr, isr: one group) sit at a place that is
+// the same function of the replica index for every replica and never straddle a word, so that a field of a replica chosen
+// at RUN TIME is "select a word, shift by a multiple of a stride, extract at a compile-time offset": what k_expand's
+// kind-major pass 2 needs (kmc_device.h).
+//   rm = 1, one replica per word: word r = log from bit 0 (alone in the low 32-bit half when it fits there), then the small
+//       group (from bit 32 when both halves fit).  No shift at all; at the headline's constants no field of any replica
+//       straddles a 32-bit register.
+//   rm = 2, grouped: the logs packed lg_q per word into the first words, the small groups sm_q per word into the next.
+//       For replicas that are much smaller than a word (5 brokers, LogSize 2: three words either way) or larger than one
+//       (7 brokers, LogSize 8: a 48-bit log and a 21-bit group — 11 words where the tight packing needs 9).
+// The global fields (nextRecordId ... the requests) go first-fit into the bits these words leave free — never straddling a
+// word — and into extra words behind them.  Automatic choice: rm = 1 when it costs no word over TIGHT; else rm = 2 when
+// it costs at most a quarter more; else TIGHT.  KMC_LAYOUT=tight|rm|rmg (host) overrides, for tests and A/B runs.
 //
 // FiniteReplicatedLog standalone: for r: log[r] (L x BK bits, record = 0 Nil | 1..K), then
 // for r: end[r] (BO).   IdSequence standalone: one 64-bit word = nextId.
@@ -75,12 +80,17 @@ KMC_HD constexpr int kmc_bits_for(long long nvalues) {
 
 #define KMC_LAYOUT_AUTO 0   // replica-major when it fits and costs no extra word, else tight
 #define KMC_LAYOUT_TIGHT 1
-#define KMC_LAYOUT_RM 2     // replica-major or invalid
+#define KMC_LAYOUT_RM 2     // replica-major: one replica per word when a replica fits one, else grouped
+#define KMC_LAYOUT_RMG 3    // replica-major, grouped
 
 struct KmcLayout {
     int model, N, L, R, E, K;
-    int rm;                                           // 1: replica-major (Kafka family only)
-    int f_log, f_end, f_hw, f_ep, f_ldr, f_isr;      // rm: in-word offsets of a replica's fields (word r = replica r)
+    int rm;                                           // 0 tight, 1 replica-major one per word, 2 replica-major grouped
+    // rm != 0: the log of replica r is the LB bits at bit (r % lg_q) * lg_stride + lg_base of word lg_word0 + r / lg_q,
+    // its small group (end | hw | ep | ldr | isr, SB bits) at bit (r % sm_q) * sm_stride + sm_base of word sm_word0 + r / sm_q
+    int LB, SB;
+    int lg_q, lg_stride, lg_base, lg_word0, lg_words;
+    int sm_q, sm_stride, sm_base, sm_word0, sm_words;
     int BO, BR, BEr, BId, BE, BL, BI, BNR;  // field widths
     int log_off[KMC_MAXN], end_off[KMC_MAXN], hw_off[KMC_MAXN], ep_off[KMC_MAXN], ldr_off[KMC_MAXN],
         isr_off[KMC_MAXN];
@@ -160,53 +170,82 @@ KMC_HD constexpr KmcLayout kmc_make_layout(int model, int N, int L, int R, int E
     y.bits = pos; y.W = (pos + 63) / 64;
     y.valid = y.W >= 1 && y.W <= KMC_MAXW;
     if (lm == KMC_LAYOUT_TIGHT) return y;
-    // ---- replica-major arrangement of the same fields ----
+    // ---- replica-major arrangements of the same fields ----
     const int logbits = y.BR * L, small = 2 * y.BO + y.BE + y.BL + y.BI;
-    if (logbits + small > 64) {          // a replica does not fit one word
-        if (lm == KMC_LAYOUT_RM) y.valid = 0;
-        return y;
-    }
-    KmcLayout z = y;
-    z.rm = 1;
-    const int small0 = (logbits <= 32 && small <= 32) ? 32 : logbits;
-    z.f_log = 0; z.f_end = small0; z.f_hw = z.f_end + y.BO; z.f_ep = z.f_hw + y.BO; z.f_ldr = z.f_ep + y.BE;
-    z.f_isr = z.f_ldr + y.BL;
-    const int small_end = z.f_isr + y.BI;
-    for (int r = 0; r < N; ++r) {
-        z.log_off[r] = 64 * r + z.f_log; z.end_off[r] = 64 * r + z.f_end; z.hw_off[r] = 64 * r + z.f_hw;
-        z.ep_off[r] = 64 * r + z.f_ep; z.ldr_off[r] = 64 * r + z.f_ldr; z.isr_off[r] = 64 * r + z.f_isr;
-    }
-    // free regions, first the tails of the replica words, then the gaps between a short log and bit 32, then extra words
-    int reg_off[2 * KMC_MAXN + KMC_MAXW] = {}, reg_len[2 * KMC_MAXN + KMC_MAXW] = {};
-    int nreg = 0, words = N;
-    for (int r = 0; r < N; ++r) { reg_off[nreg] = 64 * r + small_end; reg_len[nreg] = 64 - small_end; ++nreg; }
-    if (small0 == 32)
-        for (int r = 0; r < N; ++r) { reg_off[nreg] = 64 * r + logbits; reg_len[nreg] = 32 - logbits; ++nreg; }
-    const int nglob = 5 + 2 * (E + 1);
-    for (int g = 0; g < nglob; ++g) {
-        const int e = (g - 5) / 2;
-        const int bits = g == 0 ? y.BNR : g == 1 ? y.BE : g == 2 ? y.BE : g == 3 ? y.BL : g == 4 ? y.BI
-                         : ((g - 5) % 2 == 0 ? y.BL : y.BI);
-        int at = -1;
-        for (int k = 0; k < nreg && at < 0; ++k)
-            if (reg_len[k] >= bits) { at = reg_off[k]; reg_off[k] += bits; reg_len[k] -= bits; }
-        if (at < 0) {
-            if (words >= KMC_MAXW) { if (lm == KMC_LAYOUT_RM) y.valid = 0; return y; }
-            reg_off[nreg] = 64 * words + bits; reg_len[nreg] = 64 - bits; ++nreg;
-            at = 64 * words; ++words;
+    KmcLayout best = y;
+    int have = 0;
+    for (int form = 1; form <= 2 && !have; ++form) {
+        if (form == 1 && (lm == KMC_LAYOUT_RMG || logbits + small > 64)) continue;   // a replica does not fit one word
+        KmcLayout z = y;
+        z.rm = form; z.LB = logbits; z.SB = small;
+        // free regions for the global fields: the tails of the words holding replica fields (for form 1 also the gap
+        // between a short log and bit 32), then extra words
+        int reg_off[2 * KMC_MAXN + KMC_MAXW] = {}, reg_len[2 * KMC_MAXN + KMC_MAXW] = {};
+        int nreg = 0, words = 0;
+        if (form == 1) {
+            const int small0 = (logbits <= 32 && small <= 32) ? 32 : logbits;
+            z.lg_q = 1; z.lg_stride = 0; z.lg_base = 0; z.lg_word0 = 0; z.lg_words = N;
+            z.sm_q = 1; z.sm_stride = 0; z.sm_base = small0; z.sm_word0 = 0; z.sm_words = N;
+            words = N;
+            for (int r = 0; r < N; ++r) { reg_off[nreg] = 64 * r + small0 + small; reg_len[nreg] = 64 - small0 - small; ++nreg; }
+            if (small0 == 32)
+                for (int r = 0; r < N; ++r) { reg_off[nreg] = 64 * r + logbits; reg_len[nreg] = 32 - logbits; ++nreg; }
+        } else {
+            z.lg_q = 64 / logbits; z.lg_stride = logbits; z.lg_base = 0; z.lg_word0 = 0;
+            z.lg_words = (N + z.lg_q - 1) / z.lg_q;
+            z.sm_q = 64 / small; z.sm_stride = small; z.sm_base = 0; z.sm_word0 = z.lg_words;
+            z.sm_words = (N + z.sm_q - 1) / z.sm_q;
+            words = z.lg_words + z.sm_words;
+            if (words > KMC_MAXW) continue;
+            for (int i = 0; i < z.lg_words; ++i) {
+                const int n = (i + 1) * z.lg_q <= N ? z.lg_q : N - i * z.lg_q;
+                reg_off[nreg] = 64 * i + n * logbits; reg_len[nreg] = 64 - n * logbits; ++nreg;
+            }
+            for (int i = 0; i < z.sm_words; ++i) {
+                const int n = (i + 1) * z.sm_q <= N ? z.sm_q : N - i * z.sm_q;
+                reg_off[nreg] = 64 * (z.sm_word0 + i) + n * small; reg_len[nreg] = 64 - n * small; ++nreg;
+            }
         }
-        if (g == 0) z.nextrec_off = at;
-        else if (g == 1) z.nextep_off = at;
-        else if (g == 2) z.qep_off = at;
-        else if (g == 3) z.qldr_off = at;
-        else if (g == 4) z.qisr_off = at;
-        else if ((g - 5) % 2 == 0) z.reqldr_off[e] = at;
-        else z.reqisr_off[e] = at;
+        for (int r = 0; r < N; ++r) {
+            z.log_off[r] = 64 * (z.lg_word0 + r / z.lg_q) + (r % z.lg_q) * z.lg_stride + z.lg_base;
+            const int so = 64 * (z.sm_word0 + r / z.sm_q) + (r % z.sm_q) * z.sm_stride + z.sm_base;
+            z.end_off[r] = so; z.hw_off[r] = so + y.BO; z.ep_off[r] = so + 2 * y.BO; z.ldr_off[r] = so + 2 * y.BO + y.BE;
+            z.isr_off[r] = so + 2 * y.BO + y.BE + y.BL;
+        }
+        const int nglob = 5 + 2 * (E + 1);
+        bool fits = true;
+        for (int g = 0; g < nglob && fits; ++g) {
+            const int e = (g - 5) / 2;
+            const int bits = g == 0 ? y.BNR : g == 1 ? y.BE : g == 2 ? y.BE : g == 3 ? y.BL : g == 4 ? y.BI
+                             : ((g - 5) % 2 == 0 ? y.BL : y.BI);
+            int at = -1;
+            for (int k = 0; k < nreg && at < 0; ++k)
+                if (reg_len[k] >= bits) { at = reg_off[k]; reg_off[k] += bits; reg_len[k] -= bits; }
+            if (at < 0) {
+                if (words >= KMC_MAXW) { fits = false; break; }
+                reg_off[nreg] = 64 * words + bits; reg_len[nreg] = 64 - bits; ++nreg;
+                at = 64 * words; ++words;
+            }
+            if (g == 0) z.nextrec_off = at;
+            else if (g == 1) z.nextep_off = at;
+            else if (g == 2) z.qep_off = at;
+            else if (g == 3) z.qldr_off = at;
+            else if (g == 4) z.qisr_off = at;
+            else if ((g - 5) % 2 == 0) z.reqldr_off[e] = at;
+            else z.reqisr_off[e] = at;
+        }
+        if (!fits) continue;
+        z.W = words;
+        z.valid = z.W >= 1 && z.W <= KMC_MAXW;
+        if (!z.valid) continue;
+        // the automatic choice: one replica per word when it costs no word over the tight packing, grouped when it costs
+        // at most a quarter more
+        if (lm == KMC_LAYOUT_AUTO && z.W > (form == 1 ? y.W : y.W + (y.W + 3) / 4)) continue;
+        best = z;
+        have = 1;
     }
-    z.W = words;
-    z.valid = z.W >= 1 && z.W <= KMC_MAXW;
-    if (lm == KMC_LAYOUT_AUTO && (z.W > y.W || !z.valid)) return y;
-    return z;
+    if (!have && lm != KMC_LAYOUT_AUTO) best.valid = 0;
+    return best;
 }
 
 // Generic bit-field access on a packed state.  With compile-time `off`/`bits` (the device

@@ -33,6 +33,14 @@ template <class M> int successors(const u64* s, u64* out, int cap) {
 // Kind-major effects (KmcKafka::apply<K>, replica-major layouts) against the instance-major ones (inst<I>) on every
 // enabled binding of one state: same successor words, same `extra`, same kind.  -> checked / bad counts; false when the
 // model has no kind-major form.
+template <class M> constexpr int seg_of_instance(int i) {   // the segment of the kind-major walk that holds instance i
+    for (int sg = 0; sg < M::NSEGS; ++sg) {
+        const int lo = M::kind_base(M::seg_kind(sg)) + M::seg_first(sg);
+        const int left = M::kind_count(M::seg_kind(sg)) - M::seg_first(sg);
+        if (i >= lo && i < lo + (left < M::WINBITS ? left : M::WINBITS)) return sg;
+    }
+    return 0;
+}
 template <class M> bool kind_major_check(const u64* s, int* checked, int* bad) {
     *checked = *bad = 0;
     if constexpr (!M::KIND_MAJOR) {
@@ -45,16 +53,19 @@ template <class M> bool kind_major_check(const u64* s, int* checked, int* bad) {
             int kind = 0;
             u32 extra1 = 0;
             if (!M::template inst<i>(pre, s, t1, kind, extra1)) return;
-            kmc_static_for<0, M::NKINDS>([&](auto KK) {
-                constexpr int k = decltype(KK)::value;
-                if constexpr (i >= M::kind_base(k) && i < M::kind_base(k + 1)) {
-                    u64 t2[M::W];
-                    u32 extra2 = 77;
-                    M::template apply<k>(pre, s, t2, (u32)(i - M::kind_base(k)), extra2);
-                    ++*checked;
-                    if (memcmp(t1, t2, sizeof t1) != 0 || extra1 != extra2 || kind != k) ++*bad;
-                }
-            });
+            // ... through the walk's own decomposition: the segment (kind, window) whose bitset holds instance i, the bit
+            // within it, and apply<kind>(first binding of the window + bit) — what kmc_expand_body does per lane
+            constexpr int sg = seg_of_instance<M>(i);
+            u32 en32[(M::NINST + 31) / 32 + 1] = {};
+            en32[i >> 5] = 1u << (i & 31);
+            const typename M::KindBits km = M::template seg_bits<sg>(en32);
+            const u32 b = km == 0 ? 0u : sizeof(km) == 8 ? (u32)__builtin_ctzll((u64)km) : (u32)__builtin_ctz((u32)km);
+            u64 t2[M::W];
+            u32 extra2 = 77;
+            M::template apply<M::seg_kind(sg)>(pre, s, t2, b + (u32)M::seg_first(sg), extra2);
+            ++*checked;
+            if (km == 0 || (km & (km - 1)) != 0 || memcmp(t1, t2, sizeof t1) != 0 || extra1 != extra2 || kind != M::seg_kind(sg))
+                ++*bad;
         });
         return true;
     }
@@ -121,6 +132,12 @@ const Entry TABLE[] = {
     KAFKA_LM(KMC_MODEL_KIP320, 4, 2, 2, 1, KMC_LAYOUT_RM), KAFKA_LM(KMC_MODEL_KIP279, 5, 1, 1, 1, KMC_LAYOUT_RM),
     KAFKA_LM(KMC_MODEL_KIP101, 4, 2, 1, 2, KMC_LAYOUT_RM), KAFKA_LM(KMC_MODEL_KIP320, 7, 1, 1, 0, KMC_LAYOUT_RM),
     KAFKA_LM(KMC_MODEL_KIP320_FIRST_TRY, 8, 1, 1, 0, KMC_LAYOUT_RM), KAFKA_LM(KMC_MODEL_KIP320, 2, 3, 2, 3, KMC_LAYOUT_RM),
+    // ... and the grouped form (several logs / small groups per word): forced at the headline's constants, and where one
+    // replica per word is not possible or not chosen
+    KAFKA_LM(KMC_MODEL_KIP320, 3, 6, 6, 2, KMC_LAYOUT_RMG), KAFKA_LM(KMC_MODEL_KIP279, 3, 5, 5, 2, KMC_LAYOUT_RMG),
+    KAFKA_LM(KMC_MODEL_KIP101, 3, 2, 2, 2, KMC_LAYOUT_RMG), KAFKA_LM(KMC_MODEL_KIP320_FIRST_TRY, 3, 2, 2, 2, KMC_LAYOUT_RMG),
+    KAFKA_LM(KMC_MODEL_TRUNCATE_TO_HW, 6, 1, 1, 1, KMC_LAYOUT_RMG), KAFKA_LM(KMC_MODEL_KIP279, 7, 1, 1, 0, KMC_LAYOUT_RMG),
+    KAFKA(KMC_MODEL_KIP279, 5, 2, 2, 1), KAFKA(KMC_MODEL_KIP320, 7, 8, 8, 3),
     ASYNC(3, 2, 2), ASYNC(4, 2, 2), ASYNC(2, 3, 7), ASYNC(1, 4, 0),
     FRL(2, 4, 2), FRL(3, 2, 2),
 };

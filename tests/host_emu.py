@@ -39,7 +39,7 @@ def lib():
     return _lib
 
 
-LAYOUT_ENV = {0: "auto", 1: "tight", 2: "rm"}   # KMC_LAYOUT_* -> the KMC_LAYOUT value that makes the host library agree
+LAYOUT_ENV = {0: "auto", 1: "tight", 2: "rm", 3: "rmg"}   # KMC_LAYOUT_* -> the KMC_LAYOUT value that makes the host library agree
 
 
 def configs():

@@ -13,7 +13,7 @@ CONFIGS = host_emu.configs()
 
 
 def _ids(c):
-    return f"{MODEL_NAMES[c[0]]}-{c[1]}-{c[2]}-{c[3]}-{c[4]}-{c[5]}" + ("", "-tight", "-rm")[c[6]]
+    return f"{MODEL_NAMES[c[0]]}-{c[1]}-{c[2]}-{c[3]}-{c[4]}-{c[5]}" + ("", "-tight", "-rm", "-rmg")[c[6]]
 
 
 @pytest.fixture(autouse=True)
@@ -175,8 +175,16 @@ def test_kind_major_effects_equal_the_instance_major_ones(cfg6):
     assert total > 500
 
 
-def test_the_headline_is_replica_major_and_small_configurations_stay_tight():
-    """The automatic choice (kmc_layout.h): replica-major where a replica's fields fill most of a word anyway."""
-    rm = {(_c[0], _c[1], _c[2], _c[3], _c[4]) for _c in RM_CONFIGS if _c[6] == 0}
-    assert (kmo.MODELS["Kip320"], 3, 6, 6, 2) in rm
-    assert (kmo.MODELS["Kip320"], 3, 2, 2, 2) not in rm and (kmo.MODELS["Kip320"], 7, 1, 1, 0) not in rm
+def test_the_automatic_layout_choice():
+    """kmc_layout.h: one replica per word where that costs no word over the tight packing (the headline), grouped
+    replica-major elsewhere (BASELINE configs 4 and 5, the small configurations of the parity tests); the tight packing —
+    and with it k_expand's instance-major walk — only when asked for."""
+    def form(model, N, L, R, E, lm=0):
+        host_emu.lib().emu_layout(lm)
+        try:
+            return host_emu.lib().emu_is_rm(kmo.MODELS[model], N, L, R, E)
+        finally:
+            host_emu.lib().emu_layout(0)
+    assert form("Kip320", 3, 6, 6, 2) == 1 and form("Kip320", 3, 5, 5, 2) == 1
+    assert form("Kip279", 5, 2, 2, 1) == 2 and form("Kip320", 7, 8, 8, 3) == 2 and form("Kip320", 3, 2, 2, 2) == 2
+    assert form("Kip320", 3, 6, 6, 2, 1) == 0 and form("Kip320", 3, 6, 6, 2, 3) == 2 and form("Kip320", 3, 2, 2, 2, 2) == 1

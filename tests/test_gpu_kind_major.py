@@ -1,8 +1,12 @@
-"""The two walks of k_expand's pass 2 (csrc/kmc_device.h), each forced onto the configurations the other one gets by
-default: the KIND-MAJOR walk (replica-major layout, KmcKafka::apply<K> with the binding chosen per lane at run time; the
-automatic choice at the headline's constants) on the small configurations whose every level the oracle holds as an exact
-set, and the INSTANCE-MAJOR walk (tight layout, inst<I>) on two of the large golden counts.  KMC_LAYOUT=rm / tight, read
-when a handle is opened."""
+"""The two walks of k_expand's pass 2 (csrc/kmc_device.h) and the layouts of the state vector behind them
+(csrc/kmc_layout.h), each forced onto configurations that get another one by default (KMC_LAYOUT, read when a handle is
+opened):
+  * the KIND-MAJOR walk (KmcKafka::apply<K>, the binding chosen per lane at run time) on the ONE-REPLICA-PER-WORD layout —
+    the automatic choice at the headline's constants — forced (rm) onto small configurations whose every level the oracle
+    holds as an exact set; on the GROUPED layout — what every other Kafka configuration gets, so the rest of the -m gpu
+    suite runs it — forced (rmg) onto a large golden count;
+  * the INSTANCE-MAJOR walk (tight layout, inst<I>; nobody's default any more) forced (tight) onto small configurations
+    with exact level sets and onto two large golden counts."""
 import json
 import os
 
@@ -11,7 +15,7 @@ import pytest
 import kmo
 from kafka_specification_amd import CheckerConfig, ModelChecker
 from kafka_specification_amd.sharded import check_loopback
-from kafka_specification_amd.configs import INSTANCE_MAJOR_LARGE, KAFKA, KIND_MAJOR_SMALL
+from kafka_specification_amd.configs import GROUPED_LARGE, INSTANCE_MAJOR_LARGE, INSTANCE_MAJOR_SMALL, KAFKA, KIND_MAJOR_SMALL
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -37,9 +41,9 @@ def run(model, N, L, R, E, invariants=("TypeOk",), keep_levels=False, **kw):
     return res, level_sets, trace
 
 
-@pytest.mark.parametrize("model,N,L,R,E", KIND_MAJOR_SMALL)
-def test_kind_major_walk_levels_are_the_oracles_sets(layout, model, N, L, R, E):
-    layout("rm")
+@pytest.mark.parametrize("model,N,L,R,E,mode", [t + ("rm",) for t in KIND_MAJOR_SMALL] + [t + ("tight",) for t in INSTANCE_MAJOR_SMALL])
+def test_forced_walk_levels_are_the_oracles_sets(layout, model, N, L, R, E, mode):
+    layout(mode)
     inv = ("TypeOk", "WeakIsr", "StrongIsr")
     o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=(), threads=4))
     res, level_sets, _ = run(model, N, L, R, E, invariants=(), keep_levels=True, table_capacity=1 << 24, frontier_capacity=1 << 22)
@@ -56,17 +60,17 @@ def test_kind_major_walk_levels_are_the_oracles_sets(layout, model, N, L, R, E):
 
 
 def test_kind_major_walk_is_what_the_headline_constants_get(layout):
-    """No override: 3 brokers with LogSize 6 is replica-major — forcing `rm` changes nothing there — while forcing `tight`
-    packs the same fields differently; both are 3 words."""
+    """No override: 3 brokers with LogSize 6 is one replica per word — forcing `rm` changes nothing there — while `tight`
+    and `rmg` pack the same fields differently; all are 3 words."""
     consts = dict(model="Kip320", device=-1, n_replicas=3, log_size=6, max_records=6, max_leader_epoch=2)
     s = kmo.Run(kmo.make_config("Kip320", N=3, L=6, R=6, E=2, invariants=(), max_states=2000, threads=1)).state(1500)
     packed = {}
-    for mode in ("auto", "rm", "tight"):
+    for mode in ("auto", "rm", "tight", "rmg"):
         layout(mode)
         with ModelChecker(CheckerConfig(**consts)) as mc:
             assert mc.state_words == 3 and mc.unpack(mc.pack(s)) == s
             packed[mode] = tuple(mc.pack(s))
-    assert packed["auto"] == packed["rm"] != packed["tight"]
+    assert packed["auto"] == packed["rm"] and len({packed["rm"], packed["tight"], packed["rmg"]}) == 3
 
 
 @pytest.mark.parametrize("model", ["Kip279", "KafkaTruncateToHighWatermark"])
@@ -94,9 +98,9 @@ def test_kind_major_walk_traces_and_sharding(layout, model):
     assert (rs.distinct, rs.generated, rs.levels) == (of.distinct, of.generated, of.levels)
 
 
-@pytest.mark.parametrize("model,N,L,R,E", INSTANCE_MAJOR_LARGE)
-def test_instance_major_walk_on_a_large_golden_count(layout, model, N, L, R, E):
-    layout("tight")
+@pytest.mark.parametrize("model,N,L,R,E,mode", [t + ("tight",) for t in INSTANCE_MAJOR_LARGE] + [t + ("rmg",) for t in GROUPED_LARGE])
+def test_forced_walk_on_a_large_golden_count(layout, model, N, L, R, E, mode):
+    layout(mode)
     name = {"Kip320": "oracle_kip320_3_5_5_2.json", "Kip279": "oracle_kip279_3_5_5_2.json"}[model]
     g = json.load(open(os.path.join(HERE, "golden", name)))
     inv = ("TypeOk", "WeakIsr", "StrongIsr") if model == "Kip320" else ("TypeOk",)

@@ -59,7 +59,7 @@ def test_async_isr_constraint_through_the_native_exchange():
 
 def test_baseline_config5_seven_brokers_through_the_native_exchange_with_eight_ranks():
     """BASELINE.json config 5 at its own constants (models/Kip320_7brokers.cfg: 7 brokers, LogSize 8, MaxRecords 8,
-    MaxLeaderEpoch 3 — 9-word states, 10-word records because the predecessor fingerprint travels too) over 8 concurrent
+    MaxLeaderEpoch 3 — 10-word states, 11-word records because the predecessor fingerprint travels too) over 8 concurrent
     ranks: the first 7 BFS levels (1.27 M states; nothing exhausts this configuration) equal the oracle's prefix in level
     sizes and per-action generated counts, identically on every rank."""
     out = _run("Kip320", 7, 8, 8, 3, 8, "TypeOk", "trace", "levels=7")

@@ -469,7 +469,7 @@ def test_sharded_checkpoint_and_recover(tmp_path, P):
 
 
 def test_baseline_config5_seven_brokers_on_eight_logical_shards():
-    """BASELINE.json config 5 (Kip320, 7 brokers, LogSize 8, MaxRecords 8, MaxLeaderEpoch 3: W = 9 words, 10-word exchange
+    """BASELINE.json config 5 (Kip320, 7 brokers, LogSize 8, MaxRecords 8, MaxLeaderEpoch 3: W = 10 words (grouped replica-major layout), 11-word exchange
     records with keep_trace) through the exchange under the ABI on P = 8 logical shards of one GPU.  The configuration is
     not exhaustible (8.8e8 states after 11 levels), so the pin is the oracle's prefix: the sizes of the first 7 levels,
     per-action generated counts, and the exact state SETS of the levels up to 50 k states, gathered over the shards."""
@@ -483,7 +483,7 @@ def test_baseline_config5_seven_brokers_on_eight_logical_shards():
     engines = [HipShardEngine(cfg, s, P, 0, native=True) for s in range(P)]
     sets = {}
     try:
-        assert engines[0].record_words == 10 and engines[0].W == 9
+        assert engines[0].record_words == 11 and engines[0].W == 10
 
         def level_done(info):      # the shards still hold the level just recorded (its expansion is in flight, not finished)
             if info["new_states"] <= 50_000:
