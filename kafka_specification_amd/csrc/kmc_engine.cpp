@@ -1551,9 +1551,11 @@ int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap
 // predecessor table when traces are kept) and the current frontier's planes, segment by segment.
 namespace {
 struct CkptHeader {
-    char magic[8];          // "KMCCKPT2"
+    char magic[8];          // "KMCCKPT3"
     kmc_config cfg;         // pointers inside are not meaningful in the file
     uint64_t table_cap, fcap, seg_cap, level, n_cur, n_levels, w, has_pred;
+    uint64_t layout_form;   // KmcLayout::rm of the packed states in the file (0 tight, 1 / 2 replica-major): the same constants
+                            // can be packed in more than one way (KMC_LAYOUT), often into the same number of words
 };
 bool wr(FILE* f, const void* p, size_t n) { return fwrite(p, 1, n, f) == n; }
 bool rd(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n; }
@@ -1599,11 +1601,12 @@ int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     FILE* f = fopen(path, "wb");
     if (!f) return fail(KMC_E_ARG, "cannot open %s for writing", path);
     CkptHeader hd{};
-    memcpy(hd.magic, "KMCCKPT2", 8);
+    memcpy(hd.magic, "KMCCKPT3", 8);
     hd.cfg = h->cfg;
     hd.cfg.cache_dir = nullptr;
     hd.table_cap = h->table_cap; hd.fcap = h->fcap; hd.seg_cap = h->seg_cap; hd.level = h->level;
     hd.n_cur = h->n_cur; hd.n_levels = h->levels.size(); hd.w = h->W; hd.has_pred = h->pred != nullptr;
+    hd.layout_form = (uint64_t)h->lay.rm;
     int rc = KMC_OK;
     bool ok = wr(f, &hd, sizeof hd) && wr(f, &h->res, sizeof h->res) && wr(f, h->levels.data(), h->levels.size() * 8) &&
               wr(f, h->seg_n, sizeof h->seg_n) && wr(f, h->init_words.data(), h->W * 8);
@@ -1626,15 +1629,17 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
     if (!f) return fail(KMC_E_ARG, "cannot open %s", path);
     CkptHeader hd{};
     int rc = KMC_OK;
-    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT2", 8) != 0) rc = fail(KMC_E_ARG, "%s is not a checkpoint", path);
+    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT3", 8) != 0)
+        rc = fail(KMC_E_ARG, "%s is not a checkpoint of this version", path);
     const kmc_config& a = hd.cfg;
     const kmc_config& b = h->cfg;
     if (!rc && (a.model != b.model || a.n_replicas != b.n_replicas || a.log_size != b.log_size ||
                 a.max_records != b.max_records || a.max_leader_epoch != b.max_leader_epoch ||
                 a.n_log_records != b.n_log_records || a.max_id != b.max_id || a.hash_seed != b.hash_seed ||
                 a.n_shards != b.n_shards || a.shard_id != b.shard_id || hd.w != (uint64_t)h->W ||
-                (a.wide_fingerprint != 0) != (b.wide_fingerprint != 0)))
-        rc = fail(KMC_E_ARG, "checkpoint was taken for a different model / constants / hash seed / shard / fingerprint width");
+                hd.layout_form != (uint64_t)h->lay.rm || (a.wide_fingerprint != 0) != (b.wide_fingerprint != 0)))
+        rc = fail(KMC_E_ARG, "checkpoint was taken for a different model / constants / hash seed / shard / fingerprint width / "
+                             "state layout");
     if (!rc && (hd.table_cap != h->table_cap || hd.fcap != h->fcap || hd.seg_cap != h->seg_cap ||
                 hd.has_pred != (uint64_t)(h->pred != nullptr)))
         rc = fail(KMC_E_ARG, "checkpoint capacities differ: open the handle with table_capacity=%llu frontier_capacity=%llu keep_trace=%d",

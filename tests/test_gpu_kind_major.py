@@ -107,3 +107,28 @@ def test_forced_walk_on_a_large_golden_count(layout, model, N, L, R, E, mode):
     res, _, _ = run(model, N, L, R, E, invariants=inv, table_capacity=1 << 29, frontier_capacity=1 << 26)
     assert (res.distinct, res.generated, res.depth) == (g["distinct"], g["generated"], g["depth"])
     assert res.levels == g["levels"]
+
+
+def test_a_checkpoint_is_refused_under_another_layout(layout, tmp_path):
+    """The same constants pack into the same number of words in more than one way: the checkpoint header records the
+    arrangement, and a handle opened under another one refuses the file instead of reading garbage states."""
+    from kafka_specification_amd import KmcError
+    base = dict(model="Kip320", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=2, invariants=("TypeOk",),
+                table_capacity=1 << 22, frontier_capacity=1 << 20)
+    path = str(tmp_path / "k.ckpt")
+    o = kmo.Run(kmo.make_config("Kip320", N=3, L=2, R=2, E=2, invariants=("TypeOk",)))
+    layout("auto")      # grouped replica-major at these constants: 2 words, like the tight packing
+    with ModelChecker(CheckerConfig(**base, max_levels=6)) as mc:
+        assert mc.run().verdict == "level_limit"
+        mc.save_checkpoint(path)
+        words = mc.state_words
+    layout("tight")
+    with ModelChecker(CheckerConfig(**base)) as mc:
+        assert mc.state_words == words == 2
+        with pytest.raises(KmcError, match="state layout"):
+            mc.load_checkpoint(path)
+    layout("auto")
+    with ModelChecker(CheckerConfig(**base)) as mc:
+        mc.load_checkpoint(path)
+        r = mc.resume()
+    assert (r.verdict, r.distinct, r.generated, r.levels) == (o.verdict, o.distinct, o.generated, o.levels)
