@@ -145,6 +145,16 @@ typedef unsigned int u32;
                           //    successor in lane 5 between the ring and the seen-set — the failure class of round 1's miscompiled
                           //    kernel.  The conservation check (generated = probed) and KMC_VERIFY's checksum must both catch it
 #endif
+#ifndef KMC_RT_GUARDS_MIN_INSTANCES
+#define KMC_RT_GUARDS_MIN_INSTANCES 1000000   // Kafka configurations with MORE action instances than this evaluate their guards
+                                          // in per-kind loops over a run-time binding (KmcKafka::guard<K>) instead of one
+                                          // straight-line block of every instance's guard (inst<I>).  Off by default: the
+                                          // loops compile in seconds where the block takes minutes at 7 brokers, but they run
+                                          // slower everywhere (headline 38.9 ms against 31.8, config 5's first ten levels 61
+                                          // against 29: profiles/r03_runtime_guards.txt) — the block shares its sub-terms
+                                          // across instances, a loop cannot.  KMC_VERIFY's second build sets it to 0: its
+                                          // guards are then a second, independent lowering (kmc_engine.cpp)
+#endif
 #ifndef KMC_PREFETCH
 #define KMC_PREFETCH 0    // 1: request the next tile's state words while the current tile is processed (measured: no gain)
 #endif
@@ -327,7 +337,7 @@ KMC_HD inline u32 kmc_owner(u64 fp, u32 nshards) { return (u32)((((fp >> 40) & 0
 // ========================================================================================
 template <long long MAXID> struct KmcIdSequence {
     static constexpr int W = 1, NKINDS = 1, NINST = 1;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false, RUNTIME_GUARDS = false;
     struct Pre { u64 nextId; };
     static KMC_DEV void init(u64* w) { w[0] = 0; }  // IdSequence.tla:37
     static KMC_DEV Pre extract(const u64* s) { return Pre{s[0]}; }
@@ -351,7 +361,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
     static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_FINITE_REPLICATED_LOG, N, L, 0, 0, K);
     static_assert(Y.valid, "FiniteReplicatedLog parameters cannot be packed");
     static constexpr int W = Y.W, NKINDS = 3;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false, RUNTIME_GUARDS = false;
     static constexpr int C_APPEND = N * K, C_TRUNC = N * L, C_REPL = N * (N - 1);
     static constexpr int NINST = C_APPEND + C_TRUNC + C_REPL;
     static constexpr u64 MR = (1ull << Y.BR) - 1;
@@ -426,7 +436,7 @@ template <int N, int MO, int V> struct KmcAsyncIsr {
     static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_ASYNC_ISR, N, MO, 0, V, 0);
     static_assert(Y.valid, "AsyncIsr parameters cannot be packed (need N <= 6, MaxVersion <= 7)");
     static constexpr int W = Y.W, NKINDS = 7;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = true, KIND_MAJOR = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = true, KIND_MAJOR = false, RUNTIME_GUARDS = false;
     static constexpr int NS = 1 << N;  // isr masks = request bits per version
     // Next (AsyncIsr.tla:152-159) flattened into instances, one per binding of each disjunct's \E
     static constexpr int B0 = 0;             // ControllerShrinkIsr        (replica # Leader)
@@ -703,20 +713,26 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         return p.hw(l) == p.end(l) ||
                (p.hw(l) < p.end(l) && rec_epoch(rec_at(p.logv(l), p.hw(l))) + 1 == p.ep1(l));
     }
-    // IsFollowerCaughtUpToLeaderEpoch (Kip320FirstTry.tla:49-57)
-    template <int l, int f> static KMC_DEV bool caught_up_epoch(const Pre& p, u32 endOffset) {
-        if (!(presumes<l>(p) && p.ldr1(f) == (u32)(l + 1))) return false;
+    // IsFollowerCaughtUpToLeaderEpoch (Kip320FirstTry.tla:49-57), on values (`following` = the leader presumes leadership
+    // and the follower names it); the <l, f> form is what the instance-major guards use, the value form the run-time ones
+    static KMC_DEV bool caught_up_epoch_v(bool following, LogT log_l, LogT log_f, u32 end_l, u32 end_f, u32 endOffset) {
+        if (!following) return false;
         if (endOffset == 0) return true;
         const u32 o = endOffset - 1;
-        return o < p.end(l) && o < p.end(f) &&
-               rec_epoch(rec_at(p.logv(f), o)) == rec_epoch(rec_at(p.logv(l), o));
+        return o < end_l && o < end_f && rec_epoch(rec_at(log_f, o)) == rec_epoch(rec_at(log_l, o));
+    }
+    template <int l, int f> static KMC_DEV bool caught_up_epoch(const Pre& p, u32 endOffset) {
+        return caught_up_epoch_v(presumes<l>(p) && p.ldr1(f) == (u32)(l + 1), p.logv(l), p.logv(f), p.end(l), p.end(f), endOffset);
     }
     // FollowerNeedsTruncation (Kip320FirstTry.tla:64-69)
+    static KMC_DEV bool needs_truncation_v(LogT log_f, LogT log_l, u32 end_f, u32 end_l) {
+        if (end_f > end_l) return true;
+        if (end_f == 0) return false;
+        const u32 o = end_f - 1;
+        return o < end_l && rec_epoch(rec_at(log_l, o)) != rec_epoch(rec_at(log_f, o));
+    }
     template <int f, int l> static KMC_DEV bool needs_truncation(const Pre& p) {
-        if (p.end(f) > p.end(l)) return true;
-        if (p.end(f) == 0) return false;
-        const u32 o = p.end(f) - 1;
-        return o < p.end(l) && rec_epoch(rec_at(p.logv(l), o)) != rec_epoch(rec_at(p.logv(f), o));
+        return needs_truncation_v(p.logv(f), p.logv(l), p.end(f), p.end(l));
     }
     // FirstNonMatchingOffsetFromTail(leader, follower) (Kip279.tla:27-45), on the two logs and end offsets as values
     // (shared by the instance-major effects, where leader and follower are compile-time, and the kind-major ones below)
@@ -978,6 +994,10 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         }
         return 0;
     }
+    static constexpr int seg_count(int sg) {   // bindings in segment sg
+        const int left = kind_count(seg_kind(sg)) - seg_first(sg);
+        return left < WINBITS ? left : WINBITS;
+    }
     // the segment's bits of the per-lane "enabled instances" bitset en32[] (32-bit words), as one value
     template <int SG> static KMC_DEV KindBits seg_bits(const u32* en32) {
         constexpr int K = seg_kind(SG), first = seg_first(SG);
@@ -1032,6 +1052,7 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         KMC_DEV u32 end() const { return (sm >> O_END) & ((1u << Y.BO) - 1u); }
         KMC_DEV u32 hw() const { return (sm >> O_HW) & ((1u << Y.BO) - 1u); }
         KMC_DEV u32 ep1() const { return (sm >> O_EP) & ((1u << Y.BE) - 1u); }
+        KMC_DEV u32 ldr1() const { return (sm >> O_LDR) & ((1u << Y.BL) - 1u); }
         KMC_DEV u32 isr() const { return (sm >> O_ISR) & ((1u << Y.BI) - 1u); }
         KMC_DEV void set(int off, int bits, u32 val) {
             const u32 m = ((1u << bits) - 1u) << off;
@@ -1102,6 +1123,137 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         l = j / (u32)(N - 1);
         const u32 q = j % (u32)(N - 1);
         r = q + (q >= l ? 1u : 0u);
+    }
+
+    // The leader named by the request with leader epoch e (run-time e), as index + 1
+    static KMC_DEV u32 rldr1_rt(const Pre& p, u32 e) {
+        u32 v = p.rldr1(0);
+        kmc_static_for<1, E + 1>([&](auto EE) {
+            constexpr int k = decltype(EE)::value;
+            v = e == (u32)k ? p.rldr1(k) : v;
+        });
+        return v;
+    }
+    // The GUARD of binding b of kind K (0 / 1), b a run-time value: what inst<kind_base(K) + b> returns.  A second lowering
+    // of the guards, used by KMC_VERIFY's second build (RUNTIME_GUARDS: a loop of guard<K> over a kind's bindings, b
+    // wave-uniform, fused into pass 2's walk; O(kinds) code that compiles in seconds — and runs 20-110 % slower than the
+    // straight-line block of every instance's guard, which shares sub-terms across instances: KMC_RT_GUARDS_MIN_INSTANCES).
+    // The expressions are inst<I>'s, line by line; tests/host_emu.cpp compares the two on EVERY binding (enabled or not)
+    // of every visited state.
+    static constexpr bool RUNTIME_GUARDS = KIND_MAJOR && NINST > KMC_RT_GUARDS_MIN_INSTANCES;
+    template <int K> static KMC_DEV u32 guard(const Pre& p, const u64* s, u32 b) {
+        if constexpr (K == 0) {
+            // ControllerElectLeader (KafkaReplication.tla:176-179)
+            return p.epok & ((p.qisr() >> b) & 1u) & (p.qldr1() != b + 1u ? 1u : 0u);
+        } else if constexpr (K == 1) {
+            // ControllerShrinkIsr (:158-168)
+            return p.epok & ((p.qldr1() == b + 1u || ((p.qisr() >> b) & 1u)) ? 1u : 0u);
+        } else if constexpr (K == 2) {
+            // BecomeLeader (:186-195)
+            const u32 e = b / (u32)N, l = b % (u32)N;
+            return (rldr1_rt(p, e) == l + 1u && e < p.nextEp() && e + 1u > (get_small(s, l) >> O_EP & ((1u << Y.BE) - 1u))) ? 1u : 0u;
+        } else if constexpr (K == 3) {
+            const u32 l = b / (u32)N, r = b % (u32)N;
+            const Rep vl = get_rep(s, l), vr = get_rep(s, r);
+            u32 g = ((p.tm >> l) & 1u) & ((~vl.isr() >> r) & 1u);
+            if constexpr (K320) {  // FencedLeaderExpandIsr (Kip320.tla:110-117)
+                g &= (u32)(p.fm >> (l * (u32)N + r)) & 1u & (p.hm >> l);
+                g &= vl.hw() <= vr.end() ? 1u : 0u;
+            } else if constexpr (FIRST) {  // LeaderExpandIsrBetterFencing (Kip320FirstTry.tla:134-141)
+                g &= (p.hm >> l) & 1u;
+                g &= caught_up_epoch_v(((p.pm >> l) & 1u) && vr.ldr1() == l + 1u, vl.log, vr.log, vl.end(), vr.end(), vl.hw()) ? 1u : 0u;
+            } else {  // LeaderExpandIsr (KafkaReplication.tla:248-254)
+                g &= (vr.ldr1() == l + 1u && vl.hw() <= vl.end() && vl.hw() <= vr.end()) ? 1u : 0u;
+            }
+            return g;
+        } else if constexpr (K == 4) {
+            u32 l, r;
+            pair_of(b, l, r);
+            const Rep vl = get_rep(s, l), vr = get_rep(s, r);
+            u32 g = ((p.tm >> l) & 1u) & ((vl.isr() >> r) & 1u);
+            if constexpr (K320) {  // FencedLeaderShrinkIsr (Kip320.tla:78-85)
+                g &= ((((u32)(p.fm >> (l * (u32)N + r)) & 1u) == 0u) || vr.end() < vl.end()) ? 1u : 0u;
+            } else if constexpr (FIRST) {  // LeaderShrinkIsrBetterFencing (Kip320FirstTry.tla:114-120)
+                g &= !caught_up_epoch_v(((p.pm >> l) & 1u) && vr.ldr1() == l + 1u, vl.log, vr.log, vl.end(), vr.end(), vl.end()) ? 1u : 0u;
+            } else {  // LeaderShrinkIsr (KafkaReplication.tla:233-239); IsFollowerCaughtUp :219-225
+                g &= !(vr.ldr1() == l + 1u && vl.end() <= vl.end() && vl.end() <= vr.end()) ? 1u : 0u;
+            }
+            return g;
+        } else if constexpr (K == 5) {
+            // LeaderWrite (:202-207)
+            const u32 end = get_small(s, b) & ((1u << Y.BO) - 1u);
+            return ((p.pm >> b) & 1u) & ((p.nextRec() <= (u32)(R - 1) && end < (u32)L) ? 1u : 0u);
+        } else if constexpr (K == 6) {
+            const u32 l = b;
+            const Rep vl = get_rep(s, l);
+            const u32 hw = vl.hw(), isr = vl.isr();
+            u32 g;
+            if constexpr (K320) {  // FencedLeaderIncHighWatermark (Kip320.tla:63-70)
+                g = hw < vl.end() ? 1u : 0u;
+                kmc_static_for<0, N>([&](auto F) {
+                    constexpr int f = decltype(F)::value;
+                    const u32 in = (isr >> f) & 1u;
+                    g &= (in ^ 1u) | ((u32)(p.fm >> (l * (u32)N + (u32)f)) & 1u);
+                    g &= (in == 0u || hw < p.end(f)) ? 1u : 0u;
+                });
+            } else if constexpr (FIRST) {  // ImprovedLeaderIncHighWatermark (Kip320FirstTry.tla:90-97)
+                g = ((p.pm >> l) & 1u) & (hw < vl.end() ? 1u : 0u);
+                kmc_static_for<0, N>([&](auto F) {
+                    constexpr int f = decltype(F)::value;
+                    const bool following = ((p.pm >> l) & 1u) && p.ldr1(f) == l + 1u;
+                    g &= (!((isr >> f) & 1u) || caught_up_epoch_v(following, vl.log, p.logv(f), vl.end(), p.end(f), hw + 1u)) ? 1u : 0u;
+                });
+            } else {  // LeaderIncHighWatermark (KafkaReplication.tla:264-271)
+                g = ((p.pm >> l) & 1u) & (hw <= (u32)(L - 1) ? 1u : 0u);
+                kmc_static_for<0, N>([&](auto F) {
+                    constexpr int f = decltype(F)::value;
+                    g &= (!((isr >> f) & 1u) || (p.ldr1(f) == l + 1u && hw < p.end(f))) ? 1u : 0u;
+                });
+            }
+            return g;
+        } else if constexpr (K == 7) {
+            const u32 pr = b / (u32)(E + 1), e = b % (u32)(E + 1);
+            u32 l, r;
+            pair_of(pr, l, r);
+            const Rep vr = get_rep(s, r);
+            u32 g = (rldr1_rt(p, e) == l + 1u && e < p.nextEp() && e + 1u > vr.ep1()) ? 1u : 0u;
+            if constexpr (!FIRST) {
+                u32 off;
+                if constexpr (MODEL == KMC_MODEL_TRUNCATE_TO_HW) {
+                    off = vr.hw();
+                } else {
+                    const Rep vl = get_rep(s, l);
+                    if constexpr (MODEL == KMC_MODEL_KIP101) {
+                        const u32 er = vr.end();
+                        const u32 last_epoch = rec_epoch(rec_at(vr.log, er == 0 ? 0u : er - 1u));
+                        off = er == 0 ? 0u : lookup_offset_for_epoch_v(vl.log, vl.end(), vr.hw(), last_epoch);
+                    } else {
+                        off = first_non_matching_v(vl.log, vr.log, vl.end(), vr.end());
+                        if constexpr (K320) g &= ((p.pm >> l) & 1u) & (vl.ep1() == e + 1u ? 1u : 0u);
+                    }
+                }
+                g &= off <= vr.end() ? 1u : 0u;  // TruncateTo is disabled, not clamped (FiniteReplicatedLog.tla:106)
+            }
+            return g;
+        } else if constexpr (K == 8) {
+            u32 l, f;
+            pair_of(b, l, f);
+            const Rep vl = get_rep(s, l), vf = get_rep(s, f);
+            const u32 ef = vf.end();
+            u32 g = (ef < vl.end() && ef < (u32)L) ? 1u : 0u;
+            if constexpr (K320) g &= (u32)(p.fm >> (l * (u32)N + f)) & 1u;
+            else if constexpr (FIRST) g &= caught_up_epoch_v(((p.pm >> l) & 1u) && vf.ldr1() == l + 1u, vl.log, vf.log, vl.end(), vf.end(), ef) ? 1u : 0u;
+            else g &= ((p.pm >> l) & 1u) & (vf.ldr1() == l + 1u ? 1u : 0u);
+            return g;
+        } else {
+            // FollowerTruncate (Kip320FirstTry.tla:75-82)
+            u32 l, f;
+            pair_of(b, l, f);
+            const Rep vl = get_rep(s, l), vf = get_rep(s, f);
+            const u32 off = first_non_matching_v(vl.log, vf.log, vl.end(), vf.end());
+            return (((p.pm >> l) & 1u) && vf.ldr1() == l + 1u && needs_truncation_v(vf.log, vl.log, vf.end(), vl.end()) &&
+                    off <= vf.end()) ? 1u : 0u;
+        }
     }
 
     // The effect of binding b of kind K on s -> t.  The successor and `extra` equal inst<kind_base(K) + b>'s.
@@ -1836,6 +1988,8 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #pragma unroll
         for (int h = 0; h < 2 * NW; ++h) en32[h] = 0;
         const u32 valid01 = valid ? 1u : 0u;
+        u32 nsucc = 0;
+        if constexpr (!M::RUNTIME_GUARDS) {   // (the wide Kafka configurations evaluate their guards per kind, in pass 2's walk)
         kmc_static_for<0, M::NINST>([&](auto I) {
             constexpr int i = decltype(I)::value;
             u64 tt[W];
@@ -1845,9 +1999,9 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             en32[i >> 5] |= g01 << (i & 31);
             kmc_launder(en32[i >> 5]);  // keep the OR chain sequential (a reassociated tree keeps every leaf live)
         });
-        u32 nsucc = 0;
 #pragma unroll
         for (int h = 0; h < 2 * NW; ++h) nsucc += __popc(en32[h]);
+        }
 
         KMC_T(tp2);
         KMC_TADD(1, tp1, tp2);
@@ -1866,8 +2020,24 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             typename M::KindBits km = 0;
             int k = 0;   // the segment's action kind (wave-uniform)
             kmc_dispatch<0, M::NSEGS>(sgi, [&](auto SS) {
-                km = M::template seg_bits<decltype(SS)::value>(en32);
-                k = M::seg_kind(decltype(SS)::value);
+                constexpr int sg = decltype(SS)::value;
+                k = M::seg_kind(sg);
+                if constexpr (M::RUNTIME_GUARDS) {
+                    // Pass 1 of a wide configuration, fused into the walk: the guard of every binding of this segment, one
+                    // binding per iteration (wave-uniform, the replicas it names are scalars), into the per-lane bitset the
+                    // leaves below consume.  No instance bitset, no straight-line block of hundreds of guards.
+#pragma clang loop unroll(disable)
+                    for (u32 j = 0; j < (u32)M::seg_count(sg); ++j) {
+#pragma unroll
+                        for (int q2 = 0; q2 < W; ++q2) kmc_launder(s[q2]);
+                        const u32 g01 = M::template guard<M::seg_kind(sg)>(pre, s, (u32)M::seg_first(sg) + j) & valid01;
+                        km |= (typename M::KindBits)g01 << j;
+                    }
+                    if constexpr (sizeof(km) == 8) nsucc += (u32)__popcll(km);
+                    else nsucc += (u32)__popc(km);
+                } else {
+                    km = M::template seg_bits<sg>(en32);
+                }
             });
 #pragma clang loop unroll(disable)
             for (;;) {

@@ -33,7 +33,10 @@
 // KMC_VERIFY: both builds carry the fingerprint checksum (KMC_CHECKSUM, kmc_device.h); the second one differs in how it is
 // compiled — optimisation level and a quarter of the occupancy target, i.e. another register allocation
 #define KMC_VERIFY_PRIMARY_OPTIONS "-DKMC_CHECKSUM=1"
-#define KMC_VERIFY_OPTIONS "-O1 -DKMC_MIN_WAVES=2 -DKMC_CHECKSUM=1"
+// The second build of the differential self-check: another optimisation level, a quarter of the occupancy target, the
+// fingerprint checksum — and, for the Kafka models, ANOTHER LOWERING OF THE GUARDS: KmcKafka::guard<K> looped per kind over
+// a run-time binding instead of the straight-line block of every instance's inst<I> (kmc_device.h, RUNTIME_GUARDS).
+#define KMC_VERIFY_OPTIONS "-O1 -DKMC_MIN_WAVES=2 -DKMC_CHECKSUM=1 -DKMC_RT_GUARDS_MIN_INSTANCES=0"
 
 namespace {
 
@@ -824,8 +827,9 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     if (verify) {
         // Differential self-check for constants no oracle can reach (round 1 met a k_expand build that LOST successors
         // under heavy register spilling): a second code object of the same source, compiled at -O1 with a quarter of
-        // the occupancy target, re-generates every level's successors (DRY mode: no table, no frontier) and the
-        // per-action counts, deadlock counts and violation counts of the two builds must agree.
+        // the occupancy target and with the guards lowered the other way (KMC_VERIFY_OPTIONS), re-generates every level's
+        // successors (DRY mode: no table, no frontier) and the per-action counts, deadlock counts, violation counts and
+        // the checksum of the successors' fingerprints of the two builds must agree.
         std::vector<char> vcode;
         std::string vname;
         rc = get_code_object(h->cfg, arch, &vcode, &vname, KMC_VERIFY_OPTIONS);

@@ -52,7 +52,14 @@ template <class M> bool kind_major_check(const u64* s, int* checked, int* bad) {
             u64 t1[M::W];
             int kind = 0;
             u32 extra1 = 0;
-            if (!M::template inst<i>(pre, s, t1, kind, extra1)) return;
+            const u32 g1 = M::template inst<i>(pre, s, t1, kind, extra1);
+            // the run-time guard (wide configurations' pass 1) against the instance's own, enabled or not
+            constexpr int sg0 = seg_of_instance<M>(i);
+            constexpr int k0 = M::seg_kind(sg0);
+            const u32 g2 = M::template guard<k0>(pre, s, (u32)(i - M::kind_base(k0)));
+            ++*checked;
+            if ((g1 != 0) != (g2 != 0) || g2 > 1u) ++*bad;
+            if (!g1) return;
             // ... through the walk's own decomposition: the segment (kind, window) whose bitset holds instance i, the bit
             // within it, and apply<kind>(first binding of the window + bit) — what kmc_expand_body does per lane
             constexpr int sg = seg_of_instance<M>(i);

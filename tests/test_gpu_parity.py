@@ -206,3 +206,17 @@ def test_verify_mode_regenerates_every_level_with_a_second_build(monkeypatch):
         res, _ = gpu_run(model, invariants=inv, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E,
                          table_capacity=1 << 24, frontier_capacity=1 << 21)
         assert (res.verdict, res.distinct, res.generated, res.levels) == (o.verdict, o.distinct, o.generated, o.levels)
+
+
+def test_verify_mode_at_a_golden_size(monkeypatch):
+    """KMC_VERIFY=1 on Kip320 3/5/5/2 (75,569,791 states): the second build lowers the guards the other way (guard<K> over
+    run-time bindings against the per-instance block, kmc_device.h) and must regenerate every level with the same counts
+    and the same checksum of successor fingerprints; the run must equal the golden fixture."""
+    import json
+    import os
+    monkeypatch.setenv("KMC_VERIFY", "1")
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_kip320_3_5_5_2.json")))
+    res, _ = gpu_run("Kip320", invariants=("TypeOk", "WeakIsr", "StrongIsr"), n_replicas=3, log_size=5, max_records=5,
+                     max_leader_epoch=2, table_capacity=1 << 28, frontier_capacity=1 << 25)
+    assert (res.verdict, res.distinct, res.generated, res.depth) == ("ok", g["distinct"], g["generated"], g["depth"])
+    assert res.levels == g["levels"]
