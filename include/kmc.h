@@ -278,6 +278,12 @@ int kmc_step_exchange_payload(kmc_handle* h);
  * so nothing crosses the host between the expansion and the collective.  send_counts may be NULL. */
 int kmc_step_expand_counts(kmc_handle* h, const int64_t* stats, int32_t n_stats, int64_t* stats_sum,
                            uint64_t* recv_records, uint64_t* send_counts);
+/* A whole level of a shard — expansion, count exchange, payload, insert — as a pipeline of `parts` (2, 4 or 8) groups of
+ * frontier segments: part c expands into send area c mod 2 while part c-1's counts are gathered and its records travel
+ * and are inserted on a second stream, so a level's wire hides behind its own expansion.  One host wait per part; for
+ * levels large enough to pay for them.  Replaces kmc_step_expand_counts + kmc_step_exchange_payload; kmc_step_finish next. */
+int kmc_step_level_parts(kmc_handle* h, int32_t parts, const int64_t* stats, int32_t n_stats, int64_t* stats_sum,
+                         uint64_t* recv_records);
 /* The same level step for n_shards handles living in one process on one device (RCCL refuses two ranks on one
  * device): counts and statistics ([n_shards][n_stats]) are combined on the host, runs move device-to-device. */
 int kmc_step_exchange_local(kmc_handle** shards, int32_t n_shards, const int64_t* stats, int32_t n_stats,

@@ -124,6 +124,7 @@ SYMBOLS = [
     ("kmc_step_expand_counts", C.c_int, [_H, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64)]),
     ("kmc_step_exchange_payload", C.c_int, [_H]),
+    ("kmc_step_level_parts", C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
     ("kmc_step_exchange_local", C.c_int, [C.POINTER(_H), C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int64)]),
     ("kmc_step_deliver_local", C.c_int, [C.POINTER(_H), C.c_int32]),
     ("kmc_exchange_plan", C.c_int, [C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_uint64, C.c_uint64,

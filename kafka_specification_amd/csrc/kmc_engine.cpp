@@ -398,6 +398,12 @@ struct kmc_handle {
     ncclComm_t comm = nullptr;
     u64* recv = nullptr;             // device: everything this shard receives in one level, contiguous
     uint64_t recv_cap = 0;           // records
+    // the within-level pipeline (kmc_step_level_parts): a second stream for a part's collective, transfer and insert, the
+    // rows of two parts in flight, and the events that order the two streams
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_row[2] = {nullptr, nullptr}, ev_xfer[2] = {nullptr, nullptr};
+    int64_t* prow_dev[2] = {nullptr, nullptr};
+    int64_t* prow_host[2] = {nullptr, nullptr};
     int64_t* xrow_dev = nullptr;     // device: this rank's row, then the gathered rows of all ranks
     int64_t* xrow_host = nullptr;    // pinned: the same
     uint64_t last_send_counts[KMC_MAX_SHARDS * KMC_SEGS] = {0};  // of the last kmc_step_expand
@@ -407,7 +413,7 @@ struct kmc_handle {
 
 namespace {
 
-int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid) {
+int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid, hipStream_t stream = nullptr) {
     KmcArgs args = a;
     unsigned lds = 0;
     if (f == h->f_expand || f == h->f_expand_verify) {  // k_expand carves its rings out of dynamic LDS
@@ -417,7 +423,7 @@ int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid) {
     }
     size_t size = sizeof(args);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, KMC_BLOCK, 1, 1, lds, h->stream, nullptr, config));
+    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, KMC_BLOCK, 1, 1, lds, stream ? stream : h->stream, nullptr, config));
     return KMC_OK;
 }
 
@@ -775,6 +781,14 @@ void kmc_close(kmc_handle* h) {
     if (h->send && h->send_owned) hipFree(h->send);
     comm_release(h);
     if (h->recv) hipFree(h->recv);
+    if (h->xstream) hipStreamSynchronize(h->xstream);
+    for (int i = 0; i < 2; ++i) {
+        if (h->prow_dev[i]) hipFree(h->prow_dev[i]);
+        if (h->prow_host[i]) hipHostFree(h->prow_host[i]);
+        if (h->ev_row[i]) hipEventDestroy(h->ev_row[i]);
+        if (h->ev_xfer[i]) hipEventDestroy(h->ev_xfer[i]);
+    }
+    if (h->xstream) hipStreamDestroy(h->xstream);
     if (h->xrow_dev) hipFree(h->xrow_dev);
     if (h->xrow_host) hipHostFree(h->xrow_host);
     if (h->ctl_host) hipHostFree(h->ctl_host);
@@ -1783,6 +1797,7 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
     if (!h || !h->stepping || !h->step_expanded) return fail(KMC_E_STATE, "kmc_step_expand first");
     HIP_TRY(hipSetDevice(h->cfg.device));
     const int slot = (int)(h->level & 1);
+    if (h->xstream) HIP_TRY(hipStreamSynchronize(h->xstream));   // a pipelined level's last transfer and insert
     int rc = read_ctl(h, slot);
     if (rc) return rc;
     const KmcLevelCtl c = *h->ctl_host;
@@ -1966,7 +1981,7 @@ int ensure_exchange_buffers(kmc_handle* h) {
     return KMC_OK;
 }
 
-int insert_received(kmc_handle* h, uint64_t n_records) {
+int insert_received(kmc_handle* h, uint64_t n_records, hipStream_t stream = nullptr) {
     if (n_records == 0) return KMC_OK;
     const int slot = (int)(h->level & 1);
     KmcArgs a = base_args(h, slot);
@@ -1978,7 +1993,7 @@ int insert_received(kmc_handle* h, uint64_t n_records) {
     uint64_t blocks = (n_records + KMC_BLOCK - 1) / KMC_BLOCK;
     const uint64_t maxb = (uint64_t)h->n_cus * 8;
     if (blocks > maxb) blocks = maxb;
-    return launch(h, h->f_insert, a, (unsigned)blocks);
+    return launch(h, h->f_insert, a, (unsigned)blocks, stream);
 }
 
 }  // namespace
@@ -2189,6 +2204,136 @@ int kmc_step_expand_counts(kmc_handle* h, const int64_t* stats, int32_t n_stats,
     plan_level(h->xcounts.data(), P, me, h->send_cap, (uint64_t)h->rec_words, &sv, &rv, &nrec);
     if (recv_records) *recv_records = nrec;
     h->xcounts_valid = true;
+    h->step_expanded = true;
+    return KMC_OK;
+}
+
+// One BFS level of a shard as a PIPELINE of `parts` parts (2, 4 or 8 groups of the frontier's KMC_SEGS segments): part c is
+// expanded into send area c mod 2 on the engine's stream while part c-1's counts are gathered, its records travel and are
+// inserted on a second stream — the wire of a level hides behind its own expansion (inserts append to
+// the NEXT frontier and to the seen-set with atomics, so they do not disturb the expansion of the current one).  Every part
+// costs the host one wait (it must know the counts to post the receives), which is why small levels keep the one-shot path
+// (kmc_step_expand_counts + kmc_step_exchange_payload).  The caller's statistics ride with part 0.  Afterwards the level
+// stands where kmc_step_exchange_payload leaves it: kmc_step_finish is next.
+int kmc_step_level_parts(kmc_handle* h, int32_t parts, const int64_t* stats, int32_t n_stats, int64_t* stats_sum,
+                         uint64_t* recv_records) {
+    if (!h || !h->stepping) return fail(KMC_E_STATE, "kmc_step_begin first");
+    const int P = h->cfg.n_shards, me = h->cfg.shard_id;
+    if (P < 2 || !h->comm) return fail(KMC_E_STATE, "a pipelined level needs a communicator (n_shards > 1, kmc_comm_init)");
+    if (parts != 2 && parts != 4 && parts != 8) return fail(KMC_E_ARG, "parts must be 2, 4 or 8");
+    if (!h->send) return fail(KMC_E_STATE, "no send area");
+    if (n_stats < 0 || n_stats > KMC_EXCHANGE_STATS || (n_stats && (!stats || !stats_sum)))
+        return fail(KMC_E_ARG, "bad statistics vector");
+    const uint64_t half_cap = h->send_cap / 2;
+    if (half_cap < 64) return fail(KMC_E_STATE, "send area too small to be split for a pipelined level");
+    KmcRccl* r = rccl();
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int rc = ensure_exchange_buffers(h);
+    if (rc) return rc;
+    const size_t row = (size_t)P * KMC_SEGS + KMC_EXCHANGE_STATS;
+    if (!h->xstream) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->xstream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_row[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_xfer[i], hipEventDisableTiming));
+            HIP_TRY(hipMalloc(&h->prow_dev[i], (size_t)(P + 1) * row * 8));
+            HIP_TRY(hipHostMalloc(&h->prow_host[i], (size_t)(P + 1) * row * 8));
+        }
+    }
+    const int slot = (int)(h->level & 1);
+    if ((rc = zero_ctl(h, slot))) return rc;
+    const size_t area_words = (size_t)P * KMC_SEGS * half_cap * (size_t)h->rec_words;
+    const int per = KMC_SEGS / parts;
+    uint64_t total_recv = 0;
+    for (int k = 0; k < n_stats; ++k) stats_sum[k] = 0;
+
+    // stage A: part c's expansion and its row, on the engine's stream
+    auto stage_a = [&](int c) -> int {
+        const int a2 = c & 1;
+        if (c >= 2) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_xfer[a2], 0));   // part c-2 has left this send area
+        HIP_TRY(hipMemsetAsync(&(h->ctl + slot)->send_count, 0, sizeof(KmcLevelCtl) - KMC_CTL_LOCAL_BYTES, h->stream));
+        KmcArgs a = base_args(h, slot);
+        a.fin = h->frontier[h->cur];
+        a.fout = h->frontier[h->cur ^ 1];
+        a.mode = KMC_MODE_SHARDED;
+        a.send = h->send + (size_t)a2 * area_words;
+        a.send_cap = half_cap;
+        uint64_t n_part = 0;
+        for (int sg = 0; sg < KMC_SEGS; ++sg) {
+            if (sg / per != c) a.seg_count[sg] = 0;
+            n_part += a.seg_count[sg];
+        }
+        if (!h->ev_chain[2 * c]) {
+            HIP_TRY(hipEventCreate(&h->ev_chain[2 * c]));
+            HIP_TRY(hipEventCreate(&h->ev_chain[2 * c + 1]));
+        }
+        HIP_TRY(hipEventRecord(h->ev_chain[2 * c], h->stream));
+        int rc2 = KMC_OK;
+        if (n_part && (rc2 = launch(h, h->f_expand, a, expand_grid(h, n_part)))) return rc2;
+        HIP_TRY(hipEventRecord(h->ev_chain[2 * c + 1], h->stream));
+        KmcPackArgs pa{};
+        pa.ctl = h->ctl + slot;
+        pa.row = (long long*)h->prow_dev[a2];
+        pa.send_cap = half_cap;
+        pa.nshards = (uint32_t)P;
+        pa.shard = (uint32_t)me;
+        for (int k = 0; k < KMC_EXCHANGE_STATS; ++k) pa.stats[k] = (c == 0 && k < n_stats) ? stats[k] : 0;
+        size_t size = sizeof(pa);
+        void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &pa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+        HIP_TRY(hipModuleLaunchKernel(h->f_packrow, 1, 1, 1, KMC_BLOCK, 1, 1, 0, h->stream, nullptr, config));
+        HIP_TRY(hipEventRecord(h->ev_row[a2], h->stream));
+        return KMC_OK;
+    };
+
+    if ((rc = stage_a(0))) return rc;
+    for (int c = 0; c < parts; ++c) {
+        const int a2 = c & 1;
+        if (c + 1 < parts && (rc = stage_a(c + 1))) return rc;   // queued BEFORE the host waits for part c's counts
+        // stage B: part c's counts, gathered on the second stream
+        HIP_TRY(hipStreamWaitEvent(h->xstream, h->ev_row[a2], 0));
+        NCCL_TRY(r->AllGather(h->prow_dev[a2], h->prow_dev[a2] + row, row, ncclInt64, h->comm, h->xstream));
+        HIP_TRY(hipMemcpyAsync(h->prow_host[a2] + row, h->prow_dev[a2] + row, (size_t)P * row * 8, hipMemcpyDeviceToHost, h->xstream));
+        HIP_TRY(hipStreamSynchronize(h->xstream));   // this part's host wait (the previous part's insert is behind it too)
+        // stage C: the plan, the transfer and the insert of part c, on the second stream
+        h->xcounts.assign((size_t)P * P * KMC_SEGS, 0);
+        for (int s2 = 0; s2 < P; ++s2) {
+            const int64_t* g = h->prow_host[a2] + (size_t)(1 + s2) * row;
+            for (int d = 0; d < P; ++d)
+                for (int sb = 0; sb < KMC_SEGS; ++sb) {
+                    const int64_t cnt = g[d * KMC_SEGS + sb];
+                    if (cnt < 0 || (uint64_t)cnt > half_cap)
+                        return fail(KMC_E_STATE, "exchange: rank %d announces %lld records for a sub-buffer of %llu", s2,
+                                    (long long)cnt, (unsigned long long)half_cap);
+                    h->xcounts[((size_t)s2 * P + d) * KMC_SEGS + sb] = (uint64_t)cnt;
+                    if (s2 == me) h->last_send_counts[d * KMC_SEGS + sb] = (uint64_t)cnt;
+                }
+            if (c == 0)
+                for (int k = 0; k < n_stats; ++k) stats_sum[k] += g[P * KMC_SEGS + k];
+        }
+        std::vector<KmcXfer> sv, rv;
+        uint64_t nrec = 0;
+        plan_level(h->xcounts.data(), P, me, half_cap, (uint64_t)h->rec_words, &sv, &rv, &nrec);
+        if (nrec > h->recv_cap) return fail(KMC_E_STATE, "exchange: %llu records exceed the receive area", (unsigned long long)nrec);
+        const u64* area = h->send + (size_t)a2 * area_words;
+        if (!sv.empty() || !rv.empty()) {
+            NCCL_TRY(r->GroupStart());
+            for (const KmcXfer& x : sv) NCCL_TRY(r->Send(area + x.offset_words, x.words, ncclUint64, (int)x.peer, h->comm, h->xstream));
+            for (const KmcXfer& x : rv) NCCL_TRY(r->Recv(h->recv + x.offset_words, x.words, ncclUint64, (int)x.peer, h->comm, h->xstream));
+            NCCL_TRY(r->GroupEnd());
+        }
+        HIP_TRY(hipEventRecord(h->ev_xfer[a2], h->xstream));     // the send area may be refilled (part c+2)
+        if ((rc = insert_received(h, nrec, h->xstream))) return rc;   // behind the receives; the receive area is reused by
+                                                                      // part c+1's transfer, which this stream orders behind it
+        total_recv += nrec;
+    }
+    for (int c = 0; c < parts; ++c) {   // every part's expansion has completed: its row was gathered
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev_chain[2 * c], h->ev_chain[2 * c + 1]));
+        h->res.seconds_expand += 1e-3 * ms;
+        h->res.expand_launches++;
+    }
+    if (recv_records) *recv_records = total_recv;
+    h->xcounts_valid = false;
     h->step_expanded = true;
     return KMC_OK;
 }

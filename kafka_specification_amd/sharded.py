@@ -317,17 +317,33 @@ class RcclExchange:
                                                     out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nrecv)))
         return out, self._deliver
 
-    def expand_and_exchange(self, engines, stats):
+    # A level whose GLOBAL frontier (the same number on every rank) has at least PIPELINE_MIN_STATES states runs as a pipeline
+    # of PIPELINE_PARTS parts under the ABI (kmc_step_level_parts: the wire of a part hides behind the expansion of the next
+    # one), smaller levels in one shot.  Every part costs a host wait, so the threshold is far above the headline's widest
+    # level (29 M states): the pipeline is for the configurations that take seconds.  KMC_PIPELINE_PARTS=1
+    # switches it off, KMC_PIPELINE_MIN_STATES moves the threshold (the tests run it on everything).
+    PIPELINE_PARTS = int(os.environ.get("KMC_PIPELINE_PARTS", "4"))
+    PIPELINE_MIN_STATES = int(os.environ.get("KMC_PIPELINE_MIN_STATES", str(1 << 26)))
+
+    def expand_and_exchange(self, engines, stats, level_states=0):
         """The level's expansion and its count exchange in one call under the ABI (kmc_step_expand_counts): the send counts
-        go from k_expand's control block into the all-gather on the device, and the host waits once."""
+        go from k_expand's control block into the all-gather on the device, and the host waits once.  `level_states`: the
+        global size of the level being expanded (identical on every rank) — decides one shot or pipeline."""
         (st,) = stats
         st = np.ascontiguousarray(st, dtype=np.int64)
         out = np.zeros(N_STATS, dtype=np.int64)
         nrecv = C.c_uint64()
-        nat.check(self.lib.kmc_step_expand_counts(self.engine.mc.handle, st.ctypes.data_as(C.POINTER(C.c_int64)), N_STATS,
-                                                  out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nrecv), None))
         if not hasattr(self, "level_bytes"):
             self.level_bytes = []
+        parts = type(self).PIPELINE_PARTS
+        if parts > 1 and level_states >= type(self).PIPELINE_MIN_STATES and self.world > 1:
+            nat.check(self.lib.kmc_step_level_parts(self.engine.mc.handle, parts, st.ctypes.data_as(C.POINTER(C.c_int64)), N_STATS,
+                                                    out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nrecv)))
+            self.level_bytes.append(int(nrecv.value) * self.engine.record_words * 8)
+            self.pipelined_levels = getattr(self, "pipelined_levels", 0) + 1
+            return out, lambda: [[]]          # the payload has travelled and is being inserted: nothing left to deliver
+        nat.check(self.lib.kmc_step_expand_counts(self.engine.mc.handle, st.ctypes.data_as(C.POINTER(C.c_int64)), N_STATS,
+                                                  out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nrecv), None))
         self.level_bytes.append(int(nrecv.value) * self.engine.record_words * 8)
         return out, self._deliver
 
@@ -540,7 +556,9 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
         # the engines hold level depth+1 (complete); like kmc_run, level l is expanded iff l < max_levels
         can_expand = depth + 1 < max_levels
         if can_expand and pipelined and hasattr(exchange, "expand_and_exchange"):
-            st, deliver = exchange.expand_and_exchange(engines, pending)   # fused under the ABI: one host wait
+            # fused under the ABI: one host wait (or, for a very wide level, a pipeline of parts: RcclExchange).  The size of
+            # the level being expanded is the global one, the same on every rank.
+            st, deliver = exchange.expand_and_exchange(engines, pending, level_states=new)
         elif can_expand and pipelined:
             sends = [e.expand() for e in engines]
             st, deliver = exchange.exchange(sends, pending)

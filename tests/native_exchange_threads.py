@@ -5,8 +5,9 @@ concurrent rank: each thread drives its own HipShardEngine through sharded.run_s
 rank does; only the transport under the nccl* calls is the stand-in (tests/mock_rccl.cpp).  Checked against the C oracle.
 Run by tests/test_gpu_native_exchange_threads.py in a fresh process (the engine binds "RCCL" once per process).
 
-usage: native_exchange_threads.py MODEL N L R E P inv1,inv2 [trace] [levels=K]   -> one JSON line, exit code 0 when everything agrees
-(levels=K: stop after K BFS levels and compare with the oracle's prefix — for constants nothing can exhaust)"""
+usage: native_exchange_threads.py MODEL N L R E P inv1,inv2 [trace] [levels=K] [pipeline=PARTS]   -> one JSON line, exit code 0 when everything agrees
+(levels=K: stop after K BFS levels and compare with the oracle's prefix — for constants nothing can exhaust;
+ pipeline=PARTS: every level runs as a pipeline of PARTS parts, kmc_step_level_parts, instead of in one shot)"""
 import ctypes as C
 import json
 import os
@@ -17,6 +18,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 os.environ["KMC_RCCL_LIB"] = os.path.join(HERE, "_mock_rccl.so")     # before the engine's first look for librccl
 os.environ["KMC_EXCHANGE"] = "rccl"
+_parts = next((int(a[9:]) for a in sys.argv[8:] if a.startswith("pipeline=")), 0)
+if _parts:   # every level as a pipeline of that many parts (kmc_step_level_parts); read when sharded is imported
+    os.environ["KMC_PIPELINE_PARTS"] = str(_parts)
+    os.environ["KMC_PIPELINE_MIN_STATES"] = "0"
+else:
+    os.environ["KMC_PIPELINE_PARTS"] = "1"
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
@@ -84,11 +91,11 @@ def main():
     nat.check(lib.kmc_comm_unique_id(uid))          # main thread: also the one-time binding of "librccl"
     engines = [sharded.HipShardEngine(cfg, r, P, 0, native=True) for r in range(P)]
     assert all(e.native for e in engines)
-    shared, results, errors = Shared(P), [None] * P, [None] * P
+    shared, results, errors, exchanges = Shared(P), [None] * P, [None] * P, [None] * P
 
     def rank_main(r):
         try:
-            ex = ThreadRcclExchange(engines[r], bytes(uid), shared, r)
+            ex = exchanges[r] = ThreadRcclExchange(engines[r], bytes(uid), shared, r)
             ex.selftest()                           # all-gather + grouped send/receive ring across ALL ranks, verified
             results[r] = sharded.run_sharded([engines[r]], ex, cfg, engines[r].action_names())
         except BaseException as e:  # noqa: BLE001 — reported below; the other ranks run into the mock's time-out
@@ -117,6 +124,7 @@ def main():
                        r0.levels == o.levels and r0.deadlock_states == o.deadlock_states and r0.violated_invariant == o.viol_inv)
         if o.viol_inv and not K:
             matches = matches and r0.violation_depth == o.viol_depth and r0.violation_count == o.viol_count
+        out["pipelined_levels"] = _parts and min(getattr(ex, "pipelined_levels", 0) for ex in exchanges)
         out.update(verdict=r0.verdict, distinct=r0.distinct, generated=r0.generated, depth=r0.depth,
                    same_on_every_rank=same_everywhere, matches_oracle=matches,
                    exchange=type(engines[0]).__name__ + " + ThreadRcclExchange over " + os.path.basename(os.environ["KMC_RCCL_LIB"]))

@@ -64,3 +64,25 @@ def test_baseline_config5_seven_brokers_through_the_native_exchange_with_eight_r
     sizes and per-action generated counts, identically on every rank."""
     out = _run("Kip320", 7, 8, 8, 3, 8, "TypeOk", "trace", "levels=7")
     assert out["matches_oracle"] and out["same_on_every_rank"] and out["verdict"] == "level_limit"
+
+
+@pytest.mark.parametrize("P,parts", [(2, 2), (3, 4), (4, 8), (8, 4)])
+def test_pipelined_levels_match_the_oracle(P, parts):
+    """kmc_step_level_parts: every level as a pipeline of `parts` groups of frontier segments — part c expands into send area
+    c mod 2 on the engine's stream while part c-1's counts are gathered, its records travel and are inserted on a second
+    stream — with P concurrent ranks.  Same numbers as the one-shot exchange and the oracle, identically on every rank."""
+    out = _run("Kip320", 3, 2, 2, 1, P, "TypeOk,WeakIsr,StrongIsr", f"pipeline={parts}")
+    assert out["matches_oracle"] and out["same_on_every_rank"] and out["verdict"] == "ok"
+    assert out["pipelined_levels"] >= out["depth"] - 1
+
+
+def test_pipelined_levels_with_traces_a_violation_and_the_sender_side_filter():
+    out = _run("Kip101", 3, 2, 2, 2, 2, "TypeOk,StrongIsr", "trace", "pipeline=4")
+    assert out["matches_oracle"] and out["trace_len"] >= 2 and out["pipelined_levels"] > 0
+    out = _run("Kip279", 3, 2, 2, 2, 3, "TypeOk,StrongIsr", "pipeline=2")
+    assert out["matches_oracle"] and out["same_on_every_rank"] and out["verdict"] == "invariant"
+
+
+def test_pipelined_levels_on_config5_with_eight_ranks():
+    out = _run("Kip320", 7, 8, 8, 3, 8, "TypeOk", "trace", "levels=7", "pipeline=4")
+    assert out["matches_oracle"] and out["same_on_every_rank"] and out["verdict"] == "level_limit"
