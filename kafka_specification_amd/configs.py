@@ -67,7 +67,7 @@ def precompile_list():
         out.append(dict(model="AsyncIsr", n_replicas=N, log_size=M, max_leader_epoch=V))
     out.append(dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3))  # 6.45 G states: the -fp128 run
     for name, c in BASELINE_CONFIGS.items():
-        # (config 4, 7 brokers: 357 action instances, 9-word states — minutes of hiprtc time, but the -m gpu prefix test
+        # (config 4, 7 brokers: 357 action instances, 10-word states — minutes of hiprtc time, but the -m gpu prefix test
         # needs it and a GPU box should not spend its minutes compiling)
         out.append({k: v for k, v in c.items() if k != "invariants"})
     seen, uniq = set(), []
