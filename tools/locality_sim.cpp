@@ -1,4 +1,7 @@
-// locality_sim — a CPU emulation of how k_expand's WAVES walk a BFS level, to price two changes before building them:
+// locality_sim — a CPU emulation of how k_expand's WAVES walk a BFS level, to price changes before building them:
+//   (0) how many effect leaves a 64-state tile needs under the KIND-MAJOR walk (sum over action kinds of the largest
+//       number of enabled bindings any lane has: every lane applies its own next binding per leaf) — 12.6 where the
+//       instance-major walk dispatches 31: the number that started round 3's rewrite of pass 2,
 //   (1) how many effect leaves a 64-state tile dispatches (distinct enabled action instances per tile), and
 //   (2) how many seen-set probes a small per-wave filter of recently resolved fingerprints would answer,
 // under today's frontier order (64-winner batches of thousands of concurrent waves interleaved into 8 segments, tiles
@@ -33,6 +36,7 @@ struct SHash {
     size_t operator()(const State& s) const { return (size_t)kmc_fingerprint<W>(s.data(), 0); }
 };
 
+static double g_kind_major_leaves = 0;
 struct Succ {
     State t;
     u64 fp;
@@ -43,6 +47,8 @@ struct Succ {
 static int expand_tile(const State* s, int n, std::vector<Succ>& out) {
     out.clear();
     int leaves = 0;
+    int cnt[64][16];
+    memset(cnt, 0, sizeof cnt);
     typename M::Pre pre[64];
     for (int l = 0; l < n; ++l) pre[l] = M::extract(s[l].data());
     kmc_static_for<0, M::NINST>([&](auto I) {
@@ -54,10 +60,16 @@ static int expand_tile(const State* s, int n, std::vector<Succ>& out) {
             if (M::template inst<decltype(I)::value>(pre[l], s[l].data(), t.data(), kind, extra)) {
                 out.push_back({t, kmc_fingerprint<W>(t.data(), 0)});
                 any = true;
+                cnt[l][kind]++;
             }
         }
         leaves += any;
     });
+    for (int k = 0; k < 16; ++k) {   // kind-major: a kind costs as many leaves as its busiest lane has enabled bindings
+        int mx = 0;
+        for (int l = 0; l < n; ++l) mx = std::max(mx, cnt[l][k]);
+        g_kind_major_leaves += mx;
+    }
     return leaves;
 }
 
@@ -149,6 +161,7 @@ int main(int argc, char** argv) {
         tot.tiles += lv.tiles; tot.leaves += lv.leaves; tot.probes += lv.probes; tot.filter_hits += lv.filter_hits; tot.states += lv.states;
         if (!produced) break;
     }
+    printf("kind-major walk: %.2f effect leaves per tile (instance-major: %.2f)\n", g_kind_major_leaves / tot.tiles, tot.leaves / tot.tiles);
     printf("TOTAL mode %d NW %d CH %d FS %d: %.0f states, %.0f tiles (%.1f states/tile), leaves/tile %.2f, filter hits %.2f %% of %.0f probes\n",
            mode, NW, CH, FS, tot.states, tot.tiles, tot.states / tot.tiles, tot.leaves / tot.tiles, 100.0 * tot.filter_hits / tot.probes, tot.probes);
     return 0;
