@@ -104,7 +104,14 @@ typedef struct kmc_config {
                                    distinct states with the same fingerprint are then told apart instead of merged: the
                                    distinct-state count is exact up to a 128-bit collision (n^2 / 2^129).  TLC has no such
                                    switch (its FPSet is 64-bit); table_capacity still counts slots */
-    int32_t pad_;
+    int32_t symmetry;           /* 1: orbit counting.  The specs never tell two members of Replicas apart (KafkaReplication.tla
+                                   :109-120, :158-310), so only the smallest image of a state under the |Replicas|!
+                                   permutations is stored and expanded, and every count is weighted by the size of that
+                                   state's orbit: distinct / generated / per-level / per-disjunct / deadlock / violation
+                                   counts, verdict and depth are those of the plain search (and of TLC WITHOUT a SYMMETRY
+                                   set — TLC's own SYMMETRY reports the reduced counts) from ~1/|Replicas|! of the probes.
+                                   Kafka family and FiniteReplicatedLog, |Replicas| <= 4, n_shards = 1.  Traces are real
+                                   behaviours (each step a successor of the one before), not chains of representatives */
 } kmc_config;
 
 typedef struct kmc_level_info {
@@ -153,6 +160,8 @@ typedef struct kmc_result {
     uint64_t generated_repeats; /* of `generated`: successors TLC's enumeration yields a second time because two disjuncts
                                    of one binding hold at once (Kip279.tla:47-51, Kip320.tla:82-83); each is one successor
                                    and one seen-set probe, so probes = generated - 1 - generated_repeats */
+    uint64_t orbit_representatives; /* kmc_config.symmetry: the states actually stored and expanded (one per orbit);
+                                   without it equal to `distinct` */
 } kmc_result;
 
 typedef struct kmc_handle kmc_handle;
@@ -197,6 +206,10 @@ uint64_t kmc_canon_bytes(kmc_handle* h);
 int kmc_unpack_state(kmc_handle* h, const uint64_t* words, uint8_t* canon);
 int kmc_pack_state(kmc_handle* h, const uint8_t* canon, uint64_t* words);
 uint64_t kmc_fingerprint_of(kmc_handle* h, const uint64_t* words);
+/* The representative of a packed state's orbit under the permutations of Replicas (the smallest image, words compared in
+ * order as unsigned values) and the number of permutations that leave the state unchanged: its orbit has
+ * |Replicas|! / *stabiliser members.  What a kmc_config.symmetry search stores; works on host-only handles. */
+int kmc_canonical_state(kmc_handle* h, const uint64_t* words, uint64_t* representative, int32_t* stabiliser);
 /* Copy the current frontier (the last completed level) to the host as packed AoS records. */
 int kmc_frontier_states(kmc_handle* h, uint64_t* words, uint64_t cap_states, uint64_t* n_out);
 /* All successors of one packed state, straight from the device kernels: writes up to cap

@@ -49,7 +49,7 @@ class KmcConfig(C.Structure):
         ("n_shards", C.c_int32), ("shard_id", C.c_int32),
         ("table_capacity", C.c_uint64), ("frontier_capacity", C.c_uint64), ("send_capacity", C.c_uint64),
         ("hash_seed", C.c_uint64), ("max_levels", C.c_uint64), ("cache_dir", C.c_char_p),
-        ("wide_fingerprint", C.c_int32), ("pad_", C.c_int32),
+        ("wide_fingerprint", C.c_int32), ("symmetry", C.c_int32),
     ]
 
 
@@ -71,6 +71,7 @@ class KmcResult(C.Structure):
         ("n_levels", C.c_uint64), ("table_capacity", C.c_uint64), ("frontier_capacity", C.c_uint64),
         ("seconds_total", C.c_double), ("seconds_expand", C.c_double), ("expand_launches", C.c_uint64),
         ("state_words", C.c_uint64), ("state_bits", C.c_uint64), ("generated_repeats", C.c_uint64),
+        ("orbit_representatives", C.c_uint64),
     ]
 
 
@@ -94,6 +95,7 @@ SYMBOLS = [
     ("kmc_unpack_state", C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]),
     ("kmc_pack_state", C.c_int, [_H, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]),
     ("kmc_fingerprint_of", C.c_uint64, [_H, C.POINTER(C.c_uint64)]),
+    ("kmc_canonical_state", C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     ("kmc_frontier_states", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]),
     ("kmc_successors", C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]),
     ("kmc_trace", C.c_int, [_H, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_uint64, C.POINTER(C.c_uint64)]),

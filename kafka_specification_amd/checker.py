@@ -40,6 +40,10 @@ class CheckerConfig:
     cache_dir: Optional[str] = None
     wide_fingerprint: bool = False          # 128-bit seen-set entries (fingerprint + an independent check word): a 64-bit
                                             # fingerprint collision is recognised instead of silently merging two states
+    symmetry: bool = False                  # orbit counting: store / expand one state per orbit of the permutations of Replicas,
+                                            # weigh every count by the orbit's size — the plain search's numbers (TLC without a
+                                            # SYMMETRY set) from ~1/|Replicas|! of the probes.  Kafka family and
+                                            # FiniteReplicatedLog, at most 4 replicas, one GPU
 
     def to_native(self) -> nat.KmcConfig:
         if self.model not in nat.MODELS:
@@ -60,7 +64,7 @@ class CheckerConfig:
             frontier_capacity=self.frontier_capacity, send_capacity=self.send_capacity,
             hash_seed=self.hash_seed, max_levels=self.max_levels,
             cache_dir=self.cache_dir.encode() if self.cache_dir else None,
-            wide_fingerprint=int(self.wide_fingerprint))
+            wide_fingerprint=int(self.wide_fingerprint), symmetry=int(self.symmetry))
 
 
 @dataclass
@@ -86,6 +90,7 @@ class CheckResult:
     state_bits: int
     trace: list = field(default_factory=list)
     generated_repeats: int = 0   # of `generated`: successors yielded twice by two disjuncts of one binding (one probe each)
+    orbit_representatives: int = 0   # CheckerConfig.symmetry: the states actually stored and expanded (else = distinct)
 
 
 def precompile(cfg: CheckerConfig, arch: str = "gfx950") -> None:
@@ -180,7 +185,7 @@ class ModelChecker:
             table_capacity=int(r.table_capacity), frontier_capacity=int(r.frontier_capacity),
             seconds_total=float(r.seconds_total), seconds_expand=float(r.seconds_expand),
             expand_launches=int(r.expand_launches), state_words=int(r.state_words), state_bits=int(r.state_bits),
-            generated_repeats=int(r.generated_repeats))
+            generated_repeats=int(r.generated_repeats), orbit_representatives=int(r.orbit_representatives))
 
     # -- states as data -------------------------------------------------------------------
     def unpack(self, words) -> bytes:
@@ -198,6 +203,14 @@ class ModelChecker:
     def fingerprint(self, words) -> int:
         w = (C.c_uint64 * self.state_words)(*[int(x) for x in words])
         return int(self._lib.kmc_fingerprint_of(self._h, w))
+
+    def canonical(self, words):
+        """(order of the stabiliser, representative words) of a packed state's orbit under the permutations of Replicas."""
+        w = (C.c_uint64 * self.state_words)(*[int(x) for x in words])
+        out = (C.c_uint64 * self.state_words)()
+        stab = C.c_int32()
+        nat.check(self._lib.kmc_canonical_state(self._h, w, out, C.byref(stab)))
+        return stab.value, tuple(int(x) for x in out)
 
     def frontier_states(self) -> np.ndarray:
         """The last completed BFS level as an (n, state_words) uint64 array."""

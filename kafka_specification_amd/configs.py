@@ -90,7 +90,7 @@ def precompile_variants():
     return [(small, {"KMC_VERIFY": "1"}), (wide, {"KMC_VERIFY": "1"}), (golden, {"KMC_VERIFY": "1"}), (small, fault),
             (small, dict(fault, KMC_VERIFY="1")),
             (dict(model="AsyncIsr", n_replicas=3, log_size=2, max_leader_epoch=2), fault),
-            (small, {"KMC_JIT_DEFINES": "-DKMC_TEST_FP_BITS=10"})] + layout_variants()   # (collisions on demand for the wide-fingerprint test)
+            (small, {"KMC_JIT_DEFINES": "-DKMC_TEST_FP_BITS=10"})] + layout_variants() + symmetry_variants()   # (collisions on demand for the wide-fingerprint test)
 
 
 # The arrangements of the Kafka state vector (csrc/kmc_layout.h) and the two walks of k_expand's pass 2 that go with them:
@@ -104,6 +104,24 @@ INSTANCE_MAJOR_SMALL = [(m, 3, 2, 2, 1) for m in KAFKA] + [("Kip320", 4, 2, 2, 1
                                                               ("Kip279", 3, 2, 2, 2)]
 INSTANCE_MAJOR_LARGE = [("Kip320", 3, 5, 5, 2), ("Kip279", 3, 5, 5, 2)]
 GROUPED_LARGE = [("Kip320", 3, 5, 5, 2)]
+
+
+# Symmetry reduction with orbit counting (CheckerConfig.symmetry; tests/test_gpu_symmetry.py, bench.py's orbit_counting leg)
+SYMMETRY_KAFKA = [(m, N, L, R, E) for m in KAFKA
+                  for (N, L, R, E) in [(2, 2, 2, 1), (3, 2, 2, 1), (3, 1, 1, 2), (2, 3, 3, 2), (3, 2, 2, 2), (4, 1, 1, 1)]] + [
+    ("Kip320", 4, 2, 2, 1), ("Kip101", 4, 2, 1, 2), ("Kip279", 3, 2, 3, 2), ("Kip320FirstTry", 3, 3, 3, 1),
+    ("KafkaTruncateToHighWatermark", 3, 3, 3, 1), ("Kip320", 3, 6, 6, 2), ("Kip320", 3, 5, 5, 2), ("Kip320", 3, 6, 6, 3)]
+SYMMETRY_LAYOUTS = [("Kip320", 3, 2, 2, 2), ("Kip279", 3, 2, 2, 1), ("Kip101", 4, 2, 1, 1)]
+SYMMETRY_FRL = [(2, 4, 2), (3, 2, 2), (2, 4, 4), (4, 2, 1)]
+
+
+def symmetry_variants():
+    def c(t):
+        return dict(model=t[0], n_replicas=t[1], log_size=t[2], max_records=t[3], max_leader_epoch=t[4], symmetry=True)
+    return ([(c(t), {}) for t in SYMMETRY_KAFKA] +
+            [(c(t), {"KMC_LAYOUT": lay}) for t in SYMMETRY_LAYOUTS for lay in ("tight", "rm", "rmg")] +
+            [(dict(model="FiniteReplicatedLog", n_replicas=N, log_size=L, n_log_records=K, symmetry=True), {})
+             for (N, L, K) in SYMMETRY_FRL])
 
 
 def layout_variants():

@@ -155,6 +155,12 @@ typedef unsigned int u32;
                                           // across instances, a loop cannot.  KMC_VERIFY's second build sets it to 0: its
                                           // guards are then a second, independent lowering (kmc_engine.cpp)
 #endif
+#ifndef KMC_SYMM
+#define KMC_SYMM 0        // 1 (kmc_config.symmetry): symmetry reduction with orbit counting — every successor is replaced by the
+                          // representative of its orbit under the permutations of Replicas before it is fingerprinted, and
+                          // the level's counters come with the deficits (KmcLevelCtl::corr_*) that turn counts over
+                          // representatives into the counts of the plain search (KmcSymm below)
+#endif
 #ifndef KMC_PREFETCH
 #define KMC_PREFETCH 0    // 1: request the next tile's state words while the current tile is processed (measured: no gain)
 #endif
@@ -204,6 +210,13 @@ struct alignas(128) KmcLevelCtl {
     u64 oviol_count[4];              // successors OUTSIDE the state constraint violating invariant k (per generation)
     u64 oviol_fp_inv[4];             // max over those of ~fp
     u64 prof[8];                     // KMC_PROFILE: summed per-wave s_memtime ticks per phase (tuning aid)
+    // KMC_SYMM: a counter x above counts orbit REPRESENTATIVES; the plain search's count is N! * x - corr_x, where corr_x sums
+    // N! - |orbit| over the representatives counted (0 for the great majority: a state whose replicas all differ has N! images)
+    u64 corr_gen[KMC_MAX_KINDS];     // of generated[k]: summed over (expanded state, enabled binding of kind k) [+ the repeats]
+    u64 corr_viol[4];                // of viol_count[k]
+    u64 corr_dead;                   // of deadlock_count
+    u64 corr_repeats;                // of repeats
+    u64 corr_won;                    // of won = the states of the produced level
     u32 err;
     u32 halt;                        // chained launches: this level was not expanded because an earlier one ended the search
     // (everything above is what a single-GPU level reports: the host copies the block only up to here)
@@ -1491,6 +1504,133 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
 };
 
 // ========================================================================================
+// Symmetry reduction with orbit counting (kmc_config.symmetry; the kernels use it in KMC_SYMM builds)
+// ========================================================================================
+// The specs quantify over Replicas and never tell two of them apart (KafkaReplication.tla:109-120, :158-310; the five
+// modules' own actions: `\E leader, replica \in Replicas`), so the N! permutations of Replicas are automorphisms of the state
+// graph: they map Init to Init, successors to successors (binding by binding, so also the per-disjunct "generated" counts
+// and the doubly satisfied disjuncts), and keep every invariant and the BFS depth.  The search therefore only stores and
+// expands ONE state per orbit — the smallest image under the N! permutations, words compared in order — and every count it
+// reports is weighted by the orbit's size N! / |stabiliser|: distinct states, states per level, generated per disjunct,
+// deadlocks and violating states all come out as the numbers of the plain search (and of TLC without SYMMETRY), from
+// ~1/N! of the probes.  (TLC's own SYMMETRY reports the REDUCED counts — SURVEY.md rules that out; this does not change them.)
+// permute<P> is the compile-time form of kmc_permute_state (kmc_layout.h): fields move between compile-time offsets, the
+// replica ids inside fields are renamed through constants indexed by shifts.
+template <class M> struct KmcSymm {
+    static constexpr KmcLayout Y = M::Y;
+    static constexpr int N = Y.N, W = Y.W;
+    static constexpr bool KAFKA = Y.model != KMC_MODEL_FINITE_REPLICATED_LOG;
+    static constexpr int NFACT = kmc_factorial(N);
+    static_assert(kmc_model_symmetric(Y.model), "this model singles out a replica: no symmetry reduction");
+    static_assert(N <= 4, "orbit representatives are found by trying all N! permutations: N <= 4");
+    static constexpr u32 ML = (1u << Y.BL) - 1, MI = (1u << Y.BI) - 1;
+
+    // leader fields hold 0 (None) or index + 1: entry v of the table is the renamed value
+    static constexpr u64 ldr_table(int P) {
+        u64 t = 0;
+        for (int v = 1; v <= N; ++v) t |= (u64)(kmc_perm_image(N, P, v - 1) + 1) << (v * Y.BL);
+        return t;
+    }
+    // isr masks: entry m (N bits) is the mask with every member renamed (2^N entries: 64 bits at N = 4)
+    static constexpr u64 isr_table(int P) {
+        u64 t = 0;
+        for (int m = 0; m < (1 << N); ++m) {
+            u64 pm = 0;
+            for (int i = 0; i < N; ++i)
+                if (m >> i & 1) pm |= 1ull << kmc_perm_image(N, P, i);
+            t |= pm << (m * N);
+        }
+        return t;
+    }
+    template <int P> static KMC_DEV u32 map_ldr(u32 v) {
+        constexpr u64 T = ldr_table(P);
+        if constexpr ((N + 1) * Y.BL <= 32) return ((u32)T >> (v * Y.BL)) & ML;
+        else return (u32)(T >> (v * Y.BL)) & ML;
+    }
+    template <int P> static KMC_DEV u32 map_isr(u32 m) {
+        constexpr u64 T = isr_table(P);
+        if constexpr ((1 << N) * N <= 32) return ((u32)T >> (m * N)) & MI;
+        else return (u32)(T >> (m * N)) & MI;
+    }
+    // the global fields no permutation touches (nextRecordId, nextLeaderEpoch, quorumState.leaderEpoch), as a mask of word k
+    static constexpr u64 keep_mask(int k) {
+        u64 m = 0;
+        if (!KAFKA) return m;
+        const int off[3] = {Y.nextrec_off, Y.nextep_off, Y.qep_off}, bits[3] = {Y.BNR, Y.BE, Y.BE};
+        for (int f = 0; f < 3; ++f)
+            for (int b = off[f]; b < off[f] + bits[f]; ++b)
+                if ((b >> 6) == k) m |= 1ull << (b & 63);
+        return m;
+    }
+
+    template <int P> static KMC_DEV void permute(const u64* s, u64* t) {
+        kmc_static_for<0, W>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            t[k] = s[k] & keep_mask(k);
+        });
+        kmc_static_for<0, N>([&](auto RR) {
+            constexpr int r = decltype(RR)::value, d = kmc_perm_image(N, P, r);
+            kmc_orbits(t, Y.log_off[d], Y.BR * Y.L, kmc_getbits(s, Y.log_off[r], Y.BR * Y.L));
+            if constexpr (!KAFKA) {
+                kmc_orbits(t, Y.end_off[d], Y.BO, kmc_getbits(s, Y.end_off[r], Y.BO));
+            } else {
+                // end | hw | ep | ldr | isr are adjacent in every arrangement of the state vector (kmc_layout.h): one field
+                constexpr int GB = 2 * Y.BO + Y.BE, SB = GB + Y.BL + Y.BI;
+                static_assert(Y.hw_off[r] == Y.end_off[r] + Y.BO && Y.ep_off[r] == Y.hw_off[r] + Y.BO &&
+                              Y.ldr_off[r] == Y.ep_off[r] + Y.BE && Y.isr_off[r] == Y.ldr_off[r] + Y.BL, "small group not contiguous");
+                static_assert(SB <= 32, "a replica's small group is renamed in one 32-bit register");
+                const u32 g = (u32)kmc_getbits(s, Y.end_off[r], SB);
+                const u32 g2 = (g & ((1u << GB) - 1)) | (map_ldr<P>((g >> GB) & ML) << GB) | (map_isr<P>(g >> (GB + Y.BL)) << (GB + Y.BL));
+                kmc_orbits(t, Y.end_off[d], SB, g2);
+            }
+        });
+        if constexpr (KAFKA) {
+            kmc_orbits(t, Y.qldr_off, Y.BL, map_ldr<P>((u32)kmc_getbits(s, Y.qldr_off, Y.BL)));
+            kmc_orbits(t, Y.qisr_off, Y.BI, map_isr<P>((u32)kmc_getbits(s, Y.qisr_off, Y.BI)));
+            kmc_static_for<0, Y.E + 1>([&](auto EE) {
+                constexpr int e = decltype(EE)::value;
+                kmc_orbits(t, Y.reqldr_off[e], Y.BL, map_ldr<P>((u32)kmc_getbits(s, Y.reqldr_off[e], Y.BL)));
+                kmc_orbits(t, Y.reqisr_off[e], Y.BI, map_isr<P>((u32)kmc_getbits(s, Y.reqisr_off[e], Y.BI)));
+            });
+        }
+    }
+    // c = the orbit's representative (the smallest image, word 0 first), stab = the permutations that fix s
+    static KMC_DEV void canon(const u64* s, u64* c, u32& stab) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) c[k] = s[k];
+        u32 n = 1;
+        kmc_static_for<1, NFACT>([&](auto PP) {
+            u64 t[W];
+            permute<decltype(PP)::value>(s, t);
+            bool lt = false, eq = true;
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                lt = lt || (eq && t[k] < c[k]);
+                eq = eq && t[k] == c[k];
+            }
+            n = lt ? 1u : n + (eq ? 1u : 0u);
+#pragma unroll
+            for (int k = 0; k < W; ++k) c[k] = lt ? t[k] : c[k];
+        });
+        stab = n;
+    }
+    static KMC_DEV u32 stabiliser(const u64* s) {
+        u32 n = 1;
+        kmc_static_for<1, NFACT>([&](auto PP) {
+            u64 t[W];
+            permute<decltype(PP)::value>(s, t);
+            bool eq = true;
+#pragma unroll
+            for (int k = 0; k < W; ++k) eq = eq && t[k] == s[k];
+            n += eq ? 1u : 0u;
+        });
+        return n;
+    }
+    // what a state of stabiliser order `stab` lacks to a full orbit: N! - N!/stab (0 for almost every state)
+    static KMC_DEV u32 deficit(u32 stab) { return stab == 1 ? 0u : (u32)NFACT - (u32)NFACT / stab; }
+};
+
+// ========================================================================================
 // successor sink: table probe/insert + frontier append, or owner bucketing, or enumeration
 // ========================================================================================
 #ifndef KMC_HOST_EMU  // ---- everything below is wave-level device code ----
@@ -1505,6 +1645,9 @@ template <int W> struct KmcStager {
                    // in finish(): one atomicAdd per flush on that single line capped the sharded kernel at ~90 M flushes/s,
                    // 5.6x the time of the local kernel for the same work)
     u32 probed, won, outside;  // wave-uniform conservation counters (KmcLevelCtl), added to the level's once, in finish()
+#if KMC_SYMM
+    u32 corr_won;              // per lane: orbit deficits of the claims this lane won (KmcLevelCtl::corr_won)
+#endif
 #if KMC_CHECKSUM
     u64 csum, cxor;            // per lane: running sum and xor of the fingerprints this lane sent into the sink
 #endif
@@ -1514,6 +1657,9 @@ template <int W> struct KmcStager {
 
     KMC_DEV void init(u64* lds) {
         planes = lds; count = 0; filtered = 0; probed = 0; won = 0; outside = 0;
+#if KMC_SYMM
+        corr_won = 0;
+#endif
 #if KMC_CHECKSUM
         csum = 0; cxor = 0;
 #endif
@@ -1573,6 +1719,15 @@ template <int W> struct KmcStager {
         if (filtered && kmc_lane() == 0) atomicAdd(&a.ctl->send_filtered, (u64)filtered);
         filtered = 0;
         if (!publish_counters) return;   // k_expand folds them into its per-block tail (kmc_expand_body)
+#if KMC_SYMM
+        {
+            u32 x = corr_won;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (x && kmc_lane() == 0) atomicAdd(&a.ctl->corr_won, (u64)x);
+            corr_won = 0;
+        }
+#endif
         if (probed | outside) {
 #if KMC_CHECKSUM
             u64 sm = csum, xr = cxor;
@@ -1714,12 +1869,13 @@ template <class M> struct KmcSink {
     // claimed: every distinct state is expanded exactly once, its fields are already extracted
     // there, and all 64 lanes hold a state to check.  (Checking winners inside the flush ran the
     // evaluation ~3x per tile with a third of the lanes useful and re-extracted every field.)
-    static KMC_DEV void report_violation(const KmcArgs& a, u32 bad, u64 fp) {
+    static KMC_DEV void report_violation(const KmcArgs& a, u32 bad, u64 fp, u32 deficit = 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (bad >> k & 1u) {
                 atomicAdd(&a.ctl->viol_count[k], 1ull);
                 atomicMax(&a.ctl->viol_fp_inv[k], ~fp);
+                if (deficit) atomicAdd(&a.ctl->corr_viol[k], (u64)deficit);
             }
     }
 
@@ -1736,7 +1892,11 @@ template <class M> struct KmcSink {
     }
 
     // Executed by the whole wave; lanes with valid=false only take part in the ballots.
-    static KMC_DEV void process(const KmcArgs& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta) {
+    // KMC_SYMM: t is the orbit representative of the successor `raw` (what is fingerprinted, claimed, staged and shipped);
+    // ENUM lists the successor itself with the representative's fingerprint, so that a trace replayed through kmc_successors
+    // is a real behaviour whose states are FOUND by the fingerprints of their representatives.  wdefl = the orbit's deficit.
+    static KMC_DEV void process(const KmcArgs& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta, const u64* raw = nullptr,
+                                u32 wdefl = 0) {
 #ifdef KMC_TEST_FP_BITS   // tests only: a fingerprint of that many bits, i.e. collisions on demand (the wide table's check
                           // word keeps its 64 bits) — tests/test_gpu_selfcheck_and_fp128.py
         const u64 fp = kmc_mix64((kmc_fingerprint<W>(t, a.seed) & ((1ull << (KMC_TEST_FP_BITS)) - 1)) + 0x9E3779B97F4A7C15ull) | 1ull;
@@ -1780,6 +1940,9 @@ template <class M> struct KmcSink {
             // a probe chain inside its 128-byte line before moving on were measured in round 3 and change nothing:
             // profiles/r03_probe_knobs.txt.)
             const bool isnew = valid && claim_any(a, t, fp, meta);
+#if KMC_SYMM
+            out.corr_won += isnew ? wdefl : 0u;
+#endif
             if (!(a.flags & KMC_FLAG_X_NOSTAGE)) out.push(a, isnew, t);
         } else if (a.mode == KMC_MODE_SHARDED) {
             // successors this shard owns take the local path at once (probe, claim, stage): only
@@ -1822,8 +1985,9 @@ template <class M> struct KmcSink {
                 const u64 pos = atomicAdd(&a.ctl->enum_count, 1ull);
                 if (pos < a.send_cap) {
                     u64* rec = a.send + pos * (u64)(W + 2);
+                    const u64* lst = raw ? raw : t;
 #pragma unroll
-                    for (int k = 0; k < W; ++k) rec[k] = t[k];
+                    for (int k = 0; k < W; ++k) rec[k] = lst[k];
                     rec[W] = fp;
                     rec[W + 1] = meta;
                 } else {
@@ -1858,6 +2022,9 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     u32 gen_lane = 0;         // lane k accumulates the successors generated by action kind k
     u32 extra_lane = 0;       // HAS_EXTRA: this lane's states' additional bindings with a repeated successor (kind EXTRA_KIND)
     u32 deadlocks = 0;
+#if KMC_SYMM
+    u32 extra_corr = 0;       // per lane: orbit deficits of the repeated bindings counted in extra_lane
+#endif
 #if KMC_PROFILE
     u64 prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 0 load+extract+inv 1 guards 2 effects+push 3 flush 4 tail 7 total
     const u64 t_kernel0 = __builtin_amdgcn_s_memtime();
@@ -1884,6 +2051,13 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         const bool dropped = (a.mode == KMC_MODE_LOCAL || a.mode == KMC_MODE_SHARDED) && wave0 == 0 && nflush == 0 && lane == 5;
         ++nflush;
         KmcSink<M>::process(a, out, lane < nv && !table_full && !dropped, t0, meta0);
+#elif KMC_SYMM
+        {
+            u64 tc[W];
+            u32 stab_t;
+            KmcSymm<M>::canon(t0, tc, stab_t);
+            KmcSink<M>::process(a, out, lane < nv && !table_full, tc, meta0, t0, KmcSymm<M>::deficit(stab_t));
+        }
 #else
         KmcSink<M>::process(a, out, lane < nv && !table_full, t0, meta0);
 #endif
@@ -1910,8 +2084,10 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             return;
         }
     }
-    __shared__ u32 kmc_tail[32];   // per block: generated[0..15], deadlocks, probed, won, outside, repeats (see the end)
-    if (threadIdx.x < 32) kmc_tail[threadIdx.x] = 0;
+    // per block: generated[0..15], deadlocks, probed, won, outside, repeats (see the end); KMC_SYMM: [32..47] corr_gen, 48 corr_dead,
+    // 49 corr_repeats, 50 corr_won
+    __shared__ u32 kmc_tail[64];
+    if (threadIdx.x < 64) kmc_tail[threadIdx.x] = 0;
     __syncthreads();
 #pragma clang loop unroll(disable)
     for (int sg = 0; sg < KMC_SEGS; ++sg) {
@@ -1969,12 +2145,19 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #endif
         const u64 parent = (a.flags & (KMC_FLAG_TRACE | KMC_FLAG_ENUM_MATCH)) ? kmc_fingerprint<W>(s, a.seed) : 0ull;
         typename M::Pre pre = M::extract(s);
+#if KMC_SYMM
+        // the expanded state is its orbit's representative; everything counted for it below stands for the whole orbit, less
+        // this deficit when some permutation fixes it (rare: the lanes with defl != 0 take the few extra steps)
+        const u32 defl = valid ? KmcSymm<M>::deficit(KmcSymm<M>::stabiliser(s)) : 0u;
+#else
+        const u32 defl = 0;
+#endif
 
         // Invariants of the states of THIS level (see KmcSink::report_violation)
         if (KMC_INV_MASK(a) && a.mode != KMC_MODE_ENUM && !(a.flags & KMC_FLAG_X_NOINV)) {
             const u32 bad = valid ? M::violated_pre(pre, KMC_INV_MASK(a)) : 0u;
             if (__ballot(bad != 0)) {
-                if (bad) KmcSink<M>::report_violation(a, bad, kmc_fingerprint<W>(s, a.seed));
+                if (bad) KmcSink<M>::report_violation(a, bad, kmc_fingerprint<W>(s, a.seed), defl);
             }
         }
 
@@ -2002,6 +2185,20 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #pragma unroll
         for (int h = 0; h < 2 * NW; ++h) nsucc += __popc(en32[h]);
         }
+#if KMC_SYMM
+        if constexpr (M::KIND_MAJOR && !M::RUNTIME_GUARDS) {
+            if (defl) {
+                kmc_static_for<0, M::NSEGS>([&](auto SS) {
+                    constexpr int sg = decltype(SS)::value;
+                    const typename M::KindBits kb = M::template seg_bits<sg>(en32);
+                    u32 c;
+                    if constexpr (sizeof(kb) == 8) c = (u32)__popcll(kb);
+                    else c = (u32)__popc(kb);
+                    if (c) atomicAdd(&kmc_tail[32 + M::seg_kind(sg)], defl * c);
+                });
+            }
+        }
+#endif
 
         KMC_T(tp2);
         KMC_TADD(1, tp1, tp2);
@@ -2035,6 +2232,9 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
                     }
                     if constexpr (sizeof(km) == 8) nsucc += (u32)__popcll(km);
                     else nsucc += (u32)__popc(km);
+#if KMC_SYMM
+                    if (defl && km) atomicAdd(&kmc_tail[32 + M::seg_kind(sg)], defl * (sizeof(km) == 8 ? (u32)__popcll(km) : (u32)__popc((u32)km)));
+#endif
                 } else {
                     km = M::template seg_bits<sg>(en32);
                 }
@@ -2063,6 +2263,9 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
                 });
                 const u32 n = __popcll(m);
                 if constexpr (M::HAS_EXTRA) extra_lane += e ? extra : 0u;
+#if KMC_SYMM
+                if constexpr (M::HAS_EXTRA) extra_corr += e ? extra * defl : 0u;
+#endif
                 gen_lane += (lane == (u32)k) ? n : 0u;
                 if (e) {
                     const u32 pos = (head + count + kmc_rank_in(m)) & (KMC_RING - 1);
@@ -2117,6 +2320,10 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             // the end of the kernel (a wave reduction in every leaf cost 7 cross-lane operations per dispatched leaf)
             if constexpr (M::HAS_EXTRA) extra_lane += e ? extra : 0u;
             gen_lane += (lane == (u32)kind) ? n : 0u;
+#if KMC_SYMM
+            if constexpr (M::HAS_EXTRA) extra_corr += e ? extra * defl : 0u;
+            if (e && defl) atomicAdd(&kmc_tail[32 + kind], defl);
+#endif
             bool keep = e;
             u64 mk = m;
             if constexpr (M::HAS_CONSTRAINT) {
@@ -2162,6 +2369,9 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             // Reducing over the wave first was tried: its twelve cross-lane moves and their temporaries pushed k_expand over
             // the 80-VGPR budget (107 VGPRs, 4 waves per SIMD) and the headline to 38.8 ms (profiles/r03_tail.txt)
             if (valid && nsucc == 0) atomicMax(&a.ctl->deadlock_fp_inv, ~kmc_fingerprint<W>(s, a.seed));
+#if KMC_SYMM
+            if (valid && nsucc == 0 && defl) atomicAdd(&kmc_tail[48], defl);
+#endif
         }
     }
     }
@@ -2196,7 +2406,36 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     const u32 mine = lane == 16 ? deadlocks : lane == 20 ? repeats : 0u;
 #endif
     if (lane >= 16 && mine) atomicAdd(&kmc_tail[lane], mine);
+#if KMC_SYMM
+    {
+        u32 cw = out.corr_won, cx = 0;
+        if constexpr (M::HAS_EXTRA) cx = extra_corr;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            cw += __shfl_xor(cw, off);
+            cx += __shfl_xor(cx, off);
+        }
+        out.corr_won = 0;
+        if (lane == 0) {
+            if (cw) atomicAdd(&kmc_tail[50], cw);
+            if constexpr (M::HAS_EXTRA) {
+                if (cx) {
+                    atomicAdd(&kmc_tail[49], cx);
+                    atomicAdd(&kmc_tail[32 + M::EXTRA_KIND], cx);   // the repeats are part of generated[EXTRA_KIND]
+                }
+            }
+        }
+    }
+#endif
     __syncthreads();
+#if KMC_SYMM
+    if (wib == 1 && lane < 19) {
+        const u32 v = kmc_tail[32 + lane];
+        u64* dst = lane < 16 ? &a.ctl->corr_gen[lane] : lane == 16 ? &a.ctl->corr_dead : lane == 17 ? &a.ctl->corr_repeats
+                 : &a.ctl->corr_won;
+        if (v) atomicAdd(dst, (u64)v);
+    }
+#endif
     if (wib == 0 && lane < 21) {
         const u32 v = kmc_tail[lane];
         u64* dst = lane < 16 ? &a.ctl->generated[lane] : lane == 16 ? &a.ctl->deadlock_count : lane == 17 ? &a.ctl->probed

@@ -109,7 +109,8 @@ bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::strin
     case KMC_FINITE_REPLICATED_LOG:
         *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, 0, 0, c.n_log_records);
         if (!lay->valid || c.n_replicas < 2) return false;
-        snprintf(buf, sizeof buf, "FiniteReplicatedLog_N%d_L%d_K%d", c.n_replicas, c.log_size, c.n_log_records);
+        snprintf(buf, sizeof buf, "FiniteReplicatedLog_N%d_L%d_K%d%s", c.n_replicas, c.log_size, c.n_log_records,
+                 c.symmetry ? "_sym" : "");
         *name = buf;
         snprintf(buf, sizeof buf, "KmcFiniteReplicatedLog<%d,%d,%d>", c.n_replicas, c.log_size, c.n_log_records);
         *inst = buf;
@@ -136,9 +137,10 @@ bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::strin
         if (lm < 0) return false;
         *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, c.max_records, c.max_leader_epoch, 0, lm);
         if (!lay->valid || c.n_replicas < 2) return false;
-        snprintf(buf, sizeof buf, "%s_N%d_L%d_R%d_E%d%s", MODEL_NAMES[c.model], c.n_replicas, c.log_size,
+        snprintf(buf, sizeof buf, "%s_N%d_L%d_R%d_E%d%s%s", MODEL_NAMES[c.model], c.n_replicas, c.log_size,
                  c.max_records, c.max_leader_epoch,
-                 lm == KMC_LAYOUT_TIGHT ? "_tight" : lm == KMC_LAYOUT_RM ? "_rm" : lm == KMC_LAYOUT_RMG ? "_rmg" : "");
+                 lm == KMC_LAYOUT_TIGHT ? "_tight" : lm == KMC_LAYOUT_RM ? "_rm" : lm == KMC_LAYOUT_RMG ? "_rmg" : "",
+                 c.symmetry ? "_sym" : "");
         *name = buf;
         snprintf(buf, sizeof buf, "KmcKafka<%d,%d,%d,%d,%d,%d>", c.model, c.n_replicas, c.log_size, c.max_records,
                  c.max_leader_epoch, lm);
@@ -232,11 +234,16 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
                                "L*bits(record)<=64, E<=7 (AsyncIsr: N<=6, MaxVersion<=7)", cfg.model, cfg.n_replicas, cfg.log_size,
                     cfg.max_records, cfg.max_leader_epoch, cfg.n_log_records);
     *kname = name;
+    if (cfg.symmetry && (!kmc_model_symmetric(cfg.model) || cfg.n_replicas > 4 || cfg.n_shards > 1))
+        return fail(KMC_E_ARG, "symmetry (orbit counting) is for the Kafka family and FiniteReplicatedLog with at most 4 replicas "
+                               "on one GPU: %s singles out a replica, or N = %d > 4, or n_shards = %d > 1",
+                    MODEL_NAMES[cfg.model], cfg.n_replicas, cfg.n_shards);
     // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_MIN_WAVES=5 -DKMC_PROFILE=1"
     std::vector<std::string> defines;
     std::string defines_key;
     std::string all_defines = getenv("KMC_JIT_DEFINES") ? getenv("KMC_JIT_DEFINES") : "";
     if (extra_options) all_defines += std::string(" ") + extra_options;
+    if (cfg.symmetry) all_defines += " -DKMC_SYMM=1";
     if (!all_defines.empty()) {
         const char* d = all_defines.c_str();
         std::string tok;
@@ -391,6 +398,9 @@ struct kmc_handle {
     bool witness_outside = false;      // the witness is a successor outside the state constraint:
     uint64_t witness_parent_fp = 0;    //   it is in no table; this is the expanded state it was generated from
     kmc_result res{};
+    // kmc_config.symmetry: the frontier / table hold one state per orbit; res.distinct and `levels` are the WEIGHTED
+    // (= plain-search) numbers, raw_levels the representatives per level; nfact = |Replicas|!
+    uint64_t nfact = 1;
     double t_start = 0;
     double dry_seconds = 0;
     uint64_t prof[8] = {0}, prof_dry[8] = {0};
@@ -587,6 +597,19 @@ int reset_run(kmc_handle* h) {
 //   and every claim the sink won must have been appended to the next frontier:       won = sum(next_count).
 // Round 1 met a build of k_expand that LOST successors between dispatch and sink; every counter the old
 // self-check compared is bumped before that point.  These two are taken on either side of it.
+// kmc_config.symmetry: a device counter counts orbit representatives and comes with the summed deficits of their orbits
+// (KmcLevelCtl::corr_*): the plain search's count is N! * raw - corr.
+uint64_t weighted(const kmc_handle* h, uint64_t raw, uint64_t corr) { return h->cfg.symmetry ? h->nfact * raw - corr : raw; }
+// states on the frontier, as the plain search counts them (the frontier is always a whole level)
+uint64_t queue_now(const kmc_handle* h) { return h->cfg.symmetry && !h->levels.empty() ? h->levels.back() : h->n_cur; }
+// a level of `produced` stored states enters the books
+void book_level(kmc_handle* h, uint64_t produced, const KmcLevelCtl& c) {
+    h->res.orbit_representatives += produced;
+    const uint64_t w = weighted(h, produced, c.corr_won);
+    h->res.distinct += w;
+    h->levels.push_back(w);
+}
+
 int check_conservation(kmc_handle* h, const KmcLevelCtl& c, uint64_t inserted) {
     if (c.err) return KMC_OK;   // a full table / frontier / send area stops probing and appending on purpose
     uint64_t gen = 0, appended = 0;
@@ -625,7 +648,7 @@ bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, con
                 r.violated_invariant = k;
                 r.violation_depth = h->level;
                 r.violation_fp = ~c.viol_fp_inv[k];
-                for (int j = 0; j < 4; ++j) r.violation_count[j] = c.viol_count[j];
+                for (int j = 0; j < 4; ++j) r.violation_count[j] = weighted(h, c.viol_count[j], c.corr_viol[j]);
                 if (parent_frontier && h->cfg.n_shards == 1) {
                     *rc = find_state(h, parent_frontier, parent_seg, r.violation_fp, &h->witness);
                     h->have_witness = *rc == KMC_OK;
@@ -653,11 +676,12 @@ bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, con
         }
     }
     for (int k = 0; k < KMC_MAX_KINDS; ++k) {
-        r.generated += c.generated[k];
-        r.action_generated[k] += c.generated[k];
+        const uint64_t g = weighted(h, c.generated[k], c.corr_gen[k]);
+        r.generated += g;
+        r.action_generated[k] += g;
     }
-    r.generated_repeats += c.repeats;
-    r.deadlock_states += c.deadlock_count;
+    r.generated_repeats += weighted(h, c.repeats, c.corr_repeats);
+    r.deadlock_states += weighted(h, c.deadlock_count, c.corr_dead);
     if (c.err & KMC_ERR_TABLE_FULL) { r.verdict = KMC_V_TABLE_FULL; return true; }
     if (c.err & (KMC_ERR_FRONTIER_FULL | KMC_ERR_SEND_FULL)) { r.verdict = KMC_V_FRONTIER_FULL; return true; }
     if (h->cfg.check_deadlock && c.deadlock_count && (r.verdict == KMC_V_OK || r.verdict == KMC_V_INVARIANT) &&
@@ -687,6 +711,19 @@ int do_begin(kmc_handle* h) {
     HIP_TRY(hipMemcpyAsync(h->scratch_host, h->scratch, (h->W + 1) * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->init_words.assign(h->scratch_host, h->scratch_host + h->W);
+    uint64_t init_orbit = 1;
+    if (h->cfg.symmetry) {
+        // Init is stored as its orbit's representative like every other state (the specs' Init is fixed by every
+        // permutation, KafkaReplication.tla:109-120 / FiniteReplicatedLog.tla:97 — then nothing changes and the orbit is 1)
+        unsigned long long c[KMC_MAXW] = {0}, w0[KMC_MAXW] = {0};
+        for (int k = 0; k < h->W; ++k) w0[k] = h->init_words[k];
+        int stab = 1;
+        kmc_canonical_state_generic(h->lay, w0, c, &stab);
+        init_orbit = h->nfact / (uint64_t)stab;
+        for (int k = 0; k < h->W; ++k) h->init_words[k] = h->scratch_host[k] = c[k];
+        h->scratch_host[h->W] = 0;
+        HIP_TRY(hipMemcpyAsync(h->scratch, h->scratch_host, (h->W + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    }
     const uint64_t fp0 = kmc_fingerprint_of(h, h->init_words.data());
     const bool mine = h->cfg.n_shards <= 1 || kmc_owner(fp0, (uint32_t)h->cfg.n_shards) == (uint32_t)h->cfg.shard_id;
     if (mine) {
@@ -701,8 +738,9 @@ int do_begin(kmc_handle* h) {
     if ((rc = read_ctl(h, 0))) return rc;
     h->n_cur = produced_segments(h, *h->ctl_host, h->seg_n);
     h->cur = 0;
-    h->res.distinct = h->n_cur;
-    h->levels.push_back(h->n_cur);
+    h->res.orbit_representatives = h->n_cur;
+    h->res.distinct = h->cfg.symmetry ? h->n_cur * init_orbit : h->n_cur;
+    h->levels.push_back(h->res.distinct);
     h->level = 1;
     h->res.depth = 1;
     return rc;
@@ -814,6 +852,9 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
         return get_code_object(h->cfg, "gfx950", &dummy, &name);  // produces the KMC_E_ARG message
     }
     h->W = h->lay.W;
+    h->nfact = h->cfg.symmetry ? (uint64_t)kmc_factorial(h->cfg.n_replicas) : 1;
+    if (h->cfg.symmetry && !kmc_model_symmetric(h->cfg.model))
+        return fail(KMC_E_ARG, "symmetry (orbit counting): %s singles out a replica or has none", MODEL_NAMES[h->cfg.model]);
     h->rec_words = h->W + (cfg->keep_trace ? 1 : 0);
     if (cfg->device == -1) return KMC_OK;  // host-only handle: pack/unpack/fingerprint, no device work
     int ndev = 0;
@@ -956,6 +997,18 @@ uint64_t kmc_fingerprint_of(kmc_handle* h, const uint64_t* words) {
     case 11: return kmc_fingerprint<11>(w, h->cfg.hash_seed);
     default: return kmc_fingerprint<12>(w, h->cfg.hash_seed);
     }
+}
+
+int kmc_canonical_state(kmc_handle* h, const uint64_t* words, uint64_t* representative, int32_t* stabiliser) {
+    if (!h || !words || !representative) return fail(KMC_E_ARG, "null argument");
+    if (!kmc_model_symmetric(h->lay.model)) return fail(KMC_E_ARG, "%s has no replica symmetry", MODEL_NAMES[h->lay.model]);
+    unsigned long long w[KMC_MAXW] = {0}, c[KMC_MAXW] = {0};
+    for (int k = 0; k < h->W; ++k) w[k] = words[k];
+    int stab = 1;
+    kmc_canonical_state_generic(h->lay, w, c, &stab);
+    for (int k = 0; k < h->W; ++k) representative[k] = c[k];
+    if (stabiliser) *stabiliser = stab;
+    return KMC_OK;
 }
 
 uint64_t kmc_canon_bytes(kmc_handle* h) {
@@ -1117,7 +1170,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
         if (!cb) return;
         kmc_level_info info{};
         info.depth = h->level;
-        info.new_states = h->n_cur;
+        info.new_states = queue_now(h);
         info.generated_total = r.generated;
         info.distinct_total = r.distinct;
         info.seconds = now_s() - h->t_start;
@@ -1140,10 +1193,12 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             c.deadlock_count = 0;
             c.err = 0;
             c.probed = c.won = c.outside = c.repeats = 0;   // an invariant-only pass: nothing was dispatched for the record
+            for (int k = 0; k < KMC_MAX_KINDS; ++k) c.corr_gen[k] = 0;
+            c.corr_dead = c.corr_repeats = c.corr_won = 0;
             absorb(h, c, h->frontier[h->cur], h->seg_n, &rc);
             if (rc) return rc;
             if (r.verdict == KMC_V_OK) r.verdict = KMC_V_LEVEL_LIMIT;
-            r.queue_left = h->n_cur;
+            r.queue_left = queue_now(h);
             break;
         }
         static const int shadow = getenv("KMC_SHADOW") ? atoi(getenv("KMC_SHADOW")) : 0;
@@ -1170,7 +1225,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
                 // only as long as its levels provably stay under it — each level adds at most min(fan x its input,
                 // frontier capacity) states.  (Without this a batch could run the table far past the limit before the
                 // host looked, and after such a stop h->cur / seg_n no longer described the device's frontier: ADVICE r2.)
-                const double room = 0.92 * (double)h->table_cap - (double)r.distinct;
+                const double room = 0.92 * (double)h->table_cap - (double)r.orbit_representatives;
                 uint64_t in = h->n_cur, fit = 0;
                 double sum = 0;
                 for (; fit < B; ++fit) {
@@ -1224,7 +1279,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
                 stop = absorb(h, c, h->frontier[h->cur], h->seg_n, &rc);
                 if (rc) return rc;
                 if (stop) {
-                    r.queue_left = h->n_cur;
+                    r.queue_left = queue_now(h);
                     done = true;
                     break;
                 }
@@ -1238,11 +1293,10 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
                 for (int sg = 0; sg < KMC_SEGS; ++sg) h->seg_n[sg] = new_seg[sg];
                 h->level++;
                 r.depth = h->level;
-                r.distinct += produced;
-                h->levels.push_back(produced);
-                if ((double)r.distinct > 0.92 * (double)h->table_cap && r.verdict == KMC_V_OK) {
+                book_level(h, produced, c);
+                if ((double)r.orbit_representatives > 0.92 * (double)h->table_cap && r.verdict == KMC_V_OK) {
                     r.verdict = KMC_V_TABLE_FULL;
-                    r.queue_left = h->n_cur;
+                    r.queue_left = queue_now(h);
                     stop = done = true;
                 }
             }
@@ -1334,7 +1388,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
         stop = absorb(h, c, h->frontier[h->cur], h->seg_n, &rc);
         if (rc) return rc;
         if (stop) {  // invariant (produced level rolled back), deadlock, table/frontier full
-            r.queue_left = h->n_cur;
+            r.queue_left = queue_now(h);
             break;
         }
         if (produced == 0) {
@@ -1346,13 +1400,12 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
         for (int sg = 0; sg < KMC_SEGS; ++sg) h->seg_n[sg] = new_seg[sg];
         h->level++;
         r.depth = h->level;
-        r.distinct += produced;
-        h->levels.push_back(produced);
+        book_level(h, produced, c);
         report();
         // stop before linear probing degenerates (sized for load <= 0.5, still fine at 0.9)
-        if ((double)r.distinct > 0.92 * (double)h->table_cap && r.verdict == KMC_V_OK) {
+        if ((double)r.orbit_representatives > 0.92 * (double)h->table_cap && r.verdict == KMC_V_OK) {
             r.verdict = KMC_V_TABLE_FULL;
-            r.queue_left = h->n_cur;
+            r.queue_left = queue_now(h);
             break;
         }
     }
@@ -1478,6 +1531,11 @@ int kmc_contains(kmc_handle* h, const uint64_t* words, int32_t* present) {
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     uint64_t slot = 0;
+    uint64_t rep_words[KMC_MAXW];
+    if (h->cfg.symmetry) {   // the table holds one state per orbit: ask for this state's representative
+        kmc_canonical_state(h, words, rep_words, nullptr);
+        words = rep_words;
+    }
     const int rc = table_lookup(h, kmc_fingerprint_of(h, words), &slot);
     *present = rc == KMC_OK;
     g_err.clear();
@@ -1569,7 +1627,7 @@ int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap
 // predecessor table when traces are kept) and the current frontier's planes, segment by segment.
 namespace {
 struct CkptHeader {
-    char magic[8];          // "KMCCKPT3"
+    char magic[8];          // "KMCCKPT4"
     kmc_config cfg;         // pointers inside are not meaningful in the file
     uint64_t table_cap, fcap, seg_cap, level, n_cur, n_levels, w, has_pred;
     uint64_t layout_form;   // KmcLayout::rm of the packed states in the file (0 tight, 1 / 2 replica-major): the same constants
@@ -1619,7 +1677,7 @@ int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     FILE* f = fopen(path, "wb");
     if (!f) return fail(KMC_E_ARG, "cannot open %s for writing", path);
     CkptHeader hd{};
-    memcpy(hd.magic, "KMCCKPT3", 8);
+    memcpy(hd.magic, "KMCCKPT4", 8);
     hd.cfg = h->cfg;
     hd.cfg.cache_dir = nullptr;
     hd.table_cap = h->table_cap; hd.fcap = h->fcap; hd.seg_cap = h->seg_cap; hd.level = h->level;
@@ -1647,7 +1705,7 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
     if (!f) return fail(KMC_E_ARG, "cannot open %s", path);
     CkptHeader hd{};
     int rc = KMC_OK;
-    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT3", 8) != 0)
+    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT4", 8) != 0)
         rc = fail(KMC_E_ARG, "%s is not a checkpoint of this version", path);
     const kmc_config& a = hd.cfg;
     const kmc_config& b = h->cfg;
@@ -1655,9 +1713,10 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
                 a.max_records != b.max_records || a.max_leader_epoch != b.max_leader_epoch ||
                 a.n_log_records != b.n_log_records || a.max_id != b.max_id || a.hash_seed != b.hash_seed ||
                 a.n_shards != b.n_shards || a.shard_id != b.shard_id || hd.w != (uint64_t)h->W ||
-                hd.layout_form != (uint64_t)h->lay.rm || (a.wide_fingerprint != 0) != (b.wide_fingerprint != 0)))
+                hd.layout_form != (uint64_t)h->lay.rm || (a.wide_fingerprint != 0) != (b.wide_fingerprint != 0) ||
+                (a.symmetry != 0) != (b.symmetry != 0)))
         rc = fail(KMC_E_ARG, "checkpoint was taken for a different model / constants / hash seed / shard / fingerprint width / "
-                             "state layout");
+                             "state layout / symmetry setting");
     if (!rc && (hd.table_cap != h->table_cap || hd.fcap != h->fcap || hd.seg_cap != h->seg_cap ||
                 hd.has_pred != (uint64_t)(h->pred != nullptr)))
         rc = fail(KMC_E_ARG, "checkpoint capacities differ: open the handle with table_capacity=%llu frontier_capacity=%llu keep_trace=%d",
@@ -1684,7 +1743,9 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
             seg_sum += segs[sg];
         }
         for (uint64_t x : lv) lv_sum += x;
-        if (!rc && (seg_sum != hd.n_cur || lv.back() != hd.n_cur || lv_sum != saved.distinct || saved.distinct > h->table_cap ||
+        // (under symmetry the level sizes and `distinct` are the weighted numbers; the stored states are orbit_representatives)
+        if (!rc && (seg_sum != hd.n_cur || (!h->cfg.symmetry && lv.back() != hd.n_cur) || lv_sum != saved.distinct ||
+                    saved.orbit_representatives > h->table_cap || saved.orbit_representatives > saved.distinct ||
                     saved.verdict != KMC_V_LEVEL_LIMIT || saved.state_words != (uint64_t)h->W ||
                     saved.table_capacity != h->table_cap || saved.frontier_capacity != h->fcap))
             rc = fail(KMC_E_ARG, "checkpoint body is inconsistent with its header / this handle");
@@ -1714,6 +1775,7 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
 // ---- level-step interface ---------------------------------------------------------------
 int kmc_step_begin(kmc_handle* h) {
     if (!h) return fail(KMC_E_ARG, "null handle");
+    if (h->cfg.symmetry) return fail(KMC_E_STATE, "symmetry (orbit counting) runs through kmc_run; the level-step interface does not weigh its counts");
     if (!h->table) return fail(KMC_E_STATE, "host-only handle (device = -1) cannot run");
     HIP_TRY(hipSetDevice(h->cfg.device));
     int rc = do_begin(h);
@@ -1823,6 +1885,7 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
     h->level++;
     if (produced) r.depth = h->level;
     r.distinct += produced;
+    r.orbit_representatives += produced;
     h->levels.push_back(produced);
     h->step_expanded = false;
     r.seconds_total = now_s() - h->t_start;

@@ -267,3 +267,99 @@ KMC_HD inline void kmc_setbits(unsigned long long* w, int off, int bits, unsigne
         w[i + 1] = (w[i + 1] & ~(m >> lo)) | ((val & m) >> lo);
     }
 }
+
+// OR a (masked) value into a field that is still zero: what building a state from scratch needs (no read-modify-write mask)
+KMC_HD inline void kmc_orbits(unsigned long long* w, int off, int bits, unsigned long long val) {
+    if (bits == 0) return;
+    const int i = off >> 6, s = off & 63;
+    w[i] |= val << s;
+    if (s + bits > 64) w[i + 1] |= val >> (64 - s);
+}
+
+// ---- permutations of Replicas (symmetry reduction with orbit counting: kmc_config.symmetry, kmc_device.h KmcSymm) ----
+// The specs never tell two replicas apart (KafkaReplication.tla quantifies over Replicas everywhere, :158-310; Init :109-120
+// treats them alike), so a permutation of Replicas maps reachable states to reachable states, successors to successors and
+// keeps every invariant.  A permutation acts on a packed state by moving the per-replica fields and renaming the replica
+// ids held in fields (leader: 0 = None | index + 1) and the isr bit masks.
+KMC_HD constexpr int kmc_factorial(int n) {
+    int f = 1;
+    for (int i = 2; i <= n; ++i) f *= i;
+    return f;
+}
+// image of r under the P-th permutation of 0..N-1, permutations ranked by the lexicographic order of their image
+// sequences (P = 0 is the identity)
+KMC_HD constexpr int kmc_perm_image(int N, int P, int r) {
+    int avail[KMC_MAXN] = {};
+    for (int i = 0; i < N; ++i) avail[i] = i;
+    int n = N, img = 0;
+    for (int pos = 0; pos <= r; ++pos) {
+        const int f = kmc_factorial(N - 1 - pos);
+        const int idx = P / f;
+        P %= f;
+        img = avail[idx];
+        for (int j = idx; j + 1 < n; ++j) avail[j] = avail[j + 1];
+        --n;
+    }
+    return img;
+}
+// models whose state is a function of Replicas alone (AsyncIsr singles out `Leader`, AsyncIsr.tla:24,29)
+KMC_HD constexpr bool kmc_model_symmetric(int model) {
+    return model == KMC_MODEL_FINITE_REPLICATED_LOG || (model >= KMC_MODEL_TRUNCATE_TO_HW && model <= KMC_MODEL_KIP320_FIRST_TRY);
+}
+KMC_HD inline unsigned long long kmc_permute_mask(int N, const int* img, unsigned long long m) {
+    unsigned long long out = 0;
+    for (int i = 0; i < N; ++i)
+        if (m >> i & 1ull) out |= 1ull << img[i];
+    return out;
+}
+// t = the state s with replica r renamed img[r] — the run-time-layout form (host engine: witness of the initial state's
+// orbit, kmc_contains / kmc_canonical_state; the device's compile-time form is KmcSymm::permute<P>)
+KMC_HD inline void kmc_permute_state(const KmcLayout& y, const int* img, const unsigned long long* s, unsigned long long* t) {
+    for (int k = 0; k < y.W; ++k) t[k] = 0;
+    const bool kafka = y.model != KMC_MODEL_FINITE_REPLICATED_LOG;
+    for (int r = 0; r < y.N; ++r) {
+        const int d = img[r];
+        kmc_orbits(t, y.log_off[d], y.BR * y.L, kmc_getbits(s, y.log_off[r], y.BR * y.L));
+        kmc_orbits(t, y.end_off[d], y.BO, kmc_getbits(s, y.end_off[r], y.BO));
+        if (!kafka) continue;
+        kmc_orbits(t, y.hw_off[d], y.BO, kmc_getbits(s, y.hw_off[r], y.BO));
+        kmc_orbits(t, y.ep_off[d], y.BE, kmc_getbits(s, y.ep_off[r], y.BE));
+        const unsigned long long l1 = kmc_getbits(s, y.ldr_off[r], y.BL);
+        kmc_orbits(t, y.ldr_off[d], y.BL, l1 == 0 || l1 > (unsigned long long)y.N ? l1 : (unsigned long long)img[l1 - 1] + 1);
+        kmc_orbits(t, y.isr_off[d], y.BI, kmc_permute_mask(y.N, img, kmc_getbits(s, y.isr_off[r], y.BI)));
+    }
+    if (!kafka) return;
+    kmc_orbits(t, y.nextrec_off, y.BNR, kmc_getbits(s, y.nextrec_off, y.BNR));
+    kmc_orbits(t, y.nextep_off, y.BE, kmc_getbits(s, y.nextep_off, y.BE));
+    kmc_orbits(t, y.qep_off, y.BE, kmc_getbits(s, y.qep_off, y.BE));
+    const unsigned long long ql = kmc_getbits(s, y.qldr_off, y.BL);
+    kmc_orbits(t, y.qldr_off, y.BL, ql == 0 || ql > (unsigned long long)y.N ? ql : (unsigned long long)img[ql - 1] + 1);
+    kmc_orbits(t, y.qisr_off, y.BI, kmc_permute_mask(y.N, img, kmc_getbits(s, y.qisr_off, y.BI)));
+    for (int e = 0; e <= y.E; ++e) {
+        const unsigned long long rl = kmc_getbits(s, y.reqldr_off[e], y.BL);
+        kmc_orbits(t, y.reqldr_off[e], y.BL, rl == 0 || rl > (unsigned long long)y.N ? rl : (unsigned long long)img[rl - 1] + 1);
+        kmc_orbits(t, y.reqisr_off[e], y.BI, kmc_permute_mask(y.N, img, kmc_getbits(s, y.reqisr_off[e], y.BI)));
+    }
+}
+// The representative of s's orbit: the smallest image under all N! permutations, states compared as the tuple
+// (word 0, word 1, ...) of unsigned 64-bit values.  *stab = the permutations that fix s (the orbit has N! / *stab states).
+KMC_HD inline void kmc_canonical_state_generic(const KmcLayout& y, const unsigned long long* s, unsigned long long* c, int* stab) {
+    const int nf = kmc_factorial(y.N);
+    unsigned long long t[KMC_MAXW];
+    int img[KMC_MAXN];
+    int cnt = 0;
+    for (int P = 0; P < nf; ++P) {
+        for (int r = 0; r < y.N; ++r) img[r] = kmc_perm_image(y.N, P, r);
+        kmc_permute_state(y, img, s, t);
+        int cmp = 0;   // t against c
+        if (P == 0) cmp = -1;
+        for (int k = 0; k < y.W && cmp == 0; ++k) cmp = t[k] < c[k] ? -1 : t[k] > c[k] ? 1 : 0;
+        if (cmp < 0) {
+            for (int k = 0; k < y.W; ++k) c[k] = t[k];
+            cnt = 1;
+        } else if (cmp == 0) {
+            ++cnt;
+        }
+    }
+    if (stab) *stab = cnt;
+}

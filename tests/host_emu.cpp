@@ -88,6 +88,17 @@ template <class M> struct Ops {
         else return 1;
     }
     static int words() { return M::W; }
+    // KmcSymm<M>::canon / stabiliser (the compile-time permutations the KMC_SYMM kernels use): the orbit representative
+    // of one packed state and the order of its stabiliser; -1 where the model or N has no symmetry reduction
+    static int canon(const u64* s, u64* c) {
+        if constexpr (kmc_model_symmetric(M::Y.model) && M::Y.N <= 4) {
+            u32 stab = 0;
+            KmcSymm<M>::canon(s, c, stab);
+            return KmcSymm<M>::stabiliser(s) == stab ? (int)stab : -2;
+        } else {
+            return -1;
+        }
+    }
 };
 
 struct Entry {
@@ -98,22 +109,24 @@ struct Entry {
     int (*in_model)(const u64*);
     int (*words)();
     int (*kmcheck)(const u64*, int*, int*);
+    int (*canon)(const u64*, u64*);
 };
 
 #define KAFKA_LM(MODEL, N, L, R, E, LM) \
     {MODEL, N, L, R, E, 0, LM, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::succ, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::violated, \
      Ops<KmcKafka<MODEL, N, L, R, E, LM>>::init, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::in_model, \
-     Ops<KmcKafka<MODEL, N, L, R, E, LM>>::words, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::kmcheck}
+     Ops<KmcKafka<MODEL, N, L, R, E, LM>>::words, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::kmcheck, \
+     Ops<KmcKafka<MODEL, N, L, R, E, LM>>::canon}
 #define KAFKA(MODEL, N, L, R, E) KAFKA_LM(MODEL, N, L, R, E, KMC_LAYOUT_AUTO)
 #define ASYNC(N, MO, V) \
     {KMC_MODEL_ASYNC_ISR, N, MO, 0, V, 0, 0, Ops<KmcAsyncIsr<N, MO, V>>::succ, Ops<KmcAsyncIsr<N, MO, V>>::violated, \
      Ops<KmcAsyncIsr<N, MO, V>>::init, Ops<KmcAsyncIsr<N, MO, V>>::in_model, Ops<KmcAsyncIsr<N, MO, V>>::words, \
-     Ops<KmcAsyncIsr<N, MO, V>>::kmcheck}
+     Ops<KmcAsyncIsr<N, MO, V>>::kmcheck, Ops<KmcAsyncIsr<N, MO, V>>::canon}
 #define FRL(N, L, K) \
     {KMC_MODEL_FINITE_REPLICATED_LOG, N, L, 0, 0, K, 0, Ops<KmcFiniteReplicatedLog<N, L, K>>::succ, \
      Ops<KmcFiniteReplicatedLog<N, L, K>>::violated, Ops<KmcFiniteReplicatedLog<N, L, K>>::init, \
      Ops<KmcFiniteReplicatedLog<N, L, K>>::in_model, Ops<KmcFiniteReplicatedLog<N, L, K>>::words, \
-     Ops<KmcFiniteReplicatedLog<N, L, K>>::kmcheck}
+     Ops<KmcFiniteReplicatedLog<N, L, K>>::kmcheck, Ops<KmcFiniteReplicatedLog<N, L, K>>::canon}
 
 const Entry TABLE[] = {
     KAFKA(KMC_MODEL_TRUNCATE_TO_HW, 3, 2, 2, 2), KAFKA(KMC_MODEL_KIP101, 3, 2, 2, 2), KAFKA(KMC_MODEL_KIP279, 3, 2, 2, 2),
@@ -145,6 +158,9 @@ const Entry TABLE[] = {
     KAFKA_LM(KMC_MODEL_KIP101, 3, 2, 2, 2, KMC_LAYOUT_RMG), KAFKA_LM(KMC_MODEL_KIP320_FIRST_TRY, 3, 2, 2, 2, KMC_LAYOUT_RMG),
     KAFKA_LM(KMC_MODEL_TRUNCATE_TO_HW, 6, 1, 1, 1, KMC_LAYOUT_RMG), KAFKA_LM(KMC_MODEL_KIP279, 7, 1, 1, 0, KMC_LAYOUT_RMG),
     KAFKA(KMC_MODEL_KIP279, 5, 2, 2, 1), KAFKA(KMC_MODEL_KIP320, 7, 8, 8, 3),
+    // small enough for the orbit-counting search to be replayed state by state on the CPU (tests/test_symmetry_cpu.py)
+    KAFKA(KMC_MODEL_TRUNCATE_TO_HW, 3, 2, 2, 1), KAFKA(KMC_MODEL_KIP101, 3, 2, 2, 1), KAFKA(KMC_MODEL_KIP320, 3, 2, 2, 1),
+    KAFKA(KMC_MODEL_KIP320_FIRST_TRY, 3, 2, 2, 1), KAFKA(KMC_MODEL_KIP320, 4, 1, 1, 1), KAFKA(KMC_MODEL_KIP279, 2, 2, 2, 2),
     ASYNC(3, 2, 2), ASYNC(4, 2, 2), ASYNC(2, 3, 7), ASYNC(1, 4, 0),
     FRL(2, 4, 2), FRL(3, 2, 2),
 };
@@ -255,6 +271,20 @@ int emu_init(int model, int N, int L, int R, int E, int K, u64* words) {
 int emu_kind_major_check(int model, int N, int L, int R, int E, int K, const u64* state, int* checked, int* bad) {
     const Entry* e = find(model, N, L, R, E, K);
     return e ? e->kmcheck(state, checked, bad) : -1;
+}
+// the orbit representative of one state under the permutations of Replicas (device form); returns the stabiliser's order,
+// -1 when the configuration has no symmetry reduction, -2 when canon and stabiliser disagree, -3 for an unknown configuration
+int emu_canon(int model, int N, int L, int R, int E, int K, const u64* state, u64* out) {
+    const Entry* e = find(model, N, L, R, E, K);
+    return e ? e->canon(state, out) : -3;
+}
+// ... and the run-time-layout form the host engine uses (kmc_layout.h)
+int emu_canon_generic(int model, int N, int L, int R, int E, int K, const u64* state, u64* out) {
+    const KmcLayout y = kmc_make_layout(model, N, L, R, E, K, g_lm);
+    if (!y.valid || !kmc_model_symmetric(model)) return -1;
+    int stab = 0;
+    kmc_canonical_state_generic(y, state, out, &stab);
+    return stab;
 }
 int emu_in_model(int model, int N, int L, int R, int E, int K, const u64* state) {
     const Entry* e = find(model, N, L, R, E, K);

@@ -34,6 +34,8 @@ def lib():
         l.emu_kafka_reference.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_uint64), C.c_uint]
         l.emu_state_bits.argtypes = six
         l.emu_in_model.argtypes = six + [C.POINTER(C.c_uint64)]
+        l.emu_canon.argtypes = six + [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        l.emu_canon_generic.argtypes = six + [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         l.emu_kind_major_check.argtypes = six + [C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = l
     return _lib
@@ -117,3 +119,13 @@ def kafka_reference(cfg6, words, mask):
 
 def state_bits(cfg6):
     return lib().emu_state_bits(*cfg6[:6])
+
+
+def canon(cfg6, words, generic=False):
+    """(stabiliser order, representative words) of a state's orbit under the permutations of Replicas: KmcSymm<M>::canon
+    (the device's compile-time form) or, generic=True, kmc_canonical_state_generic (the host engine's run-time form)."""
+    W = lib().emu_words(*cfg6[:6])
+    out = (C.c_uint64 * W)()
+    f = lib().emu_canon_generic if generic else lib().emu_canon
+    st = f(*cfg6[:6], (C.c_uint64 * W)(*words), out)
+    return st, tuple(int(x) for x in out)

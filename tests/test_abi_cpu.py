@@ -35,7 +35,7 @@ def test_struct_sizes_match_header_layout():
     # kmc_config: 6*i32 + i64 + u32 + 6*i32 + (pad) + 5*u64 + ptr + 2*i32 ; kmc_result: see header
     assert C.sizeof(nat.KmcConfig) == 120
     assert C.sizeof(nat.KmcLevelInfo) == 40 + 8 * 16 + 32 + 32 + 32 + 32 + 8 + 8 + 8
-    assert C.sizeof(nat.KmcResult) == 8 * 4 + 8 + 8 + 32 + 8 + 8 + 8 * 16 + 8 * 3 + 16 + 8 + 16 + 8
+    assert C.sizeof(nat.KmcResult) == 8 * 4 + 8 + 8 + 32 + 8 + 8 + 8 * 16 + 8 * 3 + 16 + 8 + 16 + 8 + 8
 
 
 def test_names():
