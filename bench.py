@@ -178,10 +178,12 @@ def cpu_baseline(c, budget_states, total_states):
     return out
 
 
-def run_single(c, steps, warmup):
+def run_single(c, steps, warmup, symmetry=False):
     import kafka_specification_amd as kmc
-    cfg = kmc.CheckerConfig(**c, device=0, table_capacity=int(os.environ.get("KMC_BENCH_TABLE", 1 << 30)),
-                            frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", 1 << 26)),
+    # (under symmetry the seen-set and the frontiers hold one state per orbit: a quarter of the slots keeps the same load)
+    cfg = kmc.CheckerConfig(**c, device=0, symmetry=symmetry,
+                            table_capacity=int(os.environ.get("KMC_BENCH_TABLE", (1 << 28) if symmetry else (1 << 30))),
+                            frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", (1 << 24) if symmetry else (1 << 26))),
                             wide_fingerprint=os.environ.get("KMC_BENCH_FP128", "0") == "1")   # tuning: 128-bit entries
     results = []
     with kmc.ModelChecker(cfg) as mc:
@@ -226,6 +228,10 @@ def main():
     ap.add_argument("--level-budget", type=int, default=0, metavar="LEVELS",
                     help="stop after LEVELS BFS levels and report states/s over that budget with \"exhausted\": false "
                          "(SURVEY section 8d for configurations nobody can exhaust: BASELINE config 5 = --workload Kip320,7,8,8,3)")
+    ap.add_argument("--symmetry", action="store_true",
+                    help="the timed region runs the orbit-counting search (kmc_config.symmetry) instead of the plain one: for "
+                         "profiling that kernel; the default line times the plain search and reports orbit counting beside it")
+    ap.add_argument("--no-orbit-counting", action="store_true", help="skip the orbit_counting leg of the default line")
     ap.add_argument("--backend", default=os.environ.get("KMC_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
                     help="process-group backend of the N>1 leg: nccl (= RCCL, the product) or gloo (CPU launch-path test)")
     a = ap.parse_args()
@@ -255,9 +261,9 @@ def main():
         results, dt, extra = bench_sharded(c, a.steps, a.warmup, backend=a.backend)
         scaling, parallelism = "strong", f"fingerprint-sharded x{world}, all-to-all per BFS level"
     else:
-        results, dt = run_single(c, a.steps, a.warmup)
+        results, dt = run_single(c, a.steps, a.warmup, symmetry=a.symmetry)
         extra = {}
-        scaling, parallelism = "strong", "1 GPU"
+        scaling, parallelism = "strong", "1 GPU" + (", orbit counting over the permutations of Replicas" if a.symmetry else "")
     if rank != 0:
         return
 
@@ -352,6 +358,33 @@ def main():
                              "nor more waves per SIMD shorten it (profiles/r02_ablation.txt, r02_occupancy_sweep.txt)"},
         "device": device_info(),
     }
+    if (world == 1 and not a.symmetry and not a.no_orbit_counting and not a.level_budget and c["n_replicas"] <= 4
+            and r.verdict == "ok"):
+        # The same check with symmetry reduction by orbit counting (kmc_config.symmetry): one stored
+        # state per orbit of the permutations of Replicas, every count weighted by the orbit's size.  It must report the
+        # plain run's numbers — compared here, count by count and level by level — and is timed the same way; it is NOT
+        # `value` (SURVEY rules TLC's SYMMETRY out because it changes the counts; this one does not, but it is another search).
+        sres, sdt = run_single(c, a.steps, a.warmup, symmetry=True)
+        sr = sres[-1]
+        sk = sum(x.seconds_expand for x in sres) / len(sres)
+        same = ((sr.verdict, sr.distinct, sr.generated, sr.depth, sr.levels, sr.action_generated, sr.deadlock_states,
+                 sr.generated_repeats) ==
+                (r.verdict, r.distinct, r.generated, r.depth, r.levels, r.action_generated, r.deadlock_states,
+                 r.generated_repeats))
+        s_alg = alg_bytes_per_state * sr.orbit_representatives
+        out["orbit_counting"] = {
+            "value": sum(x.distinct for x in sres) / sdt, "unit": "distinct states/s", "ms_per_step": 1e3 * sdt / a.steps,
+            "time_to_exhaustive_s": sdt / a.steps, "speedup_over_plain": (dt / a.steps) / (sdt / a.steps),
+            "stored_states": sr.orbit_representatives, "distinct_states": sr.distinct, "states_generated": sr.generated,
+            "depth": sr.depth, "every_count_equals_the_plain_run": same,
+            "matches_oracle_golden": None if exp is None else (sr.distinct == exp["distinct"] and sr.generated == exp["generated"]
+                                                               and sr.depth == exp["depth"]),
+            "kernel_seconds_per_step": sk, "launches_per_step": sr.expand_launches,
+            "roofline": {"bound": "hbm", "achieved": s_alg / max(sk, 1e-12) / 1e9, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
+                         "frac": s_alg / max(sk, 1e-12) / HBM_PEAK_BPS,
+                         "note": "algorithmic bytes of the STORED states (the same per-state figure) over this search's "
+                                 "k_expand time; the kernel is instruction-bound here (the representative of every successor "
+                                 "is the smallest of its images under the permutations: profiles/r03_symmetry.txt)"}}
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(c, a.cpu_states or max(1_000_000, distinct // 4), distinct)
     print(json.dumps(out))

@@ -1,7 +1,7 @@
 // kmc_cli.cpp — native `tlc`-shaped front end over the C ABI (include/kmc.h); the C++ twin of
 // kafka_specification_amd/tlc.py, for hosts without Python/torch.
 //
-//   tlc [-config X.cfg] [-deadlock] [-continue] [-workers N] [-fp SEED] [-fp128] [-fpcheck] [-verify] [-force] [-table SLOTS]
+//   tlc [-config X.cfg] [-deadlock] [-continue] [-workers N] [-fp SEED] [-fp128] [-symmetry] [-fpcheck] [-verify] [-force] [-table SLOTS]
 //       [-frontier STATES] [-device D] [-notrace] Spec.tla
 //
 // [TLC-recall] flag names and output lines follow tlc2.TLC; TLC itself is not part of the
@@ -440,6 +440,7 @@ int main(int argc, char** argv) {
         else if (a == "-notrace") c.keep_trace = 0;
         else if (a == "-fpcheck") fpcheck = true;
         else if (a == "-fp128") c.wide_fingerprint = 1;  // 128-bit seen-set entries: fingerprint + independent check word
+        else if (a == "-symmetry") c.symmetry = 1;  // orbit counting: one stored state per orbit of the permutations of Replicas
         else if (a == "-force") force = true;
         else if (a == "-verify") setenv("KMC_VERIFY", "1", 1);  // every level is regenerated by a second build of the kernels
         else if (const char* why = tlc_ignored_flag(a)) fprintf(stderr, "Note: %s is accepted for compatibility and ignored (%s)\n", a.c_str(), why);
@@ -605,16 +606,24 @@ int main(int argc, char** argv) {
            (unsigned long long)r.distinct, (unsigned long long)r.queue_left);
     printf("The depth of the complete state graph search is %llu.\n", (unsigned long long)r.depth);
     // TLC's closing estimate [TLC-recall: "calculated (optimistic)" = distinct x (generated - distinct) / 2^64]
+    uint64_t col_distinct = r.distinct, col_generated = r.generated;   // what the seen-set holds / was probed with
+    if (c.symmetry) {
+        printf("Symmetry reduction (orbit counting over the permutations of Replicas): %llu states were stored and expanded, one "
+               "per orbit; every count above is the plain search's.\n", (unsigned long long)r.orbit_representatives);
+        // the seen-set holds the representatives: they are what can collide
+        col_generated = r.distinct ? (uint64_t)((double)r.generated * (double)r.orbit_representatives / (double)r.distinct) : r.generated;
+        col_distinct = r.orbit_representatives;
+    }
     if (c.wide_fingerprint) {
         printf("The seen-set stores 128 bits per state (the fingerprint and an independent check word); probability that two "
                "distinct states were merged:\n");
-        printf("  birthday bound on the stored entries:  val = %.2E\n", (double)r.distinct * (double)r.distinct / std::pow(2.0, 129));
+        printf("  birthday bound on the stored entries:  val = %.2E\n", (double)col_distinct * (double)col_distinct / std::pow(2.0, 129));
     } else {
         printf("The seen-set stores 64-bit fingerprints; estimates of the probability that not all reachable states were checked "
                "because two distinct states had the same fingerprint:\n");
         printf("  calculated (optimistic):  val = %.2E\n",
-               (double)r.distinct * (double)(r.generated > r.distinct ? r.generated - r.distinct : 0) / std::pow(2.0, 64));
-        printf("  birthday bound on the stored fingerprints:  val = %.2E\n", (double)r.distinct * (double)r.distinct / std::pow(2.0, 65));
+               (double)col_distinct * (double)(col_generated > col_distinct ? col_generated - col_distinct : 0) / std::pow(2.0, 64));
+        printf("  birthday bound on the stored fingerprints:  val = %.2E\n", (double)col_distinct * (double)col_distinct / std::pow(2.0, 65));
     }
     if (fpcheck) {  // a collision moves with the seed: equal counts under two seeds make a silent loss very unlikely
         kmc_close(h);

@@ -1514,8 +1514,11 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
 // reports is weighted by the orbit's size N! / |stabiliser|: distinct states, states per level, generated per disjunct,
 // deadlocks and violating states all come out as the numbers of the plain search (and of TLC without SYMMETRY), from
 // ~1/N! of the probes.  (TLC's own SYMMETRY reports the REDUCED counts — SURVEY.md rules that out; this does not change them.)
-// permute<P> is the compile-time form of kmc_permute_state (kmc_layout.h): fields move between compile-time offsets, the
-// replica ids inside fields are renamed through constants indexed by shifts.
+// permute<P> is the compile-time form of kmc_permute_state (kmc_layout.h): fields move between compile-time offsets.  The
+// replica ids inside a state sit in (leader, isr) PAIRS — one per replica, one in quorumState, one per LeaderAndIsr request
+// — and a pair's images under ALL the permutations come from one table lookup (LDS in the kernels): entry idx = leader |
+// isr << BL holds the renamed pair for PER permutations per 32-bit word (all six at three replicas), so that a permutation
+// costs one bit-field extract and one insert per pair instead of two shift-indexed constant lookups each.
 template <class M> struct KmcSymm {
     static constexpr KmcLayout Y = M::Y;
     static constexpr int N = Y.N, W = Y.W;
@@ -1523,35 +1526,42 @@ template <class M> struct KmcSymm {
     static constexpr int NFACT = kmc_factorial(N);
     static_assert(kmc_model_symmetric(Y.model), "this model singles out a replica: no symmetry reduction");
     static_assert(N <= 4, "orbit representatives are found by trying all N! permutations: N <= 4");
-    static constexpr u32 ML = (1u << Y.BL) - 1, MI = (1u << Y.BI) - 1;
+    static constexpr int PB = KAFKA ? Y.BL + Y.BI : 1;       // bits of a (leader, isr) pair: 5 at N = 3, 7 at N = 4
+    static constexpr int PER = 32 / PB;                      // images per table word
+    static constexpr int NG = (NFACT + PER - 1) / PER;       // table words per pair value
+    static constexpr int TABLE_WORDS = KAFKA ? (NG << PB) : 1;
+    static constexpr int NPAIR = KAFKA ? N + 1 + (Y.E + 1) : 0;
+    static constexpr u32 MP = (1u << PB) - 1, ML = (1u << Y.BL) - 1;
 
-    // leader fields hold 0 (None) or index + 1: entry v of the table is the renamed value
-    static constexpr u64 ldr_table(int P) {
-        u64 t = 0;
-        for (int v = 1; v <= N; ++v) t |= (u64)(kmc_perm_image(N, P, v - 1) + 1) << (v * Y.BL);
+    // the pair idx with every replica in it renamed by permutation P (leader: 0 = None or index + 1; isr: a bit mask)
+    static KMC_HD constexpr u32 pair_image(int P, u32 idx) {
+        const u32 l = idx & ML, m = idx >> Y.BL;
+        const u32 pl = (l == 0 || l > (u32)N) ? l : (u32)kmc_perm_image(N, P, (int)l - 1) + 1;
+        u32 pm = 0;
+        for (int i = 0; i < N; ++i)
+            if (m >> i & 1u) pm |= 1u << kmc_perm_image(N, P, i);
+        return pl | pm << Y.BL;
+    }
+    // word i of the table: the images of pair (i & MP) under permutations (i >> PB) * PER ... + PER - 1, PB bits each
+    static KMC_HD constexpr u32 table_word(int i) {
+        const u32 idx = (u32)i & MP;
+        const int g = i >> PB;
+        u32 w = 0;
+        for (int j = 0; j < PER; ++j)
+            if (g * PER + j < NFACT) w |= pair_image(g * PER + j, idx) << (j * PB);
+        return w;
+    }
+    struct Table { u32 w[TABLE_WORDS]; };
+    static constexpr Table make_table() {
+        Table t{};
+        for (int i = 0; i < TABLE_WORDS; ++i) t.w[i] = KAFKA ? table_word(i) : 0u;
         return t;
     }
-    // isr masks: entry m (N bits) is the mask with every member renamed (2^N entries: 64 bits at N = 4)
-    static constexpr u64 isr_table(int P) {
-        u64 t = 0;
-        for (int m = 0; m < (1 << N); ++m) {
-            u64 pm = 0;
-            for (int i = 0; i < N; ++i)
-                if (m >> i & 1) pm |= 1ull << kmc_perm_image(N, P, i);
-            t |= pm << (m * N);
-        }
-        return t;
-    }
-    template <int P> static KMC_DEV u32 map_ldr(u32 v) {
-        constexpr u64 T = ldr_table(P);
-        if constexpr ((N + 1) * Y.BL <= 32) return ((u32)T >> (v * Y.BL)) & ML;
-        else return (u32)(T >> (v * Y.BL)) & ML;
-    }
-    template <int P> static KMC_DEV u32 map_isr(u32 m) {
-        constexpr u64 T = isr_table(P);
-        if constexpr ((1 << N) * N <= 32) return ((u32)T >> (m * N)) & MI;
-        else return (u32)(T >> (m * N)) & MI;
-    }
+    static constexpr Table TABLE = make_table();   // (constant memory; k_expand copies it to LDS once per block)
+    // pair f: replica f for f < N, quorumState for f = N, the request of epoch f - N - 1 beyond
+    static constexpr int pair_ldr_off(int f) { return f < N ? Y.ldr_off[f] : f == N ? Y.qldr_off : Y.reqldr_off[f - N - 1]; }
+    static constexpr int pair_isr_off(int f) { return f < N ? Y.isr_off[f] : f == N ? Y.qisr_off : Y.reqisr_off[f - N - 1]; }
+    static constexpr bool pair_adjacent(int f) { return pair_isr_off(f) == pair_ldr_off(f) + Y.BL; }
     // the global fields no permutation touches (nextRecordId, nextLeaderEpoch, quorumState.leaderEpoch), as a mask of word k
     static constexpr u64 keep_mask(int k) {
         u64 m = 0;
@@ -1563,7 +1573,19 @@ template <class M> struct KmcSymm {
         return m;
     }
 
-    template <int P> static KMC_DEV void permute(const u64* s, u64* t) {
+    // the images of a state's pairs under every permutation: NPAIR x NG table reads, once per state
+    struct Prep { u32 img[NPAIR > 0 ? NPAIR : 1][NG]; };
+    static KMC_DEV void prepare(const u64* s, const u32* tab, Prep& p) {
+        kmc_static_for<0, NPAIR>([&](auto FF) {
+            constexpr int f = decltype(FF)::value;
+            u32 idx;
+            if constexpr (pair_adjacent(f)) idx = (u32)kmc_getbits(s, pair_ldr_off(f), PB);
+            else idx = (u32)kmc_getbits(s, pair_ldr_off(f), Y.BL) | ((u32)kmc_getbits(s, pair_isr_off(f), Y.BI) << Y.BL);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) p.img[f][g] = tab[(g << PB) | idx];
+        });
+    }
+    template <int P> static KMC_DEV void permute(const u64* s, const Prep& p, u64* t) {
         kmc_static_for<0, W>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
             t[k] = s[k] & keep_mask(k);
@@ -1574,34 +1596,35 @@ template <class M> struct KmcSymm {
             if constexpr (!KAFKA) {
                 kmc_orbits(t, Y.end_off[d], Y.BO, kmc_getbits(s, Y.end_off[r], Y.BO));
             } else {
-                // end | hw | ep | ldr | isr are adjacent in every arrangement of the state vector (kmc_layout.h): one field
-                constexpr int GB = 2 * Y.BO + Y.BE, SB = GB + Y.BL + Y.BI;
+                // end | hw | ep | ldr | isr are adjacent in every arrangement of the state vector (kmc_layout.h)
+                constexpr int GB = 2 * Y.BO + Y.BE;
                 static_assert(Y.hw_off[r] == Y.end_off[r] + Y.BO && Y.ep_off[r] == Y.hw_off[r] + Y.BO &&
                               Y.ldr_off[r] == Y.ep_off[r] + Y.BE && Y.isr_off[r] == Y.ldr_off[r] + Y.BL, "small group not contiguous");
-                static_assert(SB <= 32, "a replica's small group is renamed in one 32-bit register");
-                const u32 g = (u32)kmc_getbits(s, Y.end_off[r], SB);
-                const u32 g2 = (g & ((1u << GB) - 1)) | (map_ldr<P>((g >> GB) & ML) << GB) | (map_isr<P>(g >> (GB + Y.BL)) << (GB + Y.BL));
-                kmc_orbits(t, Y.end_off[d], SB, g2);
+                kmc_orbits(t, Y.end_off[d], GB, kmc_getbits(s, Y.end_off[r], GB));
+                kmc_orbits(t, Y.ldr_off[d], PB, (p.img[r][P / PER] >> ((P % PER) * PB)) & MP);
             }
         });
-        if constexpr (KAFKA) {
-            kmc_orbits(t, Y.qldr_off, Y.BL, map_ldr<P>((u32)kmc_getbits(s, Y.qldr_off, Y.BL)));
-            kmc_orbits(t, Y.qisr_off, Y.BI, map_isr<P>((u32)kmc_getbits(s, Y.qisr_off, Y.BI)));
-            kmc_static_for<0, Y.E + 1>([&](auto EE) {
-                constexpr int e = decltype(EE)::value;
-                kmc_orbits(t, Y.reqldr_off[e], Y.BL, map_ldr<P>((u32)kmc_getbits(s, Y.reqldr_off[e], Y.BL)));
-                kmc_orbits(t, Y.reqisr_off[e], Y.BI, map_isr<P>((u32)kmc_getbits(s, Y.reqisr_off[e], Y.BI)));
-            });
-        }
+        kmc_static_for<N, NPAIR>([&](auto FF) {
+            constexpr int f = decltype(FF)::value;
+            const u32 pi = (p.img[f][P / PER] >> ((P % PER) * PB)) & MP;
+            if constexpr (pair_adjacent(f)) {
+                kmc_orbits(t, pair_ldr_off(f), PB, pi);
+            } else {
+                kmc_orbits(t, pair_ldr_off(f), Y.BL, pi & ML);
+                kmc_orbits(t, pair_isr_off(f), Y.BI, pi >> Y.BL);
+            }
+        });
     }
     // c = the orbit's representative (the smallest image, word 0 first), stab = the permutations that fix s
-    static KMC_DEV void canon(const u64* s, u64* c, u32& stab) {
+    static KMC_DEV void canon(const u64* s, const u32* tab, u64* c, u32& stab) {
+        Prep p;
+        prepare(s, tab, p);
 #pragma unroll
         for (int k = 0; k < W; ++k) c[k] = s[k];
         u32 n = 1;
         kmc_static_for<1, NFACT>([&](auto PP) {
             u64 t[W];
-            permute<decltype(PP)::value>(s, t);
+            permute<decltype(PP)::value>(s, p, t);
             bool lt = false, eq = true;
 #pragma unroll
             for (int k = 0; k < W; ++k) {
@@ -1614,11 +1637,13 @@ template <class M> struct KmcSymm {
         });
         stab = n;
     }
-    static KMC_DEV u32 stabiliser(const u64* s) {
+    static KMC_DEV u32 stabiliser(const u64* s, const u32* tab) {
+        Prep p;
+        prepare(s, tab, p);
         u32 n = 1;
         kmc_static_for<1, NFACT>([&](auto PP) {
             u64 t[W];
-            permute<decltype(PP)::value>(s, t);
+            permute<decltype(PP)::value>(s, p, t);
             bool eq = true;
 #pragma unroll
             for (int k = 0; k < W; ++k) eq = eq && t[k] == s[k];
@@ -2032,6 +2057,12 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #endif
 
     u32 table_full = 0;  // wave-uniform; KMC_ERRCHK_TILE: refreshed once per tile
+#if KMC_SYMM
+    // the images of every (leader, isr) pair under every permutation of Replicas (KmcSymm): filled here, read after the
+    // block's first barrier below
+    __shared__ u32 kmc_symtab[KmcSymm<M>::TABLE_WORDS];
+    for (u32 i = threadIdx.x; i < (u32)KmcSymm<M>::TABLE_WORDS; i += KMC_BLOCK) kmc_symtab[i] = KmcSymm<M>::TABLE.w[i];
+#endif
     const u32 nwaves = gridDim.x * KMC_WAVES;
     const u32 wave0 = blockIdx.x * KMC_WAVES + wib;
 #if KMC_FAULT_DROP
@@ -2055,7 +2086,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         {
             u64 tc[W];
             u32 stab_t;
-            KmcSymm<M>::canon(t0, tc, stab_t);
+            KmcSymm<M>::canon(t0, kmc_symtab, tc, stab_t);
             KmcSink<M>::process(a, out, lane < nv && !table_full, tc, meta0, t0, KmcSymm<M>::deficit(stab_t));
         }
 #else
@@ -2148,7 +2179,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #if KMC_SYMM
         // the expanded state is its orbit's representative; everything counted for it below stands for the whole orbit, less
         // this deficit when some permutation fixes it (rare: the lanes with defl != 0 take the few extra steps)
-        const u32 defl = valid ? KmcSymm<M>::deficit(KmcSymm<M>::stabiliser(s)) : 0u;
+        const u32 defl = valid ? KmcSymm<M>::deficit(KmcSymm<M>::stabiliser(s, kmc_symtab)) : 0u;
 #else
         const u32 defl = 0;
 #endif

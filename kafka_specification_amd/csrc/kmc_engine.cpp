@@ -319,7 +319,9 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
         // (these kernels take up to minutes to compile: jump by the size of the overflow, do not crawl)
         // (a near miss at 6 waves gets 5 — 96 registers: the kind-major headline kernel spills 9 at 80 and 2 at 96 and runs
         // equally fast at either, profiles/r03_kind_major.txt)
-        const int next = spills > 64 ? 2 : spills > 24 ? 3 : spills > 16 ? 4 : 5;
+        // (the orbit-counting headline kernel spills 23 at 80: at 5 waves — 96 registers, 8 spilled — it runs 7.4 ms, at 4 waves
+        // — 108, none — 7.7 ms, profiles/r03_symmetry.txt: a miss of up to 24 tries 5 first and falls to 4 from there)
+        const int next = spills > 64 ? 2 : spills > 40 ? 3 : spills > 24 ? 4 : 5;
         waves = next < waves ? next : waves - 1;
     }
     // best-effort cache write (atomic rename)
@@ -1348,6 +1350,10 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             bool same = vc.deadlock_count == c.deadlock_count;
             for (int k = 0; k < KMC_MAX_KINDS; ++k) same = same && vc.generated[k] == c.generated[k];
             for (int k = 0; k < 4; ++k) same = same && vc.viol_count[k] == c.viol_count[k];
+            // (orbit counting: the deficits taken when a state is expanded — the second build finds the stabilisers again)
+            for (int k = 0; k < KMC_MAX_KINDS; ++k) same = same && vc.corr_gen[k] == c.corr_gen[k];
+            for (int k = 0; k < 4; ++k) same = same && vc.corr_viol[k] == c.corr_viol[k];
+            same = same && vc.corr_dead == c.corr_dead && vc.corr_repeats == c.corr_repeats;
             // ... and the successors themselves: how many reached the sink, and the order-independent checksum of their
             // fingerprints (taken where a successor enters the sink — behind the ring and the flush, where round 1's
             // miscompiled kernel lost some while every count above still agreed)

@@ -1,7 +1,7 @@
 """`tlc2.TLC`-shaped command line [TLC-recall]:
 
     python -m kafka_specification_amd.tlc [-config X.cfg] [-deadlock] [-continue] [-workers N]
-                                          [-fp SEED] [-fp128] [-fpcheck] [-verify] [-force] [-gpus P] [-table SLOTS]
+                                          [-fp SEED] [-fp128] [-symmetry] [-fpcheck] [-verify] [-force] [-gpus P] [-table SLOTS]
                                           [-frontier STATES] Spec.tla
 
 Maps the root module's name to its lowered GPU model, reads constants / invariants from the
@@ -88,6 +88,12 @@ def main(argv=None) -> int:
                     help="128-bit seen-set entries: the fingerprint plus an independent 64-bit check word per state, in the same "
                          "cache line (no extra memory traffic per probe, twice the table bytes); a 64-bit fingerprint collision "
                          "is then recognised instead of losing a state")
+    ap.add_argument("-symmetry", action="store_true",
+                    help="orbit counting: the specs never tell two members of Replicas apart, so one state per orbit of the "
+                         "permutations of Replicas is stored and expanded and every count is weighted by its orbit's size — the "
+                         "numbers printed are those of the plain search (TLC without a SYMMETRY set; TLC's own SYMMETRY prints "
+                         "the reduced counts) from ~1/|Replicas|! of the work.  Kafka family / FiniteReplicatedLog, up to 4 "
+                         "replicas, one GPU")
     ap.add_argument("-fpcheck", action="store_true",
                     help="run the search again with a second fingerprint seed and compare the counts")
     ap.add_argument("-maxlevels", type=int, default=0, help="stop after this many BFS levels (verdict level_limit)")
@@ -137,7 +143,7 @@ def main(argv=None) -> int:
         mcfg = parse_cfg(open(cfg_path).read())
         over = dict(hash_seed=a.fp, device=a.device, continue_on_violation=a.cont, keep_trace=not a.notrace,
                     table_capacity=a.table, frontier_capacity=a.frontier, max_levels=a.maxlevels,
-                    wide_fingerprint=a.fp128)
+                    wide_fingerprint=a.fp128, symmetry=a.symmetry)
         if a.deadlock:
             over["check_deadlock"] = False
         cc = to_checker_config(module, mcfg, **over)
@@ -240,7 +246,15 @@ def main(argv=None) -> int:
     print(f"{res.generated} states generated, {res.distinct} distinct states found, "
           f"{res.queue_left} states left on queue.")
     print(f"The depth of the complete state graph search is {res.depth}.")
-    for line in collision_report(res.distinct, res.generated, a.fp128):
+    if a.symmetry:
+        print(f"Symmetry reduction (orbit counting over the permutations of Replicas): {res.orbit_representatives} states "
+              f"were stored and expanded, one per orbit; every count above is the plain search's.")
+    # (the seen-set holds the representatives: they are what can collide, and what was probed for)
+    stored, probed = res.distinct, res.generated
+    if a.symmetry and res.distinct:
+        stored = res.orbit_representatives
+        probed = res.generated * stored // res.distinct
+    for line in collision_report(stored, probed, a.fp128):
         print(line)
     if second is not None:
         seed2, r2 = second

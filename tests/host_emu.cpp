@@ -92,9 +92,10 @@ template <class M> struct Ops {
     // of one packed state and the order of its stabiliser; -1 where the model or N has no symmetry reduction
     static int canon(const u64* s, u64* c) {
         if constexpr (kmc_model_symmetric(M::Y.model) && M::Y.N <= 4) {
+            const u32* tab = KmcSymm<M>::TABLE.w;
             u32 stab = 0;
-            KmcSymm<M>::canon(s, c, stab);
-            return KmcSymm<M>::stabiliser(s) == stab ? (int)stab : -2;
+            KmcSymm<M>::canon(s, tab, c, stab);
+            return KmcSymm<M>::stabiliser(s, tab) == stab ? (int)stab : -2;
         } else {
             return -1;
         }

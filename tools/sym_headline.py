@@ -1,5 +1,5 @@
 """Headline configuration (Kip320 3/6/6/2) with and without symmetry reduction (orbit counting): step time, k_expand time,
-stored states; both must report the golden counts.  usage: python tools/sym_headline.py [runs]"""
+stored states; both must report the golden counts.  usage: python tools/sym_headline.py [runs] [both|sym|plain] [log2 table slots]"""
 import json
 import os
 import sys
@@ -12,8 +12,12 @@ from kafka_specification_amd.configs import HEADLINE
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 g = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
                                 "oracle_kip320_3_6_6_2.json")))
+which = sys.argv[2] if len(sys.argv) > 2 else "both"
+tlog = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 for sym in (True, False):
-    cfg = kmc.CheckerConfig(**HEADLINE, symmetry=sym, table_capacity=(1 << 28) if sym else (1 << 30),
+    if (sym and which == "plain") or (not sym and which == "sym"):
+        continue
+    cfg = kmc.CheckerConfig(**HEADLINE, symmetry=sym, table_capacity=(1 << tlog) if tlog else (1 << 28) if sym else (1 << 30),
                             frontier_capacity=(1 << 24) if sym else (1 << 26))
     with kmc.ModelChecker(cfg) as mc:
         for i in range(runs):
