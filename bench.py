@@ -358,7 +358,7 @@ def main():
                              "nor more waves per SIMD shorten it (profiles/r02_ablation.txt, r02_occupancy_sweep.txt)"},
         "device": device_info(),
     }
-    if (world == 1 and not a.symmetry and not a.no_orbit_counting and not a.level_budget and c["n_replicas"] <= 4
+    if (world == 1 and not a.symmetry and not a.no_orbit_counting and not a.level_budget and c["n_replicas"] <= 6
             and r.verdict == "ok"):
         # The same check with symmetry reduction by orbit counting (kmc_config.symmetry): one stored
         # state per orbit of the permutations of Replicas, every count weighted by the orbit's size.  It must report the

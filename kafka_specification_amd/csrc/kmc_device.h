@@ -1525,11 +1525,13 @@ template <class M> struct KmcSymm {
     static constexpr bool KAFKA = Y.model != KMC_MODEL_FINITE_REPLICATED_LOG;
     static constexpr int NFACT = kmc_factorial(N);
     static_assert(kmc_model_symmetric(Y.model), "this model singles out a replica: no symmetry reduction");
-    static_assert(N <= 4, "orbit representatives are found by trying all N! permutations: N <= 4");
+    static_assert(N <= 6, "orbit representatives are found by trying all N! permutations: N <= 6");
+    static constexpr bool UNROLLED = N <= 4;   // N! - 1 statically specialised permutations; beyond: a loop over adjacent transpositions
     static constexpr int PB = KAFKA ? Y.BL + Y.BI : 1;       // bits of a (leader, isr) pair: 5 at N = 3, 7 at N = 4
     static constexpr int PER = 32 / PB;                      // images per table word
     static constexpr int NG = (NFACT + PER - 1) / PER;       // table words per pair value
-    static constexpr int TABLE_WORDS = KAFKA ? (NG << PB) : 1;
+    // (five and six replicas: the table holds, per adjacent transposition a <-> a + 1, the image of every pair value)
+    static constexpr int TABLE_WORDS = !KAFKA ? 1 : UNROLLED ? (NG << PB) : ((N - 1) << PB);
     static constexpr int NPAIR = KAFKA ? N + 1 + (Y.E + 1) : 0;
     static constexpr u32 MP = (1u << PB) - 1, ML = (1u << Y.BL) - 1;
 
@@ -1541,6 +1543,13 @@ template <class M> struct KmcSymm {
         for (int i = 0; i < N; ++i)
             if (m >> i & 1u) pm |= 1u << kmc_perm_image(N, P, i);
         return pl | pm << Y.BL;
+    }
+    // the pair idx with the names of replicas a and a + 1 exchanged
+    static KMC_HD constexpr u32 exchange_image(int a, u32 idx) {
+        const u32 l = idx & ML, m = idx >> Y.BL;
+        const u32 pl = l == (u32)a + 1 ? l + 1 : l == (u32)a + 2 ? l - 1 : l;
+        const u32 y = ((m >> a) ^ (m >> (a + 1))) & 1u;
+        return pl | ((m ^ (y << a) ^ (y << (a + 1))) << Y.BL);
     }
     // word i of the table: the images of pair (i & MP) under permutations (i >> PB) * PER ... + PER - 1, PB bits each
     static KMC_HD constexpr u32 table_word(int i) {
@@ -1554,7 +1563,7 @@ template <class M> struct KmcSymm {
     struct Table { u32 w[TABLE_WORDS]; };
     static constexpr Table make_table() {
         Table t{};
-        for (int i = 0; i < TABLE_WORDS; ++i) t.w[i] = KAFKA ? table_word(i) : 0u;
+        for (int i = 0; i < TABLE_WORDS; ++i) t.w[i] = !KAFKA ? 0u : UNROLLED ? table_word(i) : exchange_image(i >> PB, (u32)i & MP);
         return t;
     }
     static constexpr Table TABLE = make_table();   // (constant memory; k_expand copies it to LDS once per block)
@@ -1615,8 +1624,101 @@ template <class M> struct KmcSymm {
             }
         });
     }
+    // ---- five and six replicas: 119 / 719 statically specialised permutations are too much code, so the images are visited
+    // one ADJACENT TRANSPOSITION at a time (Steinhaus-Johnson-Trotter: every permutation exactly once, consecutive ones differ
+    // by exchanging two neighbouring replicas): a wave-uniform loop whose body dispatches to one of N - 1 specialised
+    // "exchange replicas a and a + 1" steps working in place on the current image.
+    static constexpr int NSTEPS = NFACT - 1;
+    struct Seq { unsigned char at[NSTEPS > 0 ? NSTEPS : 1]; };
+    static constexpr Seq make_sequence() {   // at[k] = a: step k exchanges the replicas at positions a and a + 1
+        Seq q{};
+        int perm[KMC_MAXN] = {}, dir[KMC_MAXN] = {};
+        for (int i = 0; i < N; ++i) { perm[i] = i; dir[i] = -1; }
+        for (int k = 0; k < NSTEPS; ++k) {
+            int mp = -1, mv = -1;    // the largest element that can move in its direction past a smaller one
+            for (int pos = 0; pos < N; ++pos) {
+                const int v = perm[pos], np = pos + dir[v];
+                if (np >= 0 && np < N && perm[np] < v && v > mv) { mv = v; mp = pos; }
+            }
+            const int np = mp + dir[mv];
+            q.at[k] = (unsigned char)(mp < np ? mp : np);
+            const int x = perm[mp]; perm[mp] = perm[np]; perm[np] = x;
+            for (int v = mv + 1; v < N; ++v) dir[v] = -dir[v];
+        }
+        return q;
+    }
+    static constexpr Seq SEQUENCE = make_sequence();
+    // the image of t under the transposition of replicas A and A + 1, in place
+    template <int A> static KMC_DEV void exchange(u64* t, const u32* tab) {
+        constexpr int B = A + 1, LB = Y.BR * Y.L;
+        {
+            const u64 d = kmc_getbits(t, Y.log_off[A], LB) ^ kmc_getbits(t, Y.log_off[B], LB);
+            kmc_xorbits(t, Y.log_off[A], LB, d);
+            kmc_xorbits(t, Y.log_off[B], LB, d);
+        }
+        if constexpr (!KAFKA) {
+            const u64 d = kmc_getbits(t, Y.end_off[A], Y.BO) ^ kmc_getbits(t, Y.end_off[B], Y.BO);
+            kmc_xorbits(t, Y.end_off[A], Y.BO, d);
+            kmc_xorbits(t, Y.end_off[B], Y.BO, d);
+        } else {
+            constexpr int SB = 2 * Y.BO + Y.BE + Y.BL + Y.BI;   // end | hw | ep | ldr | isr, adjacent in every arrangement
+            static_assert(Y.isr_off[A] == Y.end_off[A] + SB - Y.BI && Y.isr_off[B] == Y.end_off[B] + SB - Y.BI, "small group not contiguous");
+            const u64 d = kmc_getbits(t, Y.end_off[A], SB) ^ kmc_getbits(t, Y.end_off[B], SB);
+            kmc_xorbits(t, Y.end_off[A], SB, d);
+            kmc_xorbits(t, Y.end_off[B], SB, d);
+            // ... and the two names trade places in every (leader, isr) pair (leader values A + 1 <-> B + 1, isr bits A <-> B):
+            // one table read per pair
+            kmc_static_for<0, NPAIR>([&](auto FF) {
+                constexpr int f = decltype(FF)::value;
+                if constexpr (pair_adjacent(f)) {
+                    const u32 idx = (u32)kmc_getbits(t, pair_ldr_off(f), PB);
+                    kmc_xorbits(t, pair_ldr_off(f), PB, idx ^ tab[(A << PB) | idx]);
+                } else {
+                    const u32 idx = (u32)kmc_getbits(t, pair_ldr_off(f), Y.BL) | ((u32)kmc_getbits(t, pair_isr_off(f), Y.BI) << Y.BL);
+                    const u32 x = idx ^ tab[(A << PB) | idx];
+                    kmc_xorbits(t, pair_ldr_off(f), Y.BL, x & ML);
+                    kmc_xorbits(t, pair_isr_off(f), Y.BI, x >> Y.BL);
+                }
+            });
+        }
+    }
+    // visits every image of s: MINIMISE keeps the smallest in c and counts how often it occurs (= the stabiliser's order);
+    // otherwise c stays s and the images equal to s are counted
+    template <bool MINIMISE> static KMC_DEV u32 walk(const u64* s, const u32* tab, u64* c) {
+        u64 t[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) { t[k] = s[k]; c[k] = s[k]; }
+        u32 n = 1;
+#pragma clang loop unroll(disable)
+        for (int k = 0; k < NSTEPS; ++k) {
+            int a = SEQUENCE.at[k];
+#ifndef KMC_HOST_EMU
+            a = __builtin_amdgcn_readfirstlane(a);   // the step index is wave-uniform: keep the dispatch scalar
+#endif
+            kmc_dispatch<0, (N > 1 ? N - 1 : 1)>(a, [&](auto AA) { exchange<decltype(AA)::value>(t, tab); });
+            bool lt = false, eq = true;
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                lt = lt || (eq && t[q] < c[q]);
+                eq = eq && t[q] == c[q];
+            }
+            if constexpr (MINIMISE) {
+                n = lt ? 1u : n + (eq ? 1u : 0u);
+#pragma unroll
+                for (int q = 0; q < W; ++q) c[q] = lt ? t[q] : c[q];
+            } else {
+                n += eq ? 1u : 0u;
+            }
+        }
+        return n;
+    }
+
     // c = the orbit's representative (the smallest image, word 0 first), stab = the permutations that fix s
     static KMC_DEV void canon(const u64* s, const u32* tab, u64* c, u32& stab) {
+        if constexpr (!UNROLLED) {
+            stab = walk<true>(s, tab, c);
+            return;
+        }
         Prep p;
         prepare(s, tab, p);
 #pragma unroll
@@ -1638,6 +1740,10 @@ template <class M> struct KmcSymm {
         stab = n;
     }
     static KMC_DEV u32 stabiliser(const u64* s, const u32* tab) {
+        if constexpr (!UNROLLED) {
+            u64 c[W];
+            return walk<false>(s, tab, c);
+        }
         Prep p;
         prepare(s, tab, p);
         u32 n = 1;
@@ -1664,7 +1770,11 @@ template <class M> struct KmcSymm {
 // device-scope counter saturates near 90 M atomics/s; one atomic per flush of ~20 winners
 // sat right on that limit.)
 template <int W> struct KmcStager {
-    u64* planes;   // LDS, [W][KMC_QCAP]
+    // KMC_SYMM: a state travels with one more word — the order of its stabiliser under the permutations of Replicas, found
+    // for free when its representative was chosen (KmcSymm::canon) — in plane W of the stager and of the frontiers, so that
+    // the expansion does not have to walk through its N! images again to know how many states it stands for
+    static constexpr int PL = W + (KMC_SYMM ? 1 : 0);
+    u64* planes;   // LDS, [PL][KMC_QCAP]
     u32 count;     // wave-uniform; < KMC_QCAP between pushes (entries 0 .. count-1 are staged)
     u32 filtered;  // SHARDED: remote successors this wave's sender-side filter dropped (added to the level's counter once,
                    // in finish(): one atomicAdd per flush on that single line capped the sharded kernel at ~90 M flushes/s,
@@ -1708,7 +1818,7 @@ template <int W> struct KmcStager {
             if (base + lane < a.seg_cap) {
                 const u64 idx = (u64)seg * a.seg_cap + base + lane;
 #pragma unroll
-                for (int k = 0; k < W; ++k) KMC_FRONTIER_STORE(&a.fout[(u64)k * a.fout_stride + idx], planes[k * KMC_QCAP + lane]);
+                for (int k = 0; k < PL; ++k) KMC_FRONTIER_STORE(&a.fout[(u64)k * a.fout_stride + idx], planes[k * KMC_QCAP + lane]);
             } else {
                 atomicOr(&a.ctl->err, KMC_ERR_FRONTIER_FULL);
             }
@@ -1717,7 +1827,7 @@ template <int W> struct KmcStager {
     }
     // Stage the new states of a batch.  When they do not all fit, the first `room` of them complete the stager, it is
     // drained (always exactly 64: one atomicAdd, W coalesced 512-byte plane stores), and the rest start the next batch.
-    KMC_DEV void push(const KmcArgs& a, bool isnew, const u64* t) {
+    KMC_DEV void push(const KmcArgs& a, bool isnew, const u64* t, u32 tag = 0) {
         const u64 m = __ballot(isnew);
         if (m == 0) return;
         const u32 n = __popcll(m);
@@ -1727,6 +1837,7 @@ template <int W> struct KmcStager {
         if (isnew && rank < room) {
 #pragma unroll
             for (int k = 0; k < W; ++k) planes[k * KMC_QCAP + count + rank] = t[k];
+            if constexpr (PL > W) planes[W * KMC_QCAP + count + rank] = tag;
         }
         if (n < room) {
             count += n;
@@ -1736,6 +1847,7 @@ template <int W> struct KmcStager {
         if (isnew && rank >= room) {
 #pragma unroll
             for (int k = 0; k < W; ++k) planes[k * KMC_QCAP + (rank - room)] = t[k];
+            if constexpr (PL > W) planes[W * KMC_QCAP + (rank - room)] = tag;
         }
         count = n - room;
     }
@@ -1919,9 +2031,10 @@ template <class M> struct KmcSink {
     // Executed by the whole wave; lanes with valid=false only take part in the ballots.
     // KMC_SYMM: t is the orbit representative of the successor `raw` (what is fingerprinted, claimed, staged and shipped);
     // ENUM lists the successor itself with the representative's fingerprint, so that a trace replayed through kmc_successors
-    // is a real behaviour whose states are FOUND by the fingerprints of their representatives.  wdefl = the orbit's deficit.
+    // is a real behaviour whose states are FOUND by the fingerprints of their representatives.  stab = the order of t's
+    // stabiliser: it travels with a new state (KmcStager) and gives the orbit's deficit.
     static KMC_DEV void process(const KmcArgs& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta, const u64* raw = nullptr,
-                                u32 wdefl = 0) {
+                                u32 stab = 1) {
 #ifdef KMC_TEST_FP_BITS   // tests only: a fingerprint of that many bits, i.e. collisions on demand (the wide table's check
                           // word keeps its 64 bits) — tests/test_gpu_selfcheck_and_fp128.py
         const u64 fp = kmc_mix64((kmc_fingerprint<W>(t, a.seed) & ((1ull << (KMC_TEST_FP_BITS)) - 1)) + 0x9E3779B97F4A7C15ull) | 1ull;
@@ -1966,15 +2079,15 @@ template <class M> struct KmcSink {
             // profiles/r03_probe_knobs.txt.)
             const bool isnew = valid && claim_any(a, t, fp, meta);
 #if KMC_SYMM
-            out.corr_won += isnew ? wdefl : 0u;
+            out.corr_won += isnew ? KmcSymm<M>::deficit(stab) : 0u;
 #endif
-            if (!(a.flags & KMC_FLAG_X_NOSTAGE)) out.push(a, isnew, t);
+            if (!(a.flags & KMC_FLAG_X_NOSTAGE)) out.push(a, isnew, t, stab);
         } else if (a.mode == KMC_MODE_SHARDED) {
             // successors this shard owns take the local path at once (probe, claim, stage): only
             // the (P-1)/P that belong elsewhere travel
             const u32 dst = valid ? kmc_owner(fp, a.nshards) : ~0u;
             const bool isnew = dst == a.shard && claim_any(a, t, fp, meta);
-            out.push(a, isnew, t);
+            out.push(a, isnew, t, stab);
             // bucket the rest by owner: one wave-aggregated atomicAdd per destination present in this batch
             const u32 sub = blockIdx.x % KMC_SEGS;
             const bool remote = valid && dst != a.shard;
@@ -2040,7 +2153,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, keep it scalar
     const bool has_meta = (a.flags & KMC_FLAG_META) != 0;
     const u32 ring_planes = W + (has_meta ? 1u : 0u);
-    u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + W * KMC_QCAP);  // q[k*KMC_RING + pos]
+    u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + KmcStager<W>::PL * KMC_QCAP);  // q[k*KMC_RING + pos]
     KmcStager<W> out;
     out.init(q + ring_planes * KMC_RING);
     u32 head = 0, count = 0;  // wave-uniform: ring read position / number of QUEUED successors
@@ -2087,7 +2200,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             u64 tc[W];
             u32 stab_t;
             KmcSymm<M>::canon(t0, kmc_symtab, tc, stab_t);
-            KmcSink<M>::process(a, out, lane < nv && !table_full, tc, meta0, t0, KmcSymm<M>::deficit(stab_t));
+            KmcSink<M>::process(a, out, lane < nv && !table_full, tc, meta0, t0, stab_t);
         }
 #else
         KmcSink<M>::process(a, out, lane < nv && !table_full, t0, meta0);
@@ -2120,6 +2233,29 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     __shared__ u32 kmc_tail[64];
     if (threadIdx.x < 64) kmc_tail[threadIdx.x] = 0;
     __syncthreads();
+#if KMC_SYMM
+    // Sparse tiles.  A wave's time here goes into finding the representatives of its tile's successors (hundreds of vector
+    // instructions each, N! images at five and six replicas), and the levels are N! times smaller than the plain search's:
+    // a level of 30 K states is 470 tiles of 64 — one busy wave on every other SIMD, each crawling through ~7 flushes.
+    // So a tile holds 2^tile_sh <= 64 STATES, as few as it takes to give every wave of the grid one (the host launches the
+    // grid for tiles of 4, expand_grid): the successors of a level spread over eight times as many waves.
+    u32 tile_sh = 6;
+    {
+        u64 n_all = 0;
+        for (int sg = 0; sg < KMC_SEGS; ++sg) {
+            u64 n = a.seg_count[sg];
+            if (a.prev) {
+                const u64 made = a.prev->next_count[sg].v;
+                n = made < a.seg_cap ? made : a.seg_cap;
+            }
+            n_all += n;
+        }
+        const u64 per = n_all / nwaves;
+        tile_sh = __builtin_amdgcn_readfirstlane(per >= 64 ? 6u : per >= 32 ? 5u : per >= 16 ? 4u : per >= 8 ? 3u : 2u);
+    }
+#else
+    constexpr u32 tile_sh = 6;   // a tile = 64 states, one per lane
+#endif
 #pragma clang loop unroll(disable)
     for (int sg = 0; sg < KMC_SEGS; ++sg) {
     u64 seg_n = a.seg_count[sg];
@@ -2128,7 +2264,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         seg_n = made < a.seg_cap ? made : a.seg_cap;
     }
     const u64 seg_base = (u64)sg * a.seg_cap;
-    const u64 seg_tiles = (seg_n + 63) >> 6;
+    const u64 seg_tiles = (seg_n + ((1u << tile_sh) - 1)) >> tile_sh;
     // rotate the starting wave per segment so that short segments do not always land on the same waves
     const u32 first = (wave0 + nwaves - (u32)((sg * 977u) % nwaves)) % nwaves;
 #if KMC_PREFETCH
@@ -2136,7 +2272,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     // so their HBM latency (a quarter of the compute-only time when exposed) hides under it
     u64 s_next[W];
     {
-        const u64 j0 = ((u64)first << 6) + lane;
+        const u64 j0 = ((u64)first << tile_sh) + lane;
 #pragma unroll
         for (int k = 0; k < W; ++k)
             s_next[k] = (first < seg_tiles && j0 < seg_n) ? a.fin[(u64)k * a.fin_stride + seg_base + j0] : 0ull;
@@ -2146,8 +2282,8 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     // (a contiguous run of tiles per wave instead of every nwaves-th tile was measured: the same 30 effect leaves per
     // tile, kernel 37.9 ms against 35.8 — the strided deal balances the tail of a level better)
     for (u64 tile = first; tile < seg_tiles; tile += nwaves) {
-        const u64 j = (tile << 6) + lane;
-        const bool valid = j < seg_n;
+        const u64 j = (tile << tile_sh) + lane;
+        const bool valid = (lane >> tile_sh) == 0 && j < seg_n;
 #if KMC_PROFILE
         prof_acc[6] += 1;
 #endif
@@ -2158,7 +2294,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         for (int k = 0; k < W; ++k) s[k] = s_next[k];
         {
             const u64 tn = tile + nwaves;
-            const u64 jn = (tn << 6) + lane;
+            const u64 jn = (tn << tile_sh) + lane;
             const bool vn = tn < seg_tiles && jn < seg_n;
 #pragma unroll
             for (int k = 0; k < W; ++k) s_next[k] = vn ? a.fin[(u64)k * a.fin_stride + seg_base + jn] : 0ull;
@@ -2179,7 +2315,8 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #if KMC_SYMM
         // the expanded state is its orbit's representative; everything counted for it below stands for the whole orbit, less
         // this deficit when some permutation fixes it (rare: the lanes with defl != 0 take the few extra steps)
-        const u32 defl = valid ? KmcSymm<M>::deficit(KmcSymm<M>::stabiliser(s, kmc_symtab)) : 0u;
+        // (the order of its stabiliser came with it: plane W of the frontier, KmcStager)
+        const u32 defl = valid ? KmcSymm<M>::deficit((u32)KMC_FRONTIER_LOAD(&a.fin[(u64)W * a.fin_stride + idx])) : 0u;
 #else
         const u32 defl = 0;
 #endif
@@ -2476,15 +2613,15 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 }
 
 // dynamic LDS bytes k_expand needs for a state of W words
-KMC_HD inline unsigned kmc_expand_lds_bytes(int W, bool has_meta) {
-    return (unsigned)(KMC_WAVES * ((W + (has_meta ? 1 : 0)) * KMC_RING + W * KMC_QCAP) * 8);
+KMC_HD inline unsigned kmc_expand_lds_bytes(int W, bool has_meta, bool symmetry = false) {
+    return (unsigned)(KMC_WAVES * ((W + (has_meta ? 1 : 0)) * KMC_RING + (W + (symmetry ? 1 : 0)) * KMC_QCAP) * 8);
 }
 
 // Inserts a list of AoS records (W state words + predecessor fp) into the local table:
 // the initial state, and the receive side of the multi-GPU exchange.
 template <class M> KMC_DEV void kmc_insert_body(const KmcArgs& a) {
     constexpr int W = M::W;
-    __shared__ u64 stage[KMC_WAVES][W][KMC_QCAP];
+    __shared__ u64 stage[KMC_WAVES][KmcStager<W>::PL][KMC_QCAP];
     KmcStager<W> out;
     out.init(&stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0][0]);
 #if KMC_PROFILE
@@ -2503,7 +2640,12 @@ template <class M> KMC_DEV void kmc_insert_body(const KmcArgs& a) {
         const u64 meta = (valid && a.rec_words > (u32)W) ? a.recv[idx * (u64)a.rec_words + W] : 0ull;
         KmcArgs b = a;
         b.mode = KMC_MODE_LOCAL;
+#if KMC_SYMM
+        // (records arrive as representatives — Init, kmc_engine.cpp do_begin; what they lack is the stabiliser's order)
+        KmcSink<M>::process(b, out, valid, t, meta, nullptr, valid ? KmcSymm<M>::stabiliser(t, KmcSymm<M>::TABLE.w) : 1u);
+#else
         KmcSink<M>::process(b, out, valid, t, meta);
+#endif
     }
     out.finish(a);
 }

@@ -234,9 +234,9 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
                                "L*bits(record)<=64, E<=7 (AsyncIsr: N<=6, MaxVersion<=7)", cfg.model, cfg.n_replicas, cfg.log_size,
                     cfg.max_records, cfg.max_leader_epoch, cfg.n_log_records);
     *kname = name;
-    if (cfg.symmetry && (!kmc_model_symmetric(cfg.model) || cfg.n_replicas > 4 || cfg.n_shards > 1))
-        return fail(KMC_E_ARG, "symmetry (orbit counting) is for the Kafka family and FiniteReplicatedLog with at most 4 replicas "
-                               "on one GPU: %s singles out a replica, or N = %d > 4, or n_shards = %d > 1",
+    if (cfg.symmetry && (!kmc_model_symmetric(cfg.model) || cfg.n_replicas > 6 || cfg.n_shards > 1))
+        return fail(KMC_E_ARG, "symmetry (orbit counting) is for the Kafka family and FiniteReplicatedLog with at most 6 replicas "
+                               "on one GPU: %s singles out a replica, or N = %d > 6, or n_shards = %d > 1",
                     MODEL_NAMES[cfg.model], cfg.n_replicas, cfg.n_shards);
     // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_MIN_WAVES=5 -DKMC_PROFILE=1"
     std::vector<std::string> defines;
@@ -403,6 +403,7 @@ struct kmc_handle {
     // kmc_config.symmetry: the frontier / table hold one state per orbit; res.distinct and `levels` are the WEIGHTED
     // (= plain-search) numbers, raw_levels the representatives per level; nfact = |Replicas|!
     uint64_t nfact = 1;
+    int planes = 0;              // words per state in a frontier: W, and under symmetry one more — the order of the state's stabiliser
     double t_start = 0;
     double dry_seconds = 0;
     uint64_t prof[8] = {0}, prof_dry[8] = {0};
@@ -431,7 +432,7 @@ int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid, hipS
     if (f == h->f_expand || f == h->f_expand_verify) {  // k_expand carves its rings out of dynamic LDS
         const bool meta = (args.flags & KMC_FLAG_TRACE) || args.mode == KMC_MODE_ENUM;
         if (meta) args.flags |= KMC_FLAG_META;
-        lds = kmc_expand_lds_bytes(h->W, meta);
+        lds = kmc_expand_lds_bytes(h->W, meta, h->cfg.symmetry != 0);
     }
     size_t size = sizeof(args);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -475,7 +476,10 @@ uint64_t max_fanout(const kmc_handle* h) {
 }
 
 unsigned expand_grid(kmc_handle* h, uint64_t n) {
-    const uint64_t tiles = (n + 63) / 64;
+    // (orbit counting: k_expand shrinks its tiles down to 4 states when a level is small — KMC_SYMM, kmc_device.h — so the
+    // grid is sized for that)
+    const uint64_t per_tile = h->cfg.symmetry ? 4 : 64;
+    const uint64_t tiles = (n + per_tile - 1) / per_tile;
     uint64_t blocks = (tiles + KMC_WAVES - 1) / KMC_WAVES;
     // one resident wave of blocks: more than the kernel's occupancy only queues blocks and
     // unbalances the tail (measured: 73 ms at 5 blocks/CU vs 59 ms at the resident 4)
@@ -855,6 +859,7 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     }
     h->W = h->lay.W;
     h->nfact = h->cfg.symmetry ? (uint64_t)kmc_factorial(h->cfg.n_replicas) : 1;
+    h->planes = h->W + (h->cfg.symmetry ? 1 : 0);
     if (h->cfg.symmetry && !kmc_model_symmetric(h->cfg.model))
         return fail(KMC_E_ARG, "symmetry (orbit counting): %s singles out a replica or has none", MODEL_NAMES[h->cfg.model]);
     h->rec_words = h->W + (cfg->keep_trace ? 1 : 0);
@@ -896,11 +901,11 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     }
     int occ = 0;
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->f_expand, KMC_BLOCK,
-                                                           kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0)) == hipSuccess && occ > 0)
+                                                           kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0, cfg->symmetry != 0)) == hipSuccess && occ > 0)
         h->blocks_per_cu = occ > 8 ? 8 : occ;
     {   // the occupancy query may admit a block more than really fits when LDS is the limit
         // (5 x 32 KiB = all 160 KiB was reported resident, ran as 4 + a queued 5th: 69 ms vs 55 ms)
-        const unsigned lds = kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0);
+        const unsigned lds = kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0, cfg->symmetry != 0);
         const int by_lds = (int)((160u * 1024u - 1024u) / (lds ? lds : 1u));
         if (by_lds >= 1 && h->blocks_per_cu > by_lds) h->blocks_per_cu = by_lds;
     }
@@ -923,7 +928,7 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     uint64_t fcap = cfg->frontier_capacity;
     if (!fcap) {
         const double share = h->cfg.n_shards > 1 ? 0.09 : 0.20;
-        fcap = (uint64_t)(budget * share) / (8ull * h->W);
+        fcap = (uint64_t)(budget * share) / (8ull * h->planes);
         if (fcap > tcap) fcap = tcap;
     }
     if (fcap < 64) fcap = 64;
@@ -934,7 +939,7 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     if (hipMalloc(&h->table, tcap * h->slot_words * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate %llu table slots", (unsigned long long)tcap);
     if (cfg->keep_trace && hipMalloc(&h->pred, tcap * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate predecessor table");
     for (int i = 0; i < 2; ++i)
-        if (hipMalloc(&h->frontier[i], fcap * 8ull * h->W) != hipSuccess)
+        if (hipMalloc(&h->frontier[i], fcap * 8ull * h->planes) != hipSuccess)
             return fail(KMC_E_NOMEM, "cannot allocate frontier of %llu states", (unsigned long long)fcap);
     HIP_TRY(hipMalloc(&h->ctl, KMC_CTL_SLOTS * sizeof(KmcLevelCtl)));
     HIP_TRY(hipHostMalloc(&h->ctl_host, KMC_CHAIN * sizeof(KmcLevelCtl)));
@@ -1485,6 +1490,10 @@ int kmc_successors(kmc_handle* h, const uint64_t* words, uint64_t* out, uint64_t
     // the auxiliary frontier is the scratch buffer viewed as SoA with stride 1... planes must be
     // fin[k*stride + 0], so stride 1 puts the W words back to back
     HIP_TRY(hipMemcpyAsync(h->scratch, words, h->W * 8, hipMemcpyHostToDevice, h->stream));
+    if (h->cfg.symmetry) {   // plane W of this one-state frontier: the stabiliser's order (no count is taken from an ENUM pass)
+        static const uint64_t one = 1;
+        HIP_TRY(hipMemcpyAsync(h->scratch + h->W, &one, 8, hipMemcpyHostToDevice, h->stream));
+    }
     int rc = zero_ctl(h, 2);
     if (rc) return rc;
     KmcArgs a = base_args(h, 2);
@@ -1696,7 +1705,7 @@ int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     if (!rc) rc = dev_to_file(f, h->table, h->table_cap * h->slot_words);
     if (!rc && h->pred) rc = dev_to_file(f, h->pred, h->table_cap);
     for (int sg = 0; sg < KMC_SEGS && !rc; ++sg)
-        for (int k = 0; k < h->W && !rc; ++k)
+        for (int k = 0; k < h->planes && !rc; ++k)
             if (h->seg_n[sg])
                 rc = dev_to_file(f, h->frontier[h->cur] + (uint64_t)k * h->fcap + (uint64_t)sg * h->seg_cap, h->seg_n[sg]);
     fclose(f);
@@ -1767,7 +1776,7 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
     if (!rc && h->pred) rc = file_to_dev(f, h->pred, h->table_cap);
     h->cur = 0;
     for (int sg = 0; sg < KMC_SEGS && !rc; ++sg)
-        for (int k = 0; k < h->W && !rc; ++k)
+        for (int k = 0; k < h->planes && !rc; ++k)
             if (h->seg_n[sg])
                 rc = file_to_dev(f, h->frontier[0] + (uint64_t)k * h->fcap + (uint64_t)sg * h->seg_cap, h->seg_n[sg]);
     fclose(f);

@@ -276,6 +276,14 @@ KMC_HD inline void kmc_orbits(unsigned long long* w, int off, int bits, unsigned
     if (s + bits > 64) w[i + 1] |= val >> (64 - s);
 }
 
+// XOR a value into a field: with d = (field a) ^ (field b), XOR-ing d into both swaps them
+KMC_HD inline void kmc_xorbits(unsigned long long* w, int off, int bits, unsigned long long val) {
+    if (bits == 0) return;
+    const int i = off >> 6, s = off & 63;
+    w[i] ^= val << s;
+    if (s + bits > 64) w[i + 1] ^= val >> (64 - s);
+}
+
 // ---- permutations of Replicas (symmetry reduction with orbit counting: kmc_config.symmetry, kmc_device.h KmcSymm) ----
 // The specs never tell two replicas apart (KafkaReplication.tla quantifies over Replicas everywhere, :158-310; Init :109-120
 // treats them alike), so a permutation of Replicas maps reachable states to reachable states, successors to successors and

@@ -60,7 +60,35 @@ def test_orbit_counting_at_larger_constants(model, N, L, R, E):
     assert res.orbit_representatives < res.distinct / (factorial(N) * 0.8)
 
 
-@pytest.mark.parametrize("N,L,K", [(2, 4, 2), (3, 2, 2), (2, 4, 4), (4, 2, 1)])
+@pytest.mark.parametrize("model,N,L,R,E", [("Kip279", 5, 1, 1, 1), ("Kip320", 5, 1, 1, 1), ("KafkaTruncateToHighWatermark", 6, 1, 1, 1),
+                                           ("Kip101", 5, 2, 1, 1)])
+def test_five_and_six_replicas(model, N, L, R, E):
+    """Beyond four replicas the images of a state are visited one adjacent transposition at a time (a loop over the
+    Steinhaus-Johnson-Trotter sequence instead of N! - 1 unrolled permutations): 120 / 720 images per successor."""
+    inv = ("TypeOk", "WeakIsr", "StrongIsr")
+    o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv, stop_on_violation=False, threads=8))
+    res = sym_run(model, invariants=inv, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E,
+                  continue_on_violation=True, table_capacity=1 << 22, frontier_capacity=1 << 20)
+    assert (res.verdict, res.violated_invariant) == (o.verdict, o.viol_inv)
+    if o.viol_inv:
+        assert (res.violation_depth, res.violation_count) == (o.viol_depth, o.viol_count)
+    assert_plain_counts_but_verdict(res, o)
+    assert res.orbit_representatives < res.distinct / (factorial(N) * 0.3)
+
+
+def test_baseline_config4_kip279_five_brokers_equals_the_golden_fixture():
+    """BASELINE config 4 at its exhaustible binding (Kip279, 5 brokers, LogSize 2, MaxRecords 2, MaxLeaderEpoch 1):
+    the exact oracle's 112,549,196 states, generated, depth and every level — from about 1/100 of the states."""
+    g = json.load(open(os.path.join(GOLDEN, "oracle_kip279_5_2_2_1.json")))
+    res = sym_run("Kip279", invariants=("TypeOk",), n_replicas=5, log_size=2, max_records=2, max_leader_epoch=1,
+                  table_capacity=1 << 24, frontier_capacity=1 << 21)
+    assert (res.verdict, res.distinct, res.generated, res.depth) == ("ok", g["distinct"], g["generated"], g["depth"])
+    assert res.levels == g["levels"]
+    assert list(res.action_generated.values()) == g["action_generated"][:len(res.action_generated)]
+    assert res.orbit_representatives < g["distinct"] / 80
+
+
+@pytest.mark.parametrize("N,L,K", [(2, 4, 2), (3, 2, 2), (2, 4, 4), (4, 2, 1), (5, 1, 2)])
 def test_finite_replicated_log(N, L, K):
     o = kmo.Run(kmo.make_config("FiniteReplicatedLog", N=N, L=L, K=K))
     res = sym_run("FiniteReplicatedLog", n_replicas=N, log_size=L, n_log_records=K)
@@ -195,7 +223,7 @@ def test_refused_where_it_does_not_apply():
     with pytest.raises(Exception, match="symmetry"):
         ModelChecker(CheckerConfig(model="AsyncIsr", n_replicas=3, log_size=2, max_leader_epoch=2, symmetry=True))
     with pytest.raises(Exception, match="symmetry"):
-        ModelChecker(CheckerConfig(model="Kip320", n_replicas=5, log_size=1, max_records=1, max_leader_epoch=1, symmetry=True))
+        ModelChecker(CheckerConfig(model="Kip320", n_replicas=7, log_size=1, max_records=1, max_leader_epoch=0, symmetry=True))
 
 
 def test_seed_independence_and_wide_fingerprints():

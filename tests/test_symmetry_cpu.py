@@ -16,7 +16,7 @@ import kmo
 from kafka_specification_amd import CheckerConfig, ModelChecker
 
 MODEL_NAMES = {v: k for k, v in kmo.MODELS.items()}
-SYMMETRIC = [c for c in host_emu.configs() if (c[0] == 1 or 2 <= c[0] <= 6) and c[1] <= 4]
+SYMMETRIC = [c for c in host_emu.configs() if (c[0] == 1 or 2 <= c[0] <= 6) and c[1] <= 6]
 
 
 def _ids(c):
