@@ -241,6 +241,7 @@ def main():
         # on this node (the driver's own invocation shape), and pass its exit code on.  Rank 0 prints the line.
         sys.exit(self_launch(a.gpus))
 
+    from kafka_specification_amd._native import KMC_SYMMETRY_MAX_REPLICAS
     c = headline_config()
     if a.small:
         c.update(log_size=3, max_records=3)
@@ -358,7 +359,7 @@ def main():
                              "nor more waves per SIMD shorten it (profiles/r02_ablation.txt, r02_occupancy_sweep.txt)"},
         "device": device_info(),
     }
-    if (world == 1 and not a.symmetry and not a.no_orbit_counting and not a.level_budget and c["n_replicas"] <= 6
+    if (world == 1 and not a.symmetry and not a.no_orbit_counting and not a.level_budget and c["n_replicas"] <= KMC_SYMMETRY_MAX_REPLICAS
             and r.verdict == "ok"):
         # The same check with symmetry reduction by orbit counting (kmc_config.symmetry): one stored
         # state per orbit of the permutations of Replicas, every count weighted by the orbit's size.  It must report the

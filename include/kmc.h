@@ -57,6 +57,7 @@ extern "C" {
 
 #define KMC_MAX_KINDS 16
 #define KMC_MAX_SHARDS 8
+#define KMC_SYMMETRY_MAX_REPLICAS 6   /* kmc_config.symmetry: |Replicas|! images per state, 720 at most */
 #define KMC_SEND_SUBS 8     /* sub-buffers per destination in the send area (spreads the append counters) */
 #define KMC_COMM_ID_BYTES 128   /* an RCCL unique id (ncclUniqueId) */
 #define KMC_EXCHANGE_STATS 64   /* longest statistics vector that can ride on a level's count exchange */
@@ -110,7 +111,7 @@ typedef struct kmc_config {
                                    state's orbit: distinct / generated / per-level / per-disjunct / deadlock / violation
                                    counts, verdict and depth are those of the plain search (and of TLC WITHOUT a SYMMETRY
                                    set — TLC's own SYMMETRY reports the reduced counts) from ~1/|Replicas|! of the probes.
-                                   Kafka family and FiniteReplicatedLog, |Replicas| <= 4, n_shards = 1.  Traces are real
+                                   Kafka family and FiniteReplicatedLog, |Replicas| <= KMC_SYMMETRY_MAX_REPLICAS, n_shards = 1.  Traces are real
                                    behaviours (each step a successor of the one before), not chains of representatives */
 } kmc_config;
 

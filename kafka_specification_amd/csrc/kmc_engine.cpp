@@ -234,10 +234,10 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
                                "L*bits(record)<=64, E<=7 (AsyncIsr: N<=6, MaxVersion<=7)", cfg.model, cfg.n_replicas, cfg.log_size,
                     cfg.max_records, cfg.max_leader_epoch, cfg.n_log_records);
     *kname = name;
-    if (cfg.symmetry && (!kmc_model_symmetric(cfg.model) || cfg.n_replicas > 6 || cfg.n_shards > 1))
+    if (cfg.symmetry && (!kmc_model_symmetric(cfg.model) || cfg.n_replicas > KMC_SYMMETRY_MAX_REPLICAS || cfg.n_shards > 1))
         return fail(KMC_E_ARG, "symmetry (orbit counting) is for the Kafka family and FiniteReplicatedLog with at most 6 replicas "
-                               "on one GPU: %s singles out a replica, or N = %d > 6, or n_shards = %d > 1",
-                    MODEL_NAMES[cfg.model], cfg.n_replicas, cfg.n_shards);
+                               "on one GPU: %s singles out a replica, or N = %d > %d, or n_shards = %d > 1",
+                    MODEL_NAMES[cfg.model], cfg.n_replicas, KMC_SYMMETRY_MAX_REPLICAS, cfg.n_shards);
     // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_MIN_WAVES=5 -DKMC_PROFILE=1"
     std::vector<std::string> defines;
     std::string defines_key;
