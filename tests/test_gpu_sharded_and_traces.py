@@ -179,7 +179,11 @@ def test_rccl_single_rank_process_group_matches_oracle(exchange, monkeypatch):
     import torch.distributed as dist
     from kafka_specification_amd.sharded import check_distributed
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    if "MASTER_PORT" not in os.environ:   # a free port: under pytest-xdist the two parametrisations run side by side
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            monkeypatch.setenv("MASTER_PORT", str(sk.getsockname()[1]))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     created = not dist.is_initialized()
     if created:
