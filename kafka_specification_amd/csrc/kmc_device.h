@@ -296,6 +296,14 @@ KMC_DEV u64 kmc_bcast64(u64 v, int src) {
 }
 #endif
 KMC_DEV u32 kmc_min(u32 a, u32 b) { return a < b ? a : b; }
+// does any lane of the wave say so?  (the host emulation runs one state at a time: the lane itself)
+KMC_DEV bool kmc_any_lane(bool x) {
+#ifndef KMC_HOST_EMU
+    return __ballot(x) != 0;
+#else
+    return x;
+#endif
+}
 // Opaque redefinition: stops LICM from hoisting every action instance's guard/effect out of
 // the instance loop (they only depend on the loop-invariant state), which would keep all of
 // them live at once and cost the kernel its occupancy.
@@ -1526,7 +1534,7 @@ template <class M> struct KmcSymm {
     static constexpr int NFACT = kmc_factorial(N);
     static_assert(kmc_model_symmetric(Y.model), "this model singles out a replica: no symmetry reduction");
     static_assert(N <= 6, "orbit representatives are found by trying all N! permutations: N <= 6");
-    static constexpr bool UNROLLED = N <= 4;   // N! - 1 statically specialised permutations; beyond: a loop over adjacent transpositions
+    static constexpr bool UNROLLED = N <= KMC_SYMM_UNROLLED_MAX;   // N! - 1 statically specialised permutations; beyond: the sorted images (canon_sorted)
     static constexpr int PB = KAFKA ? Y.BL + Y.BI : 1;       // bits of a (leader, isr) pair: 5 at N = 3, 7 at N = 4
     static constexpr int PER = 32 / PB;                      // images per table word
     static constexpr int NG = (NFACT + PER - 1) / PER;       // table words per pair value
@@ -1629,8 +1637,10 @@ template <class M> struct KmcSymm {
     // by exchanging two neighbouring replicas): a wave-uniform loop whose body dispatches to one of N - 1 specialised
     // "exchange replicas a and a + 1" steps working in place on the current image.
     static constexpr int NSTEPS = NFACT - 1;
-    struct Seq { unsigned char at[NSTEPS > 0 ? NSTEPS : 1]; };
-    static constexpr Seq make_sequence() {   // at[k] = a: step k exchanges the replicas at positions a and a + 1
+    // at[k] = a: step k exchanges the replicas at positions a and a + 1; cross[k]: bit b set when the arrangement after step k
+    // has moved some replica across the boundary between positions b and b + 1 (it then mixes two runs of the sorted order)
+    struct Seq { unsigned char at[NSTEPS > 0 ? NSTEPS : 1], cross[NSTEPS > 0 ? NSTEPS : 1]; };
+    static constexpr Seq make_sequence() {
         Seq q{};
         int perm[KMC_MAXN] = {}, dir[KMC_MAXN] = {};
         for (int i = 0; i < N; ++i) { perm[i] = i; dir[i] = -1; }
@@ -1644,26 +1654,32 @@ template <class M> struct KmcSymm {
             q.at[k] = (unsigned char)(mp < np ? mp : np);
             const int x = perm[mp]; perm[mp] = perm[np]; perm[np] = x;
             for (int v = mv + 1; v < N; ++v) dir[v] = -dir[v];
+            unsigned c = 0;
+            for (int b = 0; b + 1 < N; ++b)
+                for (int pos = 0; pos <= b; ++pos)
+                    if (perm[pos] > b) c |= 1u << b;
+            q.cross[k] = (unsigned char)c;
         }
         return q;
     }
     static constexpr Seq SEQUENCE = make_sequence();
-    // the image of t under the transposition of replicas A and A + 1, in place
-    template <int A> static KMC_DEV void exchange(u64* t, const u32* tab) {
+    // the image of t under the transposition of replicas A and A + 1, in place; `on` = 0 leaves this lane's t as it is
+    // (everything below is an XOR of a difference: a lane that does not take part XORs zeros)
+    template <int A> static KMC_DEV void exchange(u64* t, const u32* tab, u64 on = ~0ull) {
         constexpr int B = A + 1, LB = Y.BR * Y.L;
         {
-            const u64 d = kmc_getbits(t, Y.log_off[A], LB) ^ kmc_getbits(t, Y.log_off[B], LB);
+            const u64 d = (kmc_getbits(t, Y.log_off[A], LB) ^ kmc_getbits(t, Y.log_off[B], LB)) & on;
             kmc_xorbits(t, Y.log_off[A], LB, d);
             kmc_xorbits(t, Y.log_off[B], LB, d);
         }
         if constexpr (!KAFKA) {
-            const u64 d = kmc_getbits(t, Y.end_off[A], Y.BO) ^ kmc_getbits(t, Y.end_off[B], Y.BO);
+            const u64 d = (kmc_getbits(t, Y.end_off[A], Y.BO) ^ kmc_getbits(t, Y.end_off[B], Y.BO)) & on;
             kmc_xorbits(t, Y.end_off[A], Y.BO, d);
             kmc_xorbits(t, Y.end_off[B], Y.BO, d);
         } else {
             constexpr int SB = 2 * Y.BO + Y.BE + Y.BL + Y.BI;   // end | hw | ep | ldr | isr, adjacent in every arrangement
             static_assert(Y.isr_off[A] == Y.end_off[A] + SB - Y.BI && Y.isr_off[B] == Y.end_off[B] + SB - Y.BI, "small group not contiguous");
-            const u64 d = kmc_getbits(t, Y.end_off[A], SB) ^ kmc_getbits(t, Y.end_off[B], SB);
+            const u64 d = (kmc_getbits(t, Y.end_off[A], SB) ^ kmc_getbits(t, Y.end_off[B], SB)) & on;
             kmc_xorbits(t, Y.end_off[A], SB, d);
             kmc_xorbits(t, Y.end_off[B], SB, d);
             // ... and the two names trade places in every (leader, isr) pair (leader values A + 1 <-> B + 1, isr bits A <-> B):
@@ -1672,10 +1688,10 @@ template <class M> struct KmcSymm {
                 constexpr int f = decltype(FF)::value;
                 if constexpr (pair_adjacent(f)) {
                     const u32 idx = (u32)kmc_getbits(t, pair_ldr_off(f), PB);
-                    kmc_xorbits(t, pair_ldr_off(f), PB, idx ^ tab[(A << PB) | idx]);
+                    kmc_xorbits(t, pair_ldr_off(f), PB, (idx ^ tab[(A << PB) | idx]) & (u32)on);
                 } else {
                     const u32 idx = (u32)kmc_getbits(t, pair_ldr_off(f), Y.BL) | ((u32)kmc_getbits(t, pair_isr_off(f), Y.BI) << Y.BL);
-                    const u32 x = idx ^ tab[(A << PB) | idx];
+                    const u32 x = (idx ^ tab[(A << PB) | idx]) & (u32)on;
                     kmc_xorbits(t, pair_ldr_off(f), Y.BL, x & ML);
                     kmc_xorbits(t, pair_isr_off(f), Y.BI, x >> Y.BL);
                 }
@@ -1683,8 +1699,10 @@ template <class M> struct KmcSymm {
         }
     }
     // visits every image of s: MINIMISE keeps the smallest in c and counts how often it occurs (= the stabiliser's order);
-    // otherwise c stays s and the images equal to s are counted
-    template <bool MINIMISE> static KMC_DEV u32 walk(const u64* s, const u32* tab, u64* c) {
+    // otherwise c stays s and the images equal to s are counted.  `runs`: bit b set = the replicas at positions b and b + 1 of
+    // s may trade places (canon_sorted: their keys are equal); an image whose arrangement crosses any other boundary is passed
+    // over.  All ones: every image counts.
+    template <bool MINIMISE> static KMC_DEV u32 walk(const u64* s, const u32* tab, u64* c, u32 runs = ~0u) {
         u64 t[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) { t[k] = s[k]; c[k] = s[k]; }
@@ -1692,16 +1710,21 @@ template <class M> struct KmcSymm {
 #pragma clang loop unroll(disable)
         for (int k = 0; k < NSTEPS; ++k) {
             int a = SEQUENCE.at[k];
+            u32 crossed = SEQUENCE.cross[k];
 #ifndef KMC_HOST_EMU
             a = __builtin_amdgcn_readfirstlane(a);   // the step index is wave-uniform: keep the dispatch scalar
+            crossed = __builtin_amdgcn_readfirstlane(crossed);
 #endif
             kmc_dispatch<0, (N > 1 ? N - 1 : 1)>(a, [&](auto AA) { exchange<decltype(AA)::value>(t, tab); });
+            const bool counts = (crossed & ~runs) == 0;
             bool lt = false, eq = true;
 #pragma unroll
             for (int q = 0; q < W; ++q) {
                 lt = lt || (eq && t[q] < c[q]);
                 eq = eq && t[q] == c[q];
             }
+            lt = lt && counts;
+            eq = eq && counts;
             if constexpr (MINIMISE) {
                 n = lt ? 1u : n + (eq ? 1u : 0u);
 #pragma unroll
@@ -1713,10 +1736,110 @@ template <class M> struct KmcSymm {
         return n;
     }
 
+    // ---- five and six replicas: the representative among the SORTED images -----------------------------------------------
+    // Walking through all 120 / 720 images of every successor is what the orbit-counting search spent its time on at five
+    // brokers.  So the representative is chosen among far fewer: every replica gets a KEY that does not depend on how the
+    // replicas are named — its log, end offset, high watermark and epoch; whether it names itself / nobody as leader, whether
+    // its ISR holds itself and how many it holds; whether quorumState and each LeaderAndIsr request name it as leader / in the
+    // ISR; how many OTHER replicas hold it in their ISR / name it as leader — and the representative of an orbit is its
+    // smallest image (words in order, as before) AMONG THE IMAGES WHOSE KEYS ASCEND WITH THE POSITION.  Renaming permutes the
+    // keys with the replicas, so every state of an orbit sees the same set of sorted images: a representative all the same.
+    //   1. sort: an odd-even transposition network of N (N - 1) / 2 conditional exchanges of neighbours (exchange<A> with a
+    //      lane mask; the keys trade places with the replicas);
+    //   2. where neighbours' keys are equal, the sorted image is one of several.  Almost always exchanging such neighbours
+    //      gives the SAME state (two followers nobody tells apart): when that holds at every tied boundary, the tied runs
+    //      generate the stabiliser — a permutation that fixes the state keeps every key where it is — the sorted image is
+    //      unique, and |Stab| = the product of the run lengths' factorials;
+    //   3. otherwise (a tie between replicas that ARE told apart by something the key does not see: not met in 1.8 M
+    //      successors of BASELINE config 4 and of the headline, tools/tie_stats.py — but nothing rests on that) the wave walks
+    //      through all the images of the sorted one and keeps the smallest of those that only move replicas inside tied runs.
+    struct Key { u64 a, b; };
+    template <int r> static KMC_DEV Key key_at(const u64* t) {
+        Key k;
+        k.a = kmc_getbits(t, Y.log_off[r], Y.BR * Y.L);
+        if constexpr (!KAFKA) {
+            k.b = kmc_getbits(t, Y.end_off[r], Y.BO);
+        } else {
+            constexpr int GB = 2 * Y.BO + Y.BE;   // end | hw | ep: adjacent in every arrangement (static_assert in exchange)
+            static_assert(GB + 14 + 2 * (Y.E + 1) <= 64, "replica key does not fit 64 bits");
+            const u32 ldr = (u32)kmc_getbits(t, Y.ldr_off[r], Y.BL), isr = (u32)kmc_getbits(t, Y.isr_off[r], Y.BI);
+            const u32 qldr = (u32)kmc_getbits(t, Y.qldr_off, Y.BL), qisr = (u32)kmc_getbits(t, Y.qisr_off, Y.BI);
+            u32 f = (ldr == (u32)r + 1u ? 1u : 0u) | ((isr >> r & 1u) << 1) | ((ldr == 0u ? 1u : 0u) << 2) |
+                    ((qldr == (u32)r + 1u ? 1u : 0u) << 3) | ((qisr >> r & 1u) << 4) | ((u32)__builtin_popcount(isr) << 5);
+            u32 held = 0, named = 0;   // by the other replicas
+            kmc_static_for<0, N>([&](auto OO) {
+                constexpr int o = decltype(OO)::value;
+                if constexpr (o != r) {
+                    held += (u32)kmc_getbits(t, Y.isr_off[o], Y.BI) >> r & 1u;
+                    named += (u32)kmc_getbits(t, Y.ldr_off[o], Y.BL) == (u32)r + 1u ? 1u : 0u;
+                }
+            });
+            f |= held << 8 | named << 11;
+            kmc_static_for<0, Y.E + 1>([&](auto EE) {
+                constexpr int e = decltype(EE)::value;
+                f |= ((u32)kmc_getbits(t, Y.reqldr_off[e], Y.BL) == (u32)r + 1u ? 1u : 0u) << (14 + 2 * e);
+                f |= ((u32)kmc_getbits(t, Y.reqisr_off[e], Y.BI) >> r & 1u) << (15 + 2 * e);
+            });
+            k.b = kmc_getbits(t, Y.end_off[r], GB) | (u64)f << GB;
+        }
+        return k;
+    }
+    static KMC_DEV void canon_sorted(const u64* s, const u32* tab, u64* c, u32& stab) {
+        u64 t[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) t[k] = s[k];
+        Key key[N];
+        kmc_static_for<0, N>([&](auto RR) { key[decltype(RR)::value] = key_at<decltype(RR)::value>(t); });
+        kmc_static_for<0, N>([&](auto II) {
+            kmc_static_for<0, (N - 1 - decltype(II)::value % 2 + 1) / 2>([&](auto JJ) {
+                constexpr int a = decltype(II)::value % 2 + 2 * decltype(JJ)::value;
+                if constexpr (a + 1 < N) {
+                    const bool sw = key[a + 1].a < key[a].a || (key[a + 1].a == key[a].a && key[a + 1].b < key[a].b);
+                    if (kmc_any_lane(sw)) {
+                        exchange<a>(t, tab, sw ? ~0ull : 0ull);
+                        const Key lo = key[a], hi = key[a + 1];
+                        key[a] = sw ? hi : lo;
+                        key[a + 1] = sw ? lo : hi;
+                    }
+                }
+            });
+        });
+        // tied neighbours: is trading them the identity on t?
+        u32 runs = 0, told_apart = 0;
+        kmc_static_for<0, N - 1>([&](auto AA) {
+            constexpr int a = decltype(AA)::value;
+            const bool tie = key[a].a == key[a + 1].a && key[a].b == key[a + 1].b;
+            if (kmc_any_lane(tie)) {
+                u64 u[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) u[k] = t[k];
+                exchange<a>(u, tab, tie ? ~0ull : 0ull);
+                bool same = true;
+#pragma unroll
+                for (int k = 0; k < W; ++k) same = same && u[k] == t[k];
+                runs |= tie ? 1u << a : 0u;
+                told_apart |= (tie && !same) ? 1u : 0u;
+            }
+        });
+        if (kmc_any_lane(told_apart != 0)) {   // (every lane takes the walk's answer: where nothing is told apart it is the same)
+            stab = walk<true>(t, tab, c, runs);
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) c[k] = t[k];
+        u32 n = 1, len = 1;
+#pragma unroll
+        for (int a = 0; a + 1 < N; ++a) {
+            len = (runs >> a & 1u) ? len + 1u : 1u;
+            n *= len;
+        }
+        stab = n;
+    }
+
     // c = the orbit's representative (the smallest image, word 0 first), stab = the permutations that fix s
     static KMC_DEV void canon(const u64* s, const u32* tab, u64* c, u32& stab) {
         if constexpr (!UNROLLED) {
-            stab = walk<true>(s, tab, c);
+            canon_sorted(s, tab, c, stab);
             return;
         }
         Prep p;

@@ -349,8 +349,44 @@ KMC_HD inline void kmc_permute_state(const KmcLayout& y, const int* img, const u
         kmc_orbits(t, y.reqisr_off[e], y.BI, kmc_permute_mask(y.N, img, kmc_getbits(s, y.reqisr_off[e], y.BI)));
     }
 }
-// The representative of s's orbit: the smallest image under all N! permutations, states compared as the tuple
-// (word 0, word 1, ...) of unsigned 64-bit values.  *stab = the permutations that fix s (the orbit has N! / *stab states).
+// Up to this many replicas the representative of an orbit is its smallest image outright; beyond, the smallest among the
+// images whose replica KEYS ascend with the position (kmc_device.h, KmcSymm::canon_sorted: 120 / 720 images per successor
+// were what the orbit-counting search spent its time on)
+#define KMC_SYMM_UNROLLED_MAX 4
+// The key of the replica at position r of t — everything about it that does not depend on how the replicas are named:
+// *a = its log; *b = end | hw << BO | ep << 2 BO, then (from bit 2 BO + BE) 1 bit each: names itself as leader, holds itself
+// in its ISR, names nobody, quorumState names it, quorumState's ISR holds it; 3 bits each: size of its ISR, how many OTHER
+// replicas hold it in their ISR, how many name it as leader; then per LeaderAndIsr request e, 1 bit each: the request names
+// it, the request's ISR holds it.  (The run-time-layout twin of KmcSymm::key_at.)
+KMC_HD inline void kmc_replica_key_generic(const KmcLayout& y, const unsigned long long* t, int r, unsigned long long* a,
+                                           unsigned long long* b) {
+    *a = kmc_getbits(t, y.log_off[r], y.BR * y.L);
+    *b = kmc_getbits(t, y.end_off[r], y.BO);
+    if (y.model == KMC_MODEL_FINITE_REPLICATED_LOG) return;
+    const int gb = 2 * y.BO + y.BE;
+    *b |= kmc_getbits(t, y.hw_off[r], y.BO) << y.BO | kmc_getbits(t, y.ep_off[r], y.BE) << (2 * y.BO);
+    const unsigned long long self = (unsigned long long)r + 1;
+    const unsigned long long ldr = kmc_getbits(t, y.ldr_off[r], y.BL), isr = kmc_getbits(t, y.isr_off[r], y.BI);
+    unsigned long long f = (ldr == self ? 1ull : 0ull) | (isr >> r & 1ull) << 1 | (ldr == 0 ? 1ull : 0ull) << 2 |
+                           (kmc_getbits(t, y.qldr_off, y.BL) == self ? 1ull : 0ull) << 3 |
+                           (kmc_getbits(t, y.qisr_off, y.BI) >> r & 1ull) << 4;
+    unsigned long long pop = 0, held = 0, named = 0;
+    for (int i = 0; i < y.N; ++i) pop += isr >> i & 1ull;
+    for (int o = 0; o < y.N; ++o) {
+        if (o == r) continue;
+        held += kmc_getbits(t, y.isr_off[o], y.BI) >> r & 1ull;
+        named += kmc_getbits(t, y.ldr_off[o], y.BL) == self ? 1ull : 0ull;
+    }
+    f |= pop << 5 | held << 8 | named << 11;
+    for (int e = 0; e <= y.E; ++e) {
+        f |= (kmc_getbits(t, y.reqldr_off[e], y.BL) == self ? 1ull : 0ull) << (14 + 2 * e);
+        f |= (kmc_getbits(t, y.reqisr_off[e], y.BI) >> r & 1ull) << (15 + 2 * e);
+    }
+    *b |= f << gb;
+}
+// The representative of s's orbit: the smallest image under the N! permutations (beyond KMC_SYMM_UNROLLED_MAX replicas: among
+// the images whose keys ascend with the position), states compared as the tuple (word 0, word 1, ...) of unsigned 64-bit
+// values.  *stab = the permutations that fix s (the orbit has N! / *stab states).
 KMC_HD inline void kmc_canonical_state_generic(const KmcLayout& y, const unsigned long long* s, unsigned long long* c, int* stab) {
     const int nf = kmc_factorial(y.N);
     unsigned long long t[KMC_MAXW];
@@ -359,8 +395,19 @@ KMC_HD inline void kmc_canonical_state_generic(const KmcLayout& y, const unsigne
     for (int P = 0; P < nf; ++P) {
         for (int r = 0; r < y.N; ++r) img[r] = kmc_perm_image(y.N, P, r);
         kmc_permute_state(y, img, s, t);
+        if (y.N > KMC_SYMM_UNROLLED_MAX) {
+            bool ascending = true;
+            unsigned long long pa = 0, pb = 0;
+            for (int r = 0; r < y.N && ascending; ++r) {
+                unsigned long long a = 0, b = 0;
+                kmc_replica_key_generic(y, t, r, &a, &b);
+                if (r > 0 && (a < pa || (a == pa && b < pb))) ascending = false;
+                pa = a; pb = b;
+            }
+            if (!ascending) continue;
+        }
         int cmp = 0;   // t against c
-        if (P == 0) cmp = -1;
+        if (cnt == 0) cmp = -1;
         for (int k = 0; k < y.W && cmp == 0; ++k) cmp = t[k] < c[k] ? -1 : t[k] > c[k] ? 1 : 0;
         if (cmp < 0) {
             for (int k = 0; k < y.W; ++k) c[k] = t[k];
