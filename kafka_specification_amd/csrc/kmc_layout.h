@@ -352,7 +352,9 @@ KMC_HD inline void kmc_permute_state(const KmcLayout& y, const int* img, const u
 // Up to this many replicas the representative of an orbit is its smallest image outright; beyond, the smallest among the
 // images whose replica KEYS ascend with the position (kmc_device.h, KmcSymm::canon_sorted: 120 / 720 images per successor
 // were what the orbit-counting search spent its time on)
+#ifndef KMC_SYMM_UNROLLED_MAX   // (a JIT define moves the DEVICE's threshold only — timing runs; the host forms follow the default)
 #define KMC_SYMM_UNROLLED_MAX 4
+#endif
 // The key of the replica at position r of t — everything about it that does not depend on how the replicas are named:
 // *a = its log; *b = end | hw << BO | ep << 2 BO, then (from bit 2 BO + BE) 1 bit each: names itself as leader, holds itself
 // in its ISR, names nobody, quorumState names it, quorumState's ISR holds it; 3 bits each: size of its ISR, how many OTHER
