@@ -1,5 +1,5 @@
 """One Kafka-family configuration with and without orbit counting: step time, k_expand time, stored states; the two searches
-must report the same counts.  usage: python tools/sym_ab.py MODEL N L R E [runs] [log2 table slots]
+must report the same counts.  usage: python tools/sym_ab.py MODEL N L R E [runs] [log2 table slots]      (KMC_AB_FP128=1: 128-bit seen-set entries)
 (KMC_JIT_DEFINES=-DKMC_SYMM_UNROLLED_MAX=k moves the replica count from which the representative is chosen among the sorted
 images — on the device only, so traces / kmc_contains of such a run are not meaningful; counts are.)"""
 import json
@@ -17,7 +17,7 @@ inv = ("TypeOk", "WeakIsr", "StrongIsr") if m == "Kip320" else ("TypeOk",)
 seen = {}
 for sym in (True, False):
     cfg = kmc.CheckerConfig(model=m, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, invariants=inv,
-                            continue_on_violation=True, symmetry=sym, table_capacity=1 << tlog, frontier_capacity=1 << (tlog - 3))
+                            continue_on_violation=True, symmetry=sym, wide_fingerprint=os.environ.get("KMC_AB_FP128", "0") == "1", table_capacity=1 << tlog, frontier_capacity=1 << (tlog - 3))
     with kmc.ModelChecker(cfg) as mc:
         for i in range(runs if sym else 2):
             t0 = time.time()
