@@ -244,3 +244,14 @@ def test_headline_configuration_equals_the_golden_fixture():
     assert list(res.action_generated.values()) == g["action_generated"][:len(res.action_generated)]
     assert res.deadlock_states == g["deadlock_states"]
     assert res.orbit_representatives < g["distinct"] / 5.9
+
+
+def test_six_billion_states_beyond_any_oracle():
+    """Kip320 3/6/6/3: no oracle reaches it.  Its count — 6,452,700,520 distinct / 20,756,484,505 generated / 54 levels — is what
+    three hash seeds of the PLAIN search with 128-bit seen-set entries agree on (profiles/r03_fp128.txt; 64-bit runs lose 0-9
+    states to collisions).  The orbit-counting search gets there from 1,075,491,542 stored states by a different route: other
+    states in the table, other fingerprints, every count a weighted sum."""
+    res = sym_run("Kip320", invariants=("TypeOk", "WeakIsr", "StrongIsr"), n_replicas=3, log_size=6, max_records=6,
+                  max_leader_epoch=3, wide_fingerprint=True, table_capacity=1 << 31, frontier_capacity=1 << 28)
+    assert (res.verdict, res.distinct, res.generated, res.depth) == ("ok", 6452700520, 20756484505, 54)
+    assert res.orbit_representatives == 1075491542
