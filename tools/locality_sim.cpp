@@ -89,10 +89,13 @@ struct Stats {
 
 int main(int argc, char** argv) {
     const int NW = argc > 1 ? atoi(argv[1]) : 96;          // concurrent waves (4 per block)
-    const int mode = argc > 2 ? atoi(argv[2]) : 0;         // 0 today's order, 1 per-block segments + chunked tiles
+    const int mode = argc > 2 ? atoi(argv[2]) : 0;         // 0 today's order, 1 per-block segments + chunked tiles,
+                                                           // 2 / 3 / 4: the level SORTED by replica word 2 / 1 / 0 first (then the others), chunked tiles
     const int CH = argc > 3 ? atoi(argv[3]) : 4;           // tiles per chunk (mode 1)
     const int FS = argc > 4 ? atoi(argv[4]) : 256;         // filter entries per wave (0 = none)
-    const int NSEG = mode == 0 ? 8 : NW / 4;
+    const double MAXS = argc > 5 ? atof(argv[5]) : 1e18;   // stop after the level that takes the total past this many states
+    const int NSEG = mode == 0 ? 8 : mode == 1 ? NW / 4 : 1;
+    if (mode >= 2 && (W != 3 || M::Y.rm != 1)) { fprintf(stderr, "modes 2-4 need one replica per word (build with -DSIM_L=6 -DSIM_R=6)\n"); return 1; }
     std::unordered_set<State, SHash> seen;
     std::vector<std::vector<State>> cur(NSEG), nxt(NSEG);
     State init;
@@ -106,6 +109,14 @@ int main(int argc, char** argv) {
         for (int sg = 0; sg < NSEG; ++sg)
             for (long o = 0; o < (long)cur[sg].size(); o += 64) tiles.push_back({sg, o});
         if (tiles.empty()) break;
+        if (mode >= 2) {
+            // states that differ in ONE replica only — the parents of a common successor differ in two — end up near each other
+            // when the level is ordered by the other replicas' words (replica-major layout: word r = replica r)
+            const int a = 4 - mode, b = (a + 1) % 3, c = (a + 2) % 3;
+            std::sort(cur[0].begin(), cur[0].end(), [&](const State& x, const State& y) {
+                return x[a] != y[a] ? x[a] < y[a] : x[b] != y[b] ? x[b] < y[b] : x[c] < y[c];
+            });
+        }
         std::vector<Wave> waves(NW);
         if (mode == 0) {
             // per segment, tiles dealt round-robin to all waves (rotated start per segment, like the kernel)
@@ -145,7 +156,7 @@ int main(int argc, char** argv) {
                     }
                     if (seen.insert(s.t).second) w.stager.push_back(s.t);
                 }
-                const int seg = mode == 0 ? (wi / 4) % 8 : wi / 4;
+                const int seg = mode == 0 ? (wi / 4) % 8 : mode == 1 ? wi / 4 : 0;
                 while (w.stager.size() >= 64 || (w.done() && !w.stager.empty())) {
                     const size_t n = std::min<size_t>(64, w.stager.size());
                     nxt[seg].insert(nxt[seg].end(), w.stager.begin(), w.stager.begin() + n);
@@ -159,7 +170,7 @@ int main(int argc, char** argv) {
             printf("level %2d: %8.0f states %6.0f tiles  leaves/tile %5.1f  filter hits %4.1f %% of %9.0f probes\n", level, lv.states,
                    lv.tiles, lv.leaves / lv.tiles, 100.0 * lv.filter_hits / std::max(1.0, lv.probes), lv.probes);
         tot.tiles += lv.tiles; tot.leaves += lv.leaves; tot.probes += lv.probes; tot.filter_hits += lv.filter_hits; tot.states += lv.states;
-        if (!produced) break;
+        if (!produced || tot.states > MAXS) break;
     }
     printf("kind-major walk: %.2f effect leaves per tile (instance-major: %.2f)\n", g_kind_major_leaves / tot.tiles, tot.leaves / tot.tiles);
     printf("TOTAL mode %d NW %d CH %d FS %d: %.0f states, %.0f tiles (%.1f states/tile), leaves/tile %.2f, filter hits %.2f %% of %.0f probes\n",
