@@ -13,7 +13,7 @@ import pytest
 
 import kmo
 from kafka_specification_amd import CheckerConfig, ModelChecker
-from test_symmetry_cpu import permute_bytes
+from test_symmetry_cpu import constructed_state, permute_bytes, replica_keys_ascend
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -255,3 +255,33 @@ def test_six_billion_states_beyond_any_oracle():
                   max_leader_epoch=3, wide_fingerprint=True, table_capacity=1 << 31, frontier_capacity=1 << 28)
     assert (res.verdict, res.distinct, res.generated, res.depth) == ("ok", 6452700520, 20756484505, 54)
     assert res.orbit_representatives == 1075491542
+
+
+@pytest.mark.parametrize("model,N,L,R,E", [("Kip279", 5, 1, 1, 1), ("Kip279", 5, 2, 2, 1), ("KafkaTruncateToHighWatermark", 6, 1, 1, 1)])
+def test_device_representative_where_the_keys_do_not_tell_replicas_apart(model, N, L, R, E):
+    """KmcSymm::canon_sorted's third case ON THE DEVICE.  The searches never take it (no reachable state has been seen with a
+    tie between replicas that are told apart), so it is driven here through kmc_successors: under symmetry that entry point
+    lists a state's raw successors with the fingerprints of their REPRESENTATIVES, chosen by the kernel.  Parents are
+    constructed states with such ties (tests/test_symmetry_cpu.py: the same generator, the same definition restated on the
+    bytes); a successor that leaves the tied replicas alone keeps the tie."""
+    import random
+    rnd = random.Random(99 + N + L)
+    perms = list(itertools.permutations(range(N)))
+    mid = kmo.MODELS[model]
+    cfg = CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, symmetry=True,
+                        table_capacity=1 << 16, frontier_capacity=1 << 12)
+    told_apart = checked = 0
+    with ModelChecker(cfg) as mc:
+        for sample in range(40 if N == 5 else 12):
+            parent = constructed_state(rnd, mid, N, L, R, E, told_apart_tie=True)
+            for words, fp, _kind in mc.successors(mc.pack(parent)):
+                t = mc.unpack(words)
+                images = [permute_bytes(mid, N, L, E, t, img) for img in perms]
+                sorted_images = {x for x in images if replica_keys_ascend(mid, N, L, E, x)}
+                want = min(tuple(mc.pack(x)) for x in sorted_images)
+                assert fp == mc.fingerprint(want), (sample, t.hex())
+                stab, rep = mc.canonical(words)            # the host's run-time-layout form agrees
+                assert rep == want and stab == sum(1 for x in images if x == t)
+                told_apart += len(sorted_images) > 1
+                checked += 1
+    assert checked > 50 and told_apart > 20, (checked, told_apart)

@@ -78,6 +78,40 @@ def replica_keys_ascend(model, N, L, E, b):
     return all(keys[i] <= keys[i + 1] for i in range(N - 1))
 
 
+def constructed_state(rnd, model, N, L, R, E, told_apart_tie):
+    """A random type-correct Kafka state (canonical bytes) with few distinct (end, hw, epoch, log) combinations — ties between
+    replica keys are the point.  told_apart_tie: replicas 0 and 1 alike in every field and every count the key sees, but 0
+    sits in the ISR of replica 2 and 1 in that of replica 3, and those two differ (epoch): exchanging 0 and 1 is no
+    automorphism.  Then a random renaming."""
+    blk, g = 5 + L, N * (5 + L)
+    b = bytearray(g + 5 + 2 * (E + 1))
+    proto = [rnd.randrange(0, 2) for _ in range(4)]
+    for r in range(N):
+        end = proto[rnd.randrange(4)] % (L + 1)
+        b[r * blk:r * blk + 5] = bytes([end, rnd.randrange(0, end + 1), rnd.randrange(0, 2), rnd.randrange(0, N + 1),
+                                        rnd.randrange(0, 1 << N)])
+        for o in range(end):
+            b[r * blk + 5 + o] = 1   # record id 0, epoch 0
+    b[g:g + 5] = bytes([rnd.randrange(0, R + 1), rnd.randrange(0, E + 2), rnd.randrange(0, E + 2),
+                        rnd.randrange(0, N + 1), rnd.randrange(0, 1 << N)])
+    for e in range(E + 1):
+        b[g + 5 + 2 * e], b[g + 6 + 2 * e] = rnd.randrange(0, N + 1), rnd.randrange(0, 1 << N)
+    if told_apart_tie:
+        for r in (0, 1):
+            b[r * blk:(r + 1) * blk] = bytes([0, 0, 1, 0, 0] + [0] * L)
+        b[2 * blk + 2], b[3 * blk + 2] = 0, 1
+        for r in range(2, N):
+            b[r * blk + 3] = 0 if b[r * blk + 3] in (1, 2) else b[r * blk + 3]
+            b[r * blk + 4] &= ~3
+        b[2 * blk + 4] |= 1
+        b[3 * blk + 4] |= 2
+        for at in [g + 3] + [g + 5 + 2 * e for e in range(E + 1)]:
+            b[at] = 0 if b[at] in (1, 2) else b[at]
+            b[at + 1] &= ~3
+        b = bytearray(permute_bytes(model, N, L, E, bytes(b), rnd.sample(range(N), N)))
+    return bytes(b)
+
+
 UNROLLED_MAX = 4   # KMC_SYMM_UNROLLED_MAX (kmc_layout.h)
 
 
@@ -169,34 +203,7 @@ def test_sorted_images_when_the_keys_do_not_tell_replicas_apart(cfg6):
     told_apart = 0
     with host_emu.layout(cfg6), ModelChecker(CheckerConfig(model=name, device=-1, **_consts(cfg6))) as mc:
         for sample in range(120):
-            b = bytearray(g + 5 + 2 * (E + 1))
-            proto = [rnd.randrange(0, 2) for _ in range(4)]   # few distinct (end, hw, ep, log) combinations: ties are the point
-            for r in range(N):
-                end = proto[rnd.randrange(4)] % (L + 1)
-                b[r * blk:r * blk + 5] = bytes([end, rnd.randrange(0, end + 1), rnd.randrange(0, 2), rnd.randrange(0, N + 1),
-                                                rnd.randrange(0, 1 << N)])
-                for o in range(end):
-                    b[r * blk + 5 + o] = 1   # record id 0, epoch 0
-            b[g:g + 5] = bytes([rnd.randrange(0, R + 1), rnd.randrange(0, E + 2), rnd.randrange(0, E + 2),
-                                rnd.randrange(0, N + 1), rnd.randrange(0, 1 << N)])
-            for e in range(E + 1):
-                b[g + 5 + 2 * e], b[g + 6 + 2 * e] = rnd.randrange(0, N + 1), rnd.randrange(0, 1 << N)
-            if sample % 2:
-                # replicas 0 and 1 alike in every field and every count, but 0 sits in the ISR of replica 2 and 1 in that of
-                # replica 3, and those two differ (epoch): exchanging 0 and 1 is no automorphism.  Then a random renaming.
-                for r in (0, 1):
-                    b[r * blk:(r + 1) * blk] = bytes([0, 0, 1, 0, 0] + [0] * L)
-                b[2 * blk + 2], b[3 * blk + 2] = 0, 1
-                for r in range(2, N):
-                    b[r * blk + 3] = 0 if b[r * blk + 3] in (1, 2) else b[r * blk + 3]
-                    b[r * blk + 4] &= ~3
-                b[2 * blk + 4] |= 1
-                b[3 * blk + 4] |= 2
-                for at in [g + 3] + [g + 5 + 2 * e for e in range(E + 1)]:
-                    b[at] = 0 if b[at] in (1, 2) else b[at]
-                    b[at + 1] &= ~3
-                b = bytearray(permute_bytes(model, N, L, E, bytes(b), rnd.sample(range(N), N)))
-            s = bytes(b)
+            s = constructed_state(rnd, model, N, L, R, E, told_apart_tie=sample % 2 == 1)
             assert mc.unpack(mc.pack(s)) == s
             images = [permute_bytes(model, N, L, E, s, img) for img in perms]
             sorted_images = {t for t in images if replica_keys_ascend(model, N, L, E, t)}
