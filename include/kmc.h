@@ -57,7 +57,7 @@ extern "C" {
 
 #define KMC_MAX_KINDS 16
 #define KMC_MAX_SHARDS 8
-#define KMC_SYMMETRY_MAX_REPLICAS 6   /* kmc_config.symmetry: |Replicas|! images per state, 720 at most */
+#define KMC_SYMMETRY_MAX_REPLICAS 7   /* kmc_config.symmetry: |Replicas|! images per state, 5040 at most */
 #define KMC_SEND_SUBS 8     /* sub-buffers per destination in the send area (spreads the append counters) */
 #define KMC_COMM_ID_BYTES 128   /* an RCCL unique id (ncclUniqueId) */
 #define KMC_EXCHANGE_STATS 64   /* longest statistics vector that can ride on a level's count exchange */

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("KMC_LIB_PATH") or os.path.join(_HERE, "libkmc.so")  #
 
 KMC_MAX_KINDS = 16
 KMC_MAX_SHARDS = 8
-KMC_SYMMETRY_MAX_REPLICAS = 6
+KMC_SYMMETRY_MAX_REPLICAS = 7
 KMC_SEND_SUBS = 8
 KMC_COMM_ID_BYTES = 128
 KMC_EXCHANGE_STATS = 64

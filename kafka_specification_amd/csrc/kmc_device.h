@@ -1533,7 +1533,7 @@ template <class M> struct KmcSymm {
     static constexpr bool KAFKA = Y.model != KMC_MODEL_FINITE_REPLICATED_LOG;
     static constexpr int NFACT = kmc_factorial(N);
     static_assert(kmc_model_symmetric(Y.model), "this model singles out a replica: no symmetry reduction");
-    static_assert(N <= 6, "orbit representatives are found by trying all N! permutations: N <= 6");
+    static_assert(N <= KMC_SYMM_MAX_REPLICAS, "orbit counting: the walk through all images (canon_sorted's last resort) is a table of N! - 1 steps");
     static constexpr bool UNROLLED = N <= KMC_SYMM_UNROLLED_MAX;   // N! - 1 statically specialised permutations; beyond: the sorted images (canon_sorted)
     static constexpr int PB = KAFKA ? Y.BL + Y.BI : 1;       // bits of a (leader, isr) pair: 5 at N = 3, 7 at N = 4
     static constexpr int PER = 32 / PB;                      // images per table word
@@ -1836,49 +1836,52 @@ template <class M> struct KmcSymm {
         stab = n;
     }
 
-    // c = the orbit's representative (the smallest image, word 0 first), stab = the permutations that fix s
+    // c = the orbit's representative (the smallest image, word 0 first; beyond KMC_SYMM_UNROLLED_MAX replicas among the sorted
+    // images), stab = the permutations that fix s
+    // (the unrolled forms sit in `else` branches: N! - 1 instantiations of permute<P> must not even be attempted at 7 replicas)
     static KMC_DEV void canon(const u64* s, const u32* tab, u64* c, u32& stab) {
         if constexpr (!UNROLLED) {
             canon_sorted(s, tab, c, stab);
-            return;
+        } else {
+            Prep p;
+            prepare(s, tab, p);
+#pragma unroll
+            for (int k = 0; k < W; ++k) c[k] = s[k];
+            u32 n = 1;
+            kmc_static_for<1, NFACT>([&](auto PP) {
+                u64 t[W];
+                permute<decltype(PP)::value>(s, p, t);
+                bool lt = false, eq = true;
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    lt = lt || (eq && t[k] < c[k]);
+                    eq = eq && t[k] == c[k];
+                }
+                n = lt ? 1u : n + (eq ? 1u : 0u);
+#pragma unroll
+                for (int k = 0; k < W; ++k) c[k] = lt ? t[k] : c[k];
+            });
+            stab = n;
         }
-        Prep p;
-        prepare(s, tab, p);
-#pragma unroll
-        for (int k = 0; k < W; ++k) c[k] = s[k];
-        u32 n = 1;
-        kmc_static_for<1, NFACT>([&](auto PP) {
-            u64 t[W];
-            permute<decltype(PP)::value>(s, p, t);
-            bool lt = false, eq = true;
-#pragma unroll
-            for (int k = 0; k < W; ++k) {
-                lt = lt || (eq && t[k] < c[k]);
-                eq = eq && t[k] == c[k];
-            }
-            n = lt ? 1u : n + (eq ? 1u : 0u);
-#pragma unroll
-            for (int k = 0; k < W; ++k) c[k] = lt ? t[k] : c[k];
-        });
-        stab = n;
     }
     static KMC_DEV u32 stabiliser(const u64* s, const u32* tab) {
         if constexpr (!UNROLLED) {
             u64 c[W];
             return walk<false>(s, tab, c);
-        }
-        Prep p;
-        prepare(s, tab, p);
-        u32 n = 1;
-        kmc_static_for<1, NFACT>([&](auto PP) {
-            u64 t[W];
-            permute<decltype(PP)::value>(s, p, t);
-            bool eq = true;
+        } else {
+            Prep p;
+            prepare(s, tab, p);
+            u32 n = 1;
+            kmc_static_for<1, NFACT>([&](auto PP) {
+                u64 t[W];
+                permute<decltype(PP)::value>(s, p, t);
+                bool eq = true;
 #pragma unroll
-            for (int k = 0; k < W; ++k) eq = eq && t[k] == s[k];
-            n += eq ? 1u : 0u;
-        });
-        return n;
+                for (int k = 0; k < W; ++k) eq = eq && t[k] == s[k];
+                n += eq ? 1u : 0u;
+            });
+            return n;
+        }
     }
     // what a state of stabiliser order `stab` lacks to a full orbit: N! - N!/stab (0 for almost every state)
     static KMC_DEV u32 deficit(u32 stab) { return stab == 1 ? 0u : (u32)NFACT - (u32)NFACT / stab; }

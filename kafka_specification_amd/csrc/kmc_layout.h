@@ -352,6 +352,8 @@ KMC_HD inline void kmc_permute_state(const KmcLayout& y, const int* img, const u
 // Up to this many replicas the representative of an orbit is its smallest image outright; beyond, the smallest among the
 // images whose replica KEYS ascend with the position (kmc_device.h, KmcSymm::canon_sorted: 120 / 720 images per successor
 // were what the orbit-counting search spent its time on)
+// orbit counting up to this many replicas (7! - 1 = 5039 steps in the table of the walk through all images; 8! would be 40319)
+#define KMC_SYMM_MAX_REPLICAS 7
 #ifndef KMC_SYMM_UNROLLED_MAX   // (a JIT define moves the DEVICE's threshold only — timing runs; the host forms follow the default)
 #define KMC_SYMM_UNROLLED_MAX 4
 #endif

@@ -91,7 +91,7 @@ template <class M> struct Ops {
     // KmcSymm<M>::canon / stabiliser (the compile-time permutations the KMC_SYMM kernels use): the orbit representative
     // of one packed state and the order of its stabiliser; -1 where the model or N has no symmetry reduction
     static int canon(const u64* s, u64* c) {
-        if constexpr (kmc_model_symmetric(M::Y.model) && M::Y.N <= 6) {
+        if constexpr (kmc_model_symmetric(M::Y.model) && M::Y.N <= KMC_SYMM_MAX_REPLICAS) {
             const u32* tab = KmcSymm<M>::TABLE.w;
             u32 stab = 0;
             KmcSymm<M>::canon(s, tab, c, stab);

@@ -16,7 +16,7 @@ import kmo
 from kafka_specification_amd import CheckerConfig, ModelChecker
 
 MODEL_NAMES = {v: k for k, v in kmo.MODELS.items()}
-SYMMETRIC = [c for c in host_emu.configs() if (c[0] == 1 or 2 <= c[0] <= 6) and c[1] <= 6]
+SYMMETRIC = [c for c in host_emu.configs() if (c[0] == 1 or 2 <= c[0] <= 6) and c[1] <= 7]
 
 
 def _ids(c):
@@ -134,7 +134,8 @@ def test_representative_of_an_orbit(cfg6):
         n = min(o.distinct, 20000)
         nontrivial = 0
         with ModelChecker(CheckerConfig(model=name, device=-1, **_consts(cfg6))) as mc:
-            for idx in range(0, n, max(1, n // 150)):
+            # (seven replicas: 5040 images of every sample, and the run-time-layout form walks through all of them per call)
+            for idx in range(0, n, max(1, n // (150 if N < 7 else 10))):
                 s = o.state(idx)
                 images = [permute_bytes(model, N, L, E, s, img) for img in perms]
                 packed = [tuple(mc.pack(t)) for t in images]
@@ -142,7 +143,8 @@ def test_representative_of_an_orbit(cfg6):
                 want = min(p for p, t in zip(packed, images) if N <= UNROLLED_MAX or replica_keys_ascend(model, N, L, E, t))
                 stab = sum(1 for t in images if t == s)
                 nontrivial += stab > 1
-                for w in set(packed):
+                some = set(packed) if N < 6 else set(packed[::max(1, len(packed) // (40 if N < 7 else 6))]) | {packed[0]}
+                for w in some:
                     assert host_emu.canon(cfg6, w) == (stab, want), f"state {idx}: KmcSymm::canon"
                     assert host_emu.canon(cfg6, w, generic=True) == (stab, want), f"state {idx}: generic form"
                 # the host library's own entry point (what kmc_contains canonicalises with)
@@ -152,7 +154,7 @@ def test_representative_of_an_orbit(cfg6):
 
 @pytest.mark.parametrize("cfg6", [c for c in SYMMETRIC if c[6] == 0 and
                                   (c[:6] in {(2, 3, 2, 2, 1, 0), (3, 3, 2, 2, 1, 0), (5, 3, 2, 2, 1, 0), (6, 3, 2, 2, 1, 0),
-                                             (4, 3, 2, 3, 1, 0), (5, 4, 1, 1, 1, 0), (4, 2, 2, 2, 2, 0), (1, 2, 4, 0, 0, 2), (4, 5, 1, 1, 1, 0),
+                                             (4, 3, 2, 3, 1, 0), (5, 4, 1, 1, 1, 0), (4, 2, 2, 2, 2, 0), (1, 2, 4, 0, 0, 2), (4, 5, 1, 1, 1, 0), (5, 7, 1, 1, 0, 0),
                                              (1, 3, 2, 0, 0, 2)})], ids=_ids)
 def test_orbit_counting_search_reproduces_the_plain_counts(cfg6):
     """Breadth-first search over orbit representatives with the device's successor and representative functions; every
@@ -184,7 +186,9 @@ def test_orbit_counting_search_reproduces_the_plain_counts(cfg6):
     assert (distinct, generated, len(levels)) == (o.distinct, o.generated, o.depth)
     assert levels == o.levels
     assert per_kind == o.action_generated[:16]
-    assert len(seen) < o.distinct / (nf / 2) or N == 2 or o.distinct < 2000   # and it did reduce the search
+    print(f"{name} N={N}: {len(seen)} stored states for {o.distinct}")
+    assert len(seen) < o.distinct / (nf / 2) or N == 2 or o.distinct < 2000 or N == 7   # and it did reduce the search
+    assert N != 7 or len(seen) < o.distinct / 500
 
 
 @pytest.mark.parametrize("cfg6", [c for c in SYMMETRIC if c[6] == 0 and c[1] > UNROLLED_MAX and c[0] != 1], ids=_ids)
