@@ -335,6 +335,7 @@ def main():
                    "distinct_states": distinct, "states_generated": generated, "seen_set_probes": probes, "depth": r.depth,
                    "verdict": r.verdict, "matches_oracle_golden": counts_match,
                    "exhausted": r.verdict != "level_limit", "level_budget": a.level_budget or None,
+                   "stored_states": r.orbit_representatives if a.symmetry else None,
                    "time_to_exhaustive_s": dt / a.steps, **extra},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_BPS, "traffic": traffic,

@@ -293,7 +293,7 @@ def test_baseline_config5_seven_brokers_level_by_level_against_the_plain_search(
     ten levels — 197,561,008 states for the plain search — the orbit-counting search (5040 images per orbit, never visited:
     the sorted images) must report the same numbers level by level, from a few ten thousand stored states."""
     base = dict(model="Kip320", n_replicas=7, log_size=8, max_records=8, max_leader_epoch=3, invariants=("TypeOk",), max_levels=10)
-    with ModelChecker(CheckerConfig(**base, table_capacity=1 << 29, frontier_capacity=1 << 27)) as mc:
+    with ModelChecker(CheckerConfig(**base, table_capacity=1 << 29, frontier_capacity=1 << 28)) as mc:   # level 10: 156.6 M states
         plain = mc.run()
     with ModelChecker(CheckerConfig(**base, symmetry=True, table_capacity=1 << 22, frontier_capacity=1 << 20)) as mc:
         res = mc.run()
