@@ -301,4 +301,7 @@ def test_baseline_config5_seven_brokers_level_by_level_against_the_plain_search(
     assert (res.verdict, res.distinct, res.generated, res.depth, res.levels) == \
         (plain.verdict, plain.distinct, plain.generated, plain.depth, plain.levels)
     assert res.action_generated == plain.action_generated and res.generated_repeats == plain.generated_repeats
-    assert res.orbit_representatives < plain.distinct / 2000
+    # (5040 images per orbit at best; the early levels' states have large stabilisers.  The run above fitted a frontier of
+    # 2^20 stored states, and level 10 is four fifths of everything.)
+    assert res.orbit_representatives < plain.distinct / 100, res.orbit_representatives
+    print(f"config 5, 10 levels: {res.orbit_representatives} stored states for {res.distinct}")
