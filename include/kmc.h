@@ -208,7 +208,7 @@ int kmc_unpack_state(kmc_handle* h, const uint64_t* words, uint8_t* canon);
 int kmc_pack_state(kmc_handle* h, const uint8_t* canon, uint64_t* words);
 uint64_t kmc_fingerprint_of(kmc_handle* h, const uint64_t* words);
 /* The representative of a packed state's orbit under the permutations of Replicas — the smallest image, words compared in
- * order as unsigned values; with five and six replicas the smallest among the images whose replicas stand in ascending
+ * order as unsigned values; with five to seven replicas the smallest among the images whose replicas stand in ascending
  * order of a name-independent key (log, offsets, epoch, what the state says about the replica: kmc_layout.h,
  * kmc_replica_key_generic) — and the number of permutations that leave the state unchanged: its orbit has
  * |Replicas|! / *stabiliser members.  What a kmc_config.symmetry search stores; works on host-only handles. */

@@ -235,7 +235,7 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
                     cfg.max_records, cfg.max_leader_epoch, cfg.n_log_records);
     *kname = name;
     if (cfg.symmetry && (!kmc_model_symmetric(cfg.model) || cfg.n_replicas > KMC_SYMMETRY_MAX_REPLICAS || cfg.n_shards > 1))
-        return fail(KMC_E_ARG, "symmetry (orbit counting) is for the Kafka family and FiniteReplicatedLog with at most 6 replicas "
+        return fail(KMC_E_ARG, "symmetry (orbit counting) is for the Kafka family and FiniteReplicatedLog with at most 7 replicas "
                                "on one GPU: %s singles out a replica, or N = %d > %d, or n_shards = %d > 1",
                     MODEL_NAMES[cfg.model], cfg.n_replicas, KMC_SYMMETRY_MAX_REPLICAS, cfg.n_shards);
     // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_MIN_WAVES=5 -DKMC_PROFILE=1"
