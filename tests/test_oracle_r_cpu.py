@@ -261,3 +261,68 @@ Small == x + y * 2 <= 4 /\\ {x, y} \\subseteq 0 .. 2
         r = Checker("J", {}, [d]).run(invariants=("Small",), check_deadlock=False)
     # x: 0 -> 1 -> {2, 0}; at x = 2 only B moves (y 0 -> 1, then a self-loop)
     assert r["distinct"] == 4 and r["verdict"] == "ok" and r["action_generated"] == {"A": 3, "B": 2}
+
+
+# ------------------------------------------------------------------------------------------------
+# The premise of orbit counting, checked by EXECUTING the reference's text
+# ------------------------------------------------------------------------------------------------
+def _rename(v, m):
+    """The TLA+ value v with every model value renamed through m (functions, records, tuples, sets, nested)."""
+    from oracle.tlar import Fn, ModelValue
+    if isinstance(v, ModelValue):
+        return m.get(v, v)
+    if isinstance(v, Fn):
+        return Fn({_rename(k, m): _rename(x, m) for k, x in v.d.items()})
+    if isinstance(v, frozenset):
+        return frozenset(_rename(x, m) for x in v)
+    if isinstance(v, tuple):
+        return tuple(_rename(x, m) for x in v)
+    assert isinstance(v, (int, str, bool)), type(v)
+    return v
+
+
+@live
+@pytest.mark.parametrize("module", KAFKA + ("FiniteReplicatedLog",))
+def test_live_every_permutation_of_replicas_is_an_automorphism(module):
+    """kmc_config.symmetry stores one state per orbit of the permutations of Replicas and weighs every count by the orbit's
+    size.  That rests on one claim about the SPECS: renaming the replicas maps Init to Init, the successors of a state under
+    each disjunct of Next onto the successors of the renamed state under the same disjunct (with multiplicity: the doubly
+    satisfied disjuncts), and keeps every invariant.  Here the claim is not argued from a reading of the text but checked
+    by running the text: Oracle-R's reachable states of a 3-replica configuration, every one of the 5 non-trivial renamings."""
+    import itertools
+    from collections import Counter
+    from oracle.tlar import Checker, ModelValue
+    if module == "FiniteReplicatedLog":
+        reps = [ModelValue(f"r{i}") for i in (1, 2, 3)]
+        consts = dict(Replicas=frozenset(reps), LogRecords=frozenset(ModelValue(f"x{i}") for i in (1, 2)), Nil=ModelValue("nil"),
+                      LogSize=2)
+        invariants = ("TypeOk",)
+    else:
+        consts = oc.kafka_constants(3, 1, 1, 1)
+        reps = sorted(consts["Replicas"], key=lambda r: r.name)
+        invariants = KAFKA_INV + ("LeaderInIsr",)
+    ck = Checker(module, consts, [os.path.join(ROOT, "models"), REFERENCE])
+    # (nine whole levels: a renaming keeps the distance from Init, so the states of whole levels are closed under it)
+    r = ck.run(invariants=(), stop_on_violation=False, keep_states=True, max_levels=9)
+    ip = ck.interp
+    states = [st if isinstance(st, dict) else ck.unkey(st) for lv in r["level_states"] for st in lv]
+    assert len(states) > 300
+    renamings = [dict(zip(reps, p)) for p in itertools.permutations(reps)][1:]
+    for init in ip.initial_states():
+        for m in renamings:
+            assert {v: _rename(x, m) for v, x in init.items()} == init
+    reachable = {ck.key(st) for st in states}
+    moved = 0
+    for st in states[::max(1, len(states) // 150)]:
+        succ = Counter((lab, ck.key({v: x for v, x in t.items()})) for lab, t in ip.successors(st))
+        held = {inv: ip.holds(st, inv) for inv in invariants}
+        for m in renamings:
+            image = {v: _rename(x, m) for v, x in st.items()}
+            assert ck.key(image) in reachable                      # the reachable set is closed under renaming
+            moved += image != st
+            want = Counter((lab, ck.key({v: _rename(x, m) for v, x in ck.unkey(k).items()})) for (lab, k), n in succ.items()
+                           for _ in range(n))
+            got = Counter((lab, ck.key(t)) for lab, t in ip.successors(image))
+            assert got == want, (module, st)
+            assert {inv: ip.holds(image, inv) for inv in invariants} == held
+    assert moved > 100   # and the renamings did move states
