@@ -23,3 +23,8 @@ done
 for m in Kip101 Kip279 Kip320FirstTry; do
   ./oracle/kmc_oracle --model $m --N 3 --L 6 --R 6 --E 2 --threads 8 --inv 1 --fp-only --table-log2 31 > tests/golden/oracle_fp_$(echo $m | tr A-Z a-z)_3_6_6_2.json
 done
+# BASELINE config 5 (7 brokers, LogSize 8) cannot be exhausted: the exact oracle's PREFIX of ten levels (197,561,008 states,
+# 2.5 minutes, ~25 GB) — what the plain and the orbit-counting GPU searches are held to over a level budget of 10
+# (written through tests/kmo.py: kmo.Run(make_config("Kip320", N=7, L=8, R=8, E=3, threads=8, max_states=41002348)) -> levels, generated,
+#  action_generated; the stand-alone binary's equivalent:)
+# ./oracle/kmc_oracle --model Kip320 --N 7 --L 8 --R 8 --E 3 --threads 8 --inv 1 --max-states 41002348 > tests/golden/oracle_kip320_7_8_8_3_levels10.json

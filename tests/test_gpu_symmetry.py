@@ -297,7 +297,10 @@ def test_baseline_config5_seven_brokers_level_by_level_against_the_plain_search(
         plain = mc.run()
     with ModelChecker(CheckerConfig(**base, symmetry=True, table_capacity=1 << 22, frontier_capacity=1 << 20)) as mc:
         res = mc.run()
-    assert plain.distinct == 197561008 and plain.verdict == "level_limit"
+    g = json.load(open(os.path.join(GOLDEN, "oracle_kip320_7_8_8_3_levels10.json")))   # the exact C oracle's ten-level prefix
+    assert plain.verdict == "level_limit"
+    assert (plain.distinct, plain.generated, plain.levels) == (g["distinct"], g["generated"], g["levels"]) and g["distinct"] == 197561008
+    assert list(plain.action_generated.values()) == g["action_generated"][:len(plain.action_generated)]
     assert (res.verdict, res.distinct, res.generated, res.depth, res.levels) == \
         (plain.verdict, plain.distinct, plain.generated, plain.depth, plain.levels)
     assert res.action_generated == plain.action_generated and res.generated_repeats == plain.generated_repeats
