@@ -219,3 +219,34 @@ def test_sorted_images_when_the_keys_do_not_tell_replicas_apart(cfg6):
                 assert host_emu.canon(cfg6, w) == (stab, want)
                 assert host_emu.canon(cfg6, w, generic=True) == (stab, want)
     assert told_apart >= 40, told_apart
+
+
+def test_orbit_counting_prefix_at_baseline_config5_constants():
+    """BASELINE config 5 (Kip320, 7 brokers, LogSize 8, MaxRecords 8, MaxLeaderEpoch 3 — ten words per state, 5040 images per
+    orbit): the first seven levels of the orbit-counting search, replayed on the CPU with the device's successor and
+    representative functions, weigh up to the exact oracle's level sizes (tests/golden/oracle_kip320_7_8_8_3_levels10.json)."""
+    import json
+    import os
+    cfg6 = (5, 7, 8, 8, 3, 0, 0)
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                       "oracle_kip320_7_8_8_3_levels10.json")))["levels"][:7]
+    nf = factorial(7)
+    with host_emu.layout(cfg6):
+        st0, init = host_emu.canon(cfg6, host_emu.init(cfg6))
+        assert st0 == nf
+        seen = {init: st0}
+        frontier, levels = [init], []
+        while frontier and len(levels) < len(want):
+            levels.append(sum(nf // seen[s] for s in frontier))
+            if len(levels) == len(want):
+                break
+            nxt = []
+            for s in frontier:
+                for _kind, t in host_emu.successors(cfg6, s):
+                    st, c = host_emu.canon(cfg6, t)
+                    if c not in seen:
+                        seen[c] = st
+                        nxt.append(c)
+            frontier = nxt
+    assert levels == want
+    assert len(seen) < sum(want) / 300   # 1,271,426 states from a few thousand stored ones
