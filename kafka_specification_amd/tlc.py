@@ -92,7 +92,7 @@ def main(argv=None) -> int:
                     help="orbit counting: the specs never tell two members of Replicas apart, so one state per orbit of the "
                          "permutations of Replicas is stored and expanded and every count is weighted by its orbit's size — the "
                          "numbers printed are those of the plain search (TLC without a SYMMETRY set; TLC's own SYMMETRY prints "
-                         "the reduced counts) from ~1/|Replicas|! of the work.  Kafka family / FiniteReplicatedLog, up to 4 "
+                         "the reduced counts) from ~1/|Replicas|! of the work.  Kafka family / FiniteReplicatedLog, up to 7 "
                          "replicas, one GPU")
     ap.add_argument("-fpcheck", action="store_true",
                     help="run the search again with a second fingerprint seed and compare the counts")
