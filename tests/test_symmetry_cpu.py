@@ -206,7 +206,8 @@ def test_sorted_images_when_the_keys_do_not_tell_replicas_apart(cfg6):
     blk, g = 5 + L, N * (5 + L)
     told_apart = 0
     with host_emu.layout(cfg6), ModelChecker(CheckerConfig(model=name, device=-1, **_consts(cfg6))) as mc:
-        for sample in range(120):
+        samples = 120 if N < 7 else 24   # (5040 images of every sample, permuted in Python)
+        for sample in range(samples):
             s = constructed_state(rnd, model, N, L, R, E, told_apart_tie=sample % 2 == 1)
             assert mc.unpack(mc.pack(s)) == s
             images = [permute_bytes(model, N, L, E, s, img) for img in perms]
@@ -218,7 +219,7 @@ def test_sorted_images_when_the_keys_do_not_tell_replicas_apart(cfg6):
                 w = tuple(mc.pack(t))
                 assert host_emu.canon(cfg6, w) == (stab, want)
                 assert host_emu.canon(cfg6, w, generic=True) == (stab, want)
-    assert told_apart >= 40, told_apart
+    assert told_apart >= samples // 3, told_apart
 
 
 def test_orbit_counting_prefix_at_baseline_config5_constants():
