@@ -28,3 +28,7 @@ done
 # (written through tests/kmo.py: kmo.Run(make_config("Kip320", N=7, L=8, R=8, E=3, threads=8, max_states=41002348)) -> levels, generated,
 #  action_generated; the stand-alone binary's equivalent:)
 # ./oracle/kmc_oracle --model Kip320 --N 7 --L 8 --R 8 --E 3 --threads 8 --inv 1 --max-states 41002348 > tests/golden/oracle_kip320_7_8_8_3_levels10.json
+# ... and beyond what the plain search fits anywhere: the orbit-counting oracle (oracle/orbit_oracle.c), 14 levels in one minute
+# (50,390,682,994 states from 18.9 M stored ones), 17 levels with the last level kept as fingerprints only (~40 minutes, ~35 GB)
+./oracle/orbit_oracle --model Kip320 --N 7 --L 8 --R 8 --E 3 --levels 14 --threads 8 --table-log2 26 > tests/golden/orbit_kip320_7_8_8_3_levels14.json
+# ./oracle/orbit_oracle --model Kip320 --N 7 --L 8 --R 8 --E 3 --levels 17 --last-level-fp --threads 8 --table-log2 29 --max-stored 230000000 --fp-table-log2 30 > tests/golden/orbit_kip320_7_8_8_3_levels17.json

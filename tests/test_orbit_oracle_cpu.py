@@ -1,0 +1,78 @@
+"""Oracle-O (oracle/orbit_oracle.c): the C oracle's successor function under a search over ORBITS of the permutations of
+Replicas, every count weighted by the orbit's size — the independent check of the HIP engine's orbit counting
+(kmc_config.symmetry) where the plain search fits nobody's memory.
+
+What it shares with the device is the idea; states (canonical bytes), renaming, the choice of representatives and the
+seen-set are its own (header of orbit_oracle.c).  Here it is held to the PLAIN oracle wherever that one still runs, and its
+fixtures for BASELINE config 5 are held to what the GPU printed (profiles/) — tests/test_gpu_symmetry.py holds the GPU to
+the same fixtures on the GPU box."""
+import json
+import os
+import subprocess
+
+import pytest
+
+import kmo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "orbit_oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+KAFKA = ("KafkaTruncateToHighWatermark", "Kip101", "Kip279", "Kip320", "Kip320FirstTry")
+
+
+def orbit_oracle(model, N, L, R, E, *extra):
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "orbit_oracle"])
+    out = subprocess.run([EXE, "--model", model, "--N", str(N), "--L", str(L), "--R", str(R), "--E", str(E), "--threads", "4",
+                          "--table-log2", "22", *extra], capture_output=True, text=True, check=True).stdout
+    return json.loads(out)
+
+
+@pytest.mark.parametrize("model", KAFKA)
+@pytest.mark.parametrize("N,L,R,E", [(2, 2, 2, 1), (3, 2, 2, 1), (3, 1, 1, 2), (2, 3, 3, 2), (4, 1, 1, 1), (5, 1, 1, 0)])
+def test_the_orbit_search_reports_the_plain_oracles_numbers(model, N, L, R, E):
+    o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=(), check_deadlock=False, threads=4))
+    r = orbit_oracle(model, N, L, R, E)
+    assert r["exhausted"] and (r["distinct"], r["generated"], r["depth"]) == (o.distinct, o.generated, o.depth)
+    assert r["levels"] == o.levels
+    assert r["action_generated"] == o.action_generated[:len(r["action_generated"])]
+    assert r["deadlock_states"] == o.deadlock_states
+    assert r["stored"] < o.distinct or o.distinct < 10
+
+
+def test_baseline_config4_and_a_level_budget():
+    g = json.load(open(os.path.join(GOLDEN, "oracle_kip279_5_2_2_1.json")))   # the plain oracle, 112,549,196 states
+    r = orbit_oracle("Kip279", 5, 2, 2, 1, "--table-log2", "23")
+    assert (r["distinct"], r["generated"], r["depth"], r["deadlock_states"]) == (g["distinct"], g["generated"], g["depth"], g["deadlock_states"])
+    n = len(g["action_generated"])
+    assert r["levels"] == g["levels"] and r["action_generated"][:n] == g["action_generated"] and not any(r["action_generated"][n:])
+    assert r["stored"] == 1087197        # ... what the GPU's orbit-counting search stores (profiles/r03_sym_ladder.jsonl)
+    # a level budget; and the last level kept as fingerprints only gives the same numbers
+    a = orbit_oracle("Kip279", 5, 2, 2, 1, "--levels", "12")
+    b = orbit_oracle("Kip279", 5, 2, 2, 1, "--levels", "12", "--last-level-fp")
+    assert a["levels"] == g["levels"][:12] == b["levels"] and a["generated"] == b["generated"] and not a["exhausted"]
+
+
+def test_config5_fixtures_against_the_plain_oracle_and_against_what_the_gpu_printed():
+    """BASELINE config 5 (Kip320, 7 brokers, LogSize 8, MaxRecords 8, MaxLeaderEpoch 3).  The orbit oracle's fixture over 14
+    levels (tests/golden/make_golden.sh, one minute on 8 cores) starts with the plain oracle's ten levels, and both its level
+    budgets present in profiles/r03_config5_orbit_counting.jsonl carry the numbers the GPU printed there."""
+    g10 = json.load(open(os.path.join(GOLDEN, "oracle_kip320_7_8_8_3_levels10.json")))
+    fixtures = [json.load(open(os.path.join(GOLDEN, f))) for f in sorted(os.listdir(GOLDEN)) if f.startswith("orbit_kip320_7_8_8_3_levels")]
+    assert fixtures
+    gpu = {}
+    for line in open(os.path.join(ROOT, "profiles", "r03_config5_orbit_counting.jsonl")):
+        if line.startswith("{"):
+            d = json.loads(line)
+            gpu[d["config"]["level_budget"]] = (d["config"]["distinct_states"], d["config"]["states_generated"])
+    for f in fixtures:
+        assert f["levels"][:10] == g10["levels"] and sum(f["levels"]) == f["distinct"] and f["depth"] == len(f["levels"])
+        assert f["levels"][:len(fixtures[0]["levels"])] == fixtures[0]["levels"]        # the deeper one extends the shallower
+        assert gpu[f["depth"]] == (f["distinct"], f["generated"]), f"the GPU's {f['depth']}-level run printed {gpu[f['depth']]}"
+    assert gpu[10] == (g10["distinct"], g10["generated"])
+
+
+def test_config5_seven_levels_live():
+    r = orbit_oracle("Kip320", 7, 8, 8, 3, "--levels", "8")
+    g10 = json.load(open(os.path.join(GOLDEN, "oracle_kip320_7_8_8_3_levels10.json")))
+    assert r["levels"] == g10["levels"][:8] and r["stored_per_level"][:5] == [1, 2, 6, 24, 117]
