@@ -308,3 +308,19 @@ def test_baseline_config5_seven_brokers_level_by_level_against_the_plain_search(
     # 2^20 stored states, and level 10 is four fifths of everything.)
     assert res.orbit_representatives < plain.distinct / 100, res.orbit_representatives
     print(f"config 5, 10 levels: {res.orbit_representatives} stored states for {res.distinct}")
+
+
+def test_baseline_config5_deep_levels_against_the_orbit_counting_oracle():
+    """BASELINE config 5 beyond anything a plain search fits: the deepest level budget for which the orbit-counting CPU oracle
+    (oracle/orbit_oracle.c — the idea of kmc_config.symmetry with states, renaming, representatives and seen-set of its own;
+    tests/test_orbit_oracle_cpu.py holds it to the plain oracle) has a fixture.  14 levels: 50,390,682,994 states.
+    Capacities and invariants are those of the measured run (profiles/r03_config5_orbit_counting.jsonl)."""
+    names = sorted((f for f in os.listdir(GOLDEN) if f.startswith("orbit_kip320_7_8_8_3_levels")),
+                   key=lambda f: int(f.split("levels")[1].split(".")[0]))
+    g = json.load(open(os.path.join(GOLDEN, names[-1])))
+    res = sym_run("Kip320", invariants=("TypeOk", "WeakIsr", "StrongIsr"), n_replicas=7, log_size=8, max_records=8,
+                  max_leader_epoch=3, max_levels=g["depth"], table_capacity=1 << 31, frontier_capacity=1 << 29)
+    assert res.verdict == "level_limit"
+    assert (res.distinct, res.generated, res.depth, res.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
+    assert list(res.action_generated.values()) == g["action_generated"][:len(res.action_generated)]
+    assert res.orbit_representatives == g["stored"]
