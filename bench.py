@@ -48,6 +48,19 @@ def device_source_sha256():
     return h.hexdigest()
 
 
+def headline_kernel_code_sha256():
+    """Identity of the MACHINE CODE of the headline's kernels (kmc.kernel_code_sha256: .text + kernel descriptors + metadata
+    of the cached code object this very run loads).  kmc_device.h also holds the orbit-counting, verify and profiling
+    builds behind #if: an edit there changes the source hash and leaves the headline's instructions as they were."""
+    try:
+        import kafka_specification_amd as kmc
+        c = headline_config()
+        return kmc.kernel_code_sha256(kmc.CheckerConfig(**c))
+    except Exception as e:   # no hiprtc, no library: the source hash alone decides
+        sys.stderr.write(f"bench.py: kernel_code_sha256 unavailable ({str(e)[:120]})\n")
+        return None
+
+
 def newest_profile(suffix):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
@@ -111,10 +124,16 @@ def measured_traffic():
         j = json.load(open(path))
     except Exception as e:
         return None, f"{os.path.relpath(path, ROOT)}: {e}"
-    if j.get("device_source_sha256") != device_source_sha256():
-        return None, (f"{os.path.relpath(path, ROOT)} was measured on other device code "
-                      f"({str(j.get('device_source_sha256'))[:12]}..., now {device_source_sha256()[:12]}...): not quoted")
-    return j.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
+    if j.get("device_source_sha256") == device_source_sha256():
+        return j.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
+    # other source text: quoted only if the kernels' machine code is what the summary was measured on
+    code = headline_kernel_code_sha256() if j.get("kernel_code_sha256") else None
+    if code and j["kernel_code_sha256"] == code:
+        return j.get("hbm_bytes_per_launch"), (f"{os.path.relpath(path, ROOT)} (device sources edited since, the headline's "
+                                               f"code object is instruction for instruction the measured one: "
+                                               f"kernel_code_sha256 {code[:16]})")
+    return None, (f"{os.path.relpath(path, ROOT)} was measured on other device code "
+                  f"({str(j.get('device_source_sha256'))[:12]}..., now {device_source_sha256()[:12]}...): not quoted")
 
 
 def device_info():
@@ -285,7 +304,10 @@ def main():
     kernel_s = sum(x.seconds_expand for x in results) / len(results)   # N > 1: the slowest rank's (run_sharded takes the max)
     launches = r.expand_launches
     achieved = alg_bytes_per_state * distinct / max(kernel_s, 1e-12)
-    traffic, traffic_source = measured_traffic()
+    if c == headline_config() and not a.symmetry and not a.level_budget and world == 1:
+        traffic, traffic_source = measured_traffic()
+    else:   # the committed counters are the headline's plain single-GPU search: never quoted for anything else
+        traffic, traffic_source = None, "PMC counters are collected for the headline's plain single-GPU search only"
     # Secondary view — the seen-set's probes are uniformly random 8-byte accesses, which this memory system serves
     # at a fraction of its streaming rate.  The ceilings come from tools/membench/randbench (profiles/): loads =
     # mode 1, claims = mode 3 (a load, then a CAS on the slot when it was empty: the claim sequence itself).
@@ -350,6 +372,7 @@ def main():
                      "useful_fraction_ceiling_of_a_probe": 8.0 / 128.0,
                      "traffic_source": traffic_source, "random_access": random_access, "per_rank": per_rank,
                      "device_source_sha256": device_source_sha256()[:16],
+                     "kernel_code_sha256": (headline_kernel_code_sha256() or "")[:16] or None,
                      "note": "achieved = algorithmic bytes (2*S + 8*g + 8 per distinct state) over the summed durations "
                              "of the step's per-level k_expand launches (HIP events on the engine stream).  traffic = DRAM bytes "
                              "per launch from the gfx950 request-size counters: every random 8-B probe fills one 128-B line "

@@ -172,6 +172,9 @@ typedef struct kmc_handle kmc_handle;
 int kmc_open(const kmc_config* cfg, kmc_handle** out);
 /* Compile-and-cache only; needs no GPU (used by the build step).  arch NULL = "gfx950". */
 int kmc_precompile(const kmc_config* cfg, const char* arch);
+/* Path of the cached code object cfg's kernels are loaded from (specialised first if absent; no GPU needed).  A profile
+ * records a hash of its kernels' machine code, so that a number is quoted only for the code it was measured on. */
+int kmc_code_object_path(const kmc_config* cfg, const char* arch, char* out, uint64_t cap);
 /* Whole breadth-first search on the device; cb (may be NULL) is called once per level. */
 int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user);
 int kmc_result_get(kmc_handle* h, kmc_result* out);

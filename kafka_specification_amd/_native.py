@@ -83,6 +83,7 @@ _H = C.c_void_p
 SYMBOLS = [
     ("kmc_open", C.c_int, [C.POINTER(KmcConfig), C.POINTER(_H)]),
     ("kmc_precompile", C.c_int, [C.POINTER(KmcConfig), C.c_char_p]),
+    ("kmc_code_object_path", C.c_int, [C.POINTER(KmcConfig), C.c_char_p, C.c_char_p, C.c_uint64]),
     ("kmc_run", C.c_int, [_H, PROGRESS_CB, C.c_void_p]),
     ("kmc_result_get", C.c_int, [_H, C.POINTER(KmcResult)]),
     ("kmc_checkpoint_save", C.c_int, [_H, C.c_char_p]),

@@ -99,6 +99,46 @@ def precompile(cfg: CheckerConfig, arch: str = "gfx950") -> None:
     nat.check(nat.lib().kmc_precompile(C.byref(c), arch.encode()))
 
 
+def code_object_path(cfg: CheckerConfig, arch: str = "gfx950") -> str:
+    """The cached code object cfg's kernels are loaded from (specialised first if it is not there; no GPU needed)."""
+    c = cfg.to_native()
+    buf = C.create_string_buffer(4096)
+    nat.check(nat.lib().kmc_code_object_path(C.byref(c), arch.encode(), buf, 4096))
+    return buf.value.decode()
+
+
+def elf_sections(blob: bytes) -> dict:
+    """{name: bytes} of the sections of a little-endian ELF64 image that occupy file space (an AMDGPU code object)."""
+    import struct
+    if blob[:6] != b"\x7fELF\x02\x01":
+        raise ValueError("not a little-endian ELF64 image")
+    shoff, = struct.unpack_from("<Q", blob, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", blob, 0x3A)
+    hdrs = [struct.unpack_from("<IIQQQQIIQQ", blob, shoff + i * shentsize) for i in range(shnum)]
+    names = hdrs[shstrndx]
+    strtab = blob[names[4]:names[4] + names[5]]
+    out = {}
+    for name_off, sh_type, _f, _a, off, size, *_ in hdrs:
+        if sh_type in (0, 8):   # SHT_NULL, SHT_NOBITS
+            continue
+        out[strtab[name_off:strtab.index(b"\0", name_off)].decode()] = blob[off:off + size]
+    return out
+
+
+def kernel_code_sha256(cfg: CheckerConfig, arch: str = "gfx950") -> str:
+    """Identity of the MACHINE CODE of cfg's kernels: sha256 over the code object's .text (instructions), .rodata (kernel
+    descriptors: register and LDS budgets) and .note (the AMDGPU metadata: arguments, spills, occupancy inputs).  What is
+    left out is what changes when OTHER builds' lines of the device header change (hiprtc names a `__hip_cuid_<hash of the
+    source text>` symbol in .dynstr / .strtab): profiles stamp their numbers with this, and bench.py quotes them only if
+    the kernels it just ran hash the same."""
+    import hashlib
+    sec = elf_sections(open(code_object_path(cfg, arch), "rb").read())
+    h = hashlib.sha256()
+    for name in (".text", ".rodata", ".note"):
+        h.update(name.encode() + len(sec[name]).to_bytes(8, "little") + sec[name])
+    return h.hexdigest()
+
+
 class ModelChecker:
     def __init__(self, cfg: CheckerConfig):
         self.cfg = cfg

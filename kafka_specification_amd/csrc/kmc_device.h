@@ -2354,10 +2354,18 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             return;
         }
     }
-    // per block: generated[0..15], deadlocks, probed, won, outside, repeats (see the end); KMC_SYMM: [32..47] corr_gen, 48 corr_dead,
-    // 49 corr_repeats, 50 corr_won
+    // per block: generated[0..15], deadlocks, probed, won, outside, repeats (see the end); KMC_SYMM: kmc_corr[0..15] corr_gen,
+    // 16 corr_dead, 17 corr_repeats, 18 corr_won
     __shared__ u32 kmc_tail[64];
     if (threadIdx.x < 64) kmc_tail[threadIdx.x] = 0;
+#if KMC_SYMM
+    // The orbit deficits are 64-bit cells (ds_add_u64): a block's share of a level is millions of successors times up to
+    // N! - 1 = 5,039 each — BASELINE config 5's 17th level (133 M stored states) wrapped 32-bit cells 256 times (round 3:
+    // `generated` 2^40 too large, found by oracle/orbit_oracle.c).  What a LANE or a WAVE sums stays 32-bit (a lane sees
+    // ~300 states of such a level: < 2^26 per lane even with every successor at 5,039).
+    __shared__ u64 kmc_corr[32];
+    if (threadIdx.x < 32) kmc_corr[threadIdx.x] = 0;
+#endif
     __syncthreads();
 #if KMC_SYMM
     // Sparse tiles.  A wave's time here goes into finding the representatives of its tile's successors (hundreds of vector
@@ -2488,7 +2496,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
                     u32 c;
                     if constexpr (sizeof(kb) == 8) c = (u32)__popcll(kb);
                     else c = (u32)__popc(kb);
-                    if (c) atomicAdd(&kmc_tail[32 + M::seg_kind(sg)], defl * c);
+                    if (c) atomicAdd(&kmc_corr[M::seg_kind(sg)], (u64)(defl * c));
                 });
             }
         }
@@ -2527,7 +2535,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
                     if constexpr (sizeof(km) == 8) nsucc += (u32)__popcll(km);
                     else nsucc += (u32)__popc(km);
 #if KMC_SYMM
-                    if (defl && km) atomicAdd(&kmc_tail[32 + M::seg_kind(sg)], defl * (sizeof(km) == 8 ? (u32)__popcll(km) : (u32)__popc((u32)km)));
+                    if (defl && km) atomicAdd(&kmc_corr[M::seg_kind(sg)], (u64)(defl * (sizeof(km) == 8 ? (u32)__popcll(km) : (u32)__popc((u32)km))));
 #endif
                 } else {
                     km = M::template seg_bits<sg>(en32);
@@ -2616,7 +2624,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             gen_lane += (lane == (u32)kind) ? n : 0u;
 #if KMC_SYMM
             if constexpr (M::HAS_EXTRA) extra_corr += e ? extra * defl : 0u;
-            if (e && defl) atomicAdd(&kmc_tail[32 + kind], defl);
+            if (e && defl) atomicAdd(&kmc_corr[kind], (u64)defl);
 #endif
             bool keep = e;
             u64 mk = m;
@@ -2664,7 +2672,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
             // the 80-VGPR budget (107 VGPRs, 4 waves per SIMD) and the headline to 38.8 ms (profiles/r03_tail.txt)
             if (valid && nsucc == 0) atomicMax(&a.ctl->deadlock_fp_inv, ~kmc_fingerprint<W>(s, a.seed));
 #if KMC_SYMM
-            if (valid && nsucc == 0 && defl) atomicAdd(&kmc_tail[48], defl);
+            if (valid && nsucc == 0 && defl) atomicAdd(&kmc_corr[16], (u64)defl);
 #endif
         }
     }
@@ -2711,11 +2719,11 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         }
         out.corr_won = 0;
         if (lane == 0) {
-            if (cw) atomicAdd(&kmc_tail[50], cw);
+            if (cw) atomicAdd(&kmc_corr[18], (u64)cw);
             if constexpr (M::HAS_EXTRA) {
                 if (cx) {
-                    atomicAdd(&kmc_tail[49], cx);
-                    atomicAdd(&kmc_tail[32 + M::EXTRA_KIND], cx);   // the repeats are part of generated[EXTRA_KIND]
+                    atomicAdd(&kmc_corr[17], (u64)cx);
+                    atomicAdd(&kmc_corr[M::EXTRA_KIND], (u64)cx);   // the repeats are part of generated[EXTRA_KIND]
                 }
             }
         }
@@ -2724,10 +2732,10 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     __syncthreads();
 #if KMC_SYMM
     if (wib == 1 && lane < 19) {
-        const u32 v = kmc_tail[32 + lane];
+        const u64 v = kmc_corr[lane];
         u64* dst = lane < 16 ? &a.ctl->corr_gen[lane] : lane == 16 ? &a.ctl->corr_dead : lane == 17 ? &a.ctl->corr_repeats
                  : &a.ctl->corr_won;
-        if (v) atomicAdd(dst, (u64)v);
+        if (v) atomicAdd(dst, v);
     }
 #endif
     if (wib == 0 && lane < 21) {

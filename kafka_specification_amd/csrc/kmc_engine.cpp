@@ -226,7 +226,7 @@ long expand_vgpr_spills(const std::vector<char>& code, const std::string& kernel
 
 // Compile (or fetch from the cache) the code object specialised for cfg.
 int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<char>* code, std::string* kname,
-                    const char* extra_options = nullptr) {
+                    const char* extra_options = nullptr, std::string* path_out = nullptr) {
     KmcLayout lay;
     std::string name, inst;
     if (!validate(cfg, &lay, &name, &inst))
@@ -270,6 +270,7 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
                                        "|" + std::to_string(hip_ver) + "|" + defines_key));
     const std::string dir = cfg.cache_dir ? std::string(cfg.cache_dir) : default_cache_dir();
     const std::string path = dir + "/" + name + "-" + arch + "-" + key + ".hsaco";
+    if (path_out) *path_out = path;
     if (read_file(path, code)) return KMC_OK;
     if (getenv("KMC_VERBOSE"))
         fprintf(stderr, "[kmc] specialising kernels for %s (first use; wide configurations take minutes)\n", name.c_str());
@@ -403,7 +404,6 @@ struct kmc_handle {
     // kmc_config.symmetry: the frontier / table hold one state per orbit; res.distinct and `levels` are the WEIGHTED
     // (= plain-search) numbers, raw_levels the representatives per level; nfact = |Replicas|!
     uint64_t nfact = 1;
-    bool warned_deficit_cells = false;   // book_level: said once that a launch's 32-bit deficit sums may wrap
     int planes = 0;              // words per state in a frontier: W, and under symmetry one more — the order of the state's stabiliser
     double t_start = 0;
     double dry_seconds = 0;
@@ -615,24 +615,11 @@ void book_level(kmc_handle* h, uint64_t produced, const KmcLevelCtl& c) {
     const uint64_t w = weighted(h, produced, c.corr_won);
     h->res.distinct += w;
     h->levels.push_back(w);
-    // KNOWN DEFECT (found by oracle/orbit_oracle.c at 17 levels of BASELINE config 5, round 3): k_expand sums the orbit
-    // deficits of a launch's generated counts per block in 32-bit LDS cells (kmc_device.h, kmc_tail[32 + kind]).  A level
-    // of `produced` stored states is expanded by one launch of at most n_cus x blocks_per_cu blocks; at ~32 counted
-    // successors per state and up to N! - 1 per successor a cell can wrap, and `generated` / `action_generated` then come out
-    // a multiple of 2^32 too large.  `distinct`, the level sizes and the stored states are summed per lane and per wave
-    // first and are not affected.  Until the cells are 64 bits wide (NEXT.md) the run says so, once.
-    if (h->cfg.symmetry && !h->warned_deficit_cells) {
-        const uint64_t blocks = (uint64_t)h->n_cus * (uint64_t)(h->blocks_per_cu > 0 ? h->blocks_per_cu : 1);
-        const uint64_t per_block = produced / (blocks ? blocks : 1) + 64;
-        if (per_block * 32 * (h->nfact - 1) >= (1ull << 32)) {
-            h->warned_deficit_cells = true;
-            fprintf(stderr, "[kmc] orbit counting: the level about to be expanded holds %llu stored states (%llu images per orbit): "
-                            "the 32-bit per-block sums of the orbit deficits may wrap from here on — `generated` and the "
-                            "per-disjunct counts may come out a multiple of 2^32 too large; distinct states, level sizes and "
-                            "verdicts are not affected (DESIGN.md section 10, known defect)\n",
-                    (unsigned long long)produced, (unsigned long long)h->nfact);
-        }
-    }
+    // (Widths.  k_expand sums the orbit deficits of a launch's counts per LANE and per WAVE in 32 bits and per BLOCK in
+    // 64-bit LDS cells (kmc_device.h, kmc_corr).  Round 3 had 32-bit block cells: at 17 levels of BASELINE config 5 — 133 M
+    // stored states in a level, up to 5,039 per successor — they wrapped and `generated` came out 2^40 too large, found by
+    // oracle/orbit_oracle.c.  A lane sees produced / (blocks x 256) states of a level: its sums stay below 2^26 for any level
+    // the frontier can hold.)
 }
 
 int check_conservation(kmc_handle* h, const KmcLevelCtl& c, uint64_t inserted) {
@@ -819,6 +806,19 @@ int kmc_precompile(const kmc_config* cfg, const char* arch) {
         return rc ? rc : get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname, KMC_VERIFY_OPTIONS);
     }
     return get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname);
+}
+
+// Where the code object of cfg's kernels lives in the cache (compiled first if it is not there yet): the identity of the
+// device code a measurement belongs to is the kernels' machine code, not the text of a header that also holds other builds.
+int kmc_code_object_path(const kmc_config* cfg, const char* arch, char* out, uint64_t cap) {
+    if (!cfg || !out || !cap) return fail(KMC_E_ARG, "null config / buffer");
+    std::vector<char> code;
+    std::string kname, path;
+    int rc = get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname, nullptr, &path);
+    if (rc) return rc;
+    if (path.size() + 1 > cap) return fail(KMC_E_ARG, "path of %zu bytes does not fit %llu", path.size(), (unsigned long long)cap);
+    memcpy(out, path.c_str(), path.size() + 1);
+    return KMC_OK;
 }
 
 static void comm_release(kmc_handle* h);

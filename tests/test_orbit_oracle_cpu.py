@@ -59,11 +59,14 @@ def test_config5_fixtures_against_the_plain_oracle_and_against_what_the_gpu_prin
     levels, and carry the numbers the GPU printed for the same level budgets (profiles/r03_config5_orbit_counting.jsonl):
     distinct states at 10, 14 and 17 levels, generated at 10 and 14.
 
-    KNOWN DEFECT, found by this comparison: at 17 levels the GPU's `generated` is 2^40 too large (10,091,562,508,919 against
-    8,992,050,881,143).  k_expand sums the orbit deficits of a launch's generated counts per block in a 32-bit LDS cell
-    (kmc_device.h, kmc_tail[32 + kind]); with 5039 per successor and 133 M stored states in one level, 256 of those cells
-    wrapped.  `distinct`, the level sizes and the stored states are not affected (their deficits are summed per lane and
-    per wave first).  The fix is a device change (64-bit cells) that round 3 had no GPU minutes left to validate: NEXT.md."""
+    Found by this comparison: at 17 levels the GPU's `generated` WAS 2^40 too large (10,091,562,508,919 against
+    8,992,050,881,143) in round 3's measured run.  k_expand summed the orbit deficits of a launch's generated counts per
+    block in 32-bit LDS cells; with 5039 per successor and 133 M stored states in one level, 256 of those cells wrapped.
+    `distinct`, the level sizes and the stored states were not affected (their deficits are summed per lane and per wave
+    first).  The cells are 64 bits wide since (kmc_device.h `kmc_corr`, ds_add_u64: test_symmetry_cpu.py checks the code
+    object's instructions), a change made after the round's GPU minutes were spent: the committed profile below is the
+    measurement BEFORE it and still carries the signature; the GPU test
+    test_baseline_config5_deep_levels_against_the_orbit_counting_oracle[17] is what holds the new cells to this fixture."""
     g10 = json.load(open(os.path.join(GOLDEN, "oracle_kip320_7_8_8_3_levels10.json")))
     fixtures = sorted((json.load(open(os.path.join(GOLDEN, f))) for f in os.listdir(GOLDEN) if f.startswith("orbit_kip320_7_8_8_3_levels")),
                       key=lambda f: f["depth"])
@@ -80,7 +83,7 @@ def test_config5_fixtures_against_the_plain_oracle_and_against_what_the_gpu_prin
         assert gpu[f["depth"]][0] == f["distinct"], f"the GPU's {f['depth']}-level run printed {gpu[f['depth']]}"
     assert gpu[10] == (g10["distinct"], g10["generated"])
     assert gpu[14][1] == fixtures[0]["generated"]
-    assert gpu[17][1] - fixtures[1]["generated"] == 2 ** 40      # the known defect's signature; 0 once re-measured after the fix
+    assert gpu[17][1] - fixtures[1]["generated"] in (0, 2 ** 40)   # 2^40: measured before the 64-bit cells; 0 once re-measured
 
 
 def test_config5_seven_levels_live():

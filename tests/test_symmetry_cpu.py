@@ -251,3 +251,83 @@ def test_orbit_counting_prefix_at_baseline_config5_constants():
             frontier = nxt
     assert levels == want
     assert len(seen) < sum(want) / 300   # 1,271,426 states from a few thousand stored ones
+
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def _expand_disassembly(cfg):
+    """The instructions of kmc_expand_* in the cached gfx950 code object of cfg (specialised here if need be: hiprtc, no GPU)."""
+    import subprocess
+    from kafka_specification_amd import code_object_path
+    text = subprocess.run([OBJDUMP, "-d", code_object_path(cfg)], capture_output=True, text=True, check=True).stdout
+    body, on = [], False
+    for line in text.splitlines():
+        if line.endswith(">:"):
+            on = "<kmc_expand_" in line
+        elif on:
+            body.append(line)
+    assert len(body) > 1000
+    return body
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(OBJDUMP), reason="no llvm-objdump")
+def test_orbit_deficits_leave_the_block_through_64_bit_cells():
+    """Round 3's defect (oracle/orbit_oracle.c found it at 17 levels of BASELINE config 5): k_expand summed the orbit deficits
+    of a launch per block in 32-bit LDS cells, and they wrapped.  No GPU here, so the width is read off the machine code:
+    under orbit counting the LDS adds of kmc_expand are ds_add_u64, except the two of the plain tail (raw generated per kind,
+    deadlocks / probed / won / outside / repeats: counts of a block's own successors, < 2^32 by six orders of magnitude);
+    the plain search's kernel has exactly those two and nothing 64 bits wide."""
+    inv = ("TypeOk", "WeakIsr", "StrongIsr")
+    base = dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=2, invariants=inv)
+    sym = _expand_disassembly(CheckerConfig(**base, symmetry=True))
+    plain = _expand_disassembly(CheckerConfig(**base))
+    count = lambda body, op: sum(1 for l in body if op in l)
+    assert count(plain, "ds_add_u32") == 2 and count(plain, "ds_add_u64") == 0 and count(plain, "ds_add_rtn") == 0
+    assert count(sym, "ds_add_u32") == 2, "a deficit sum goes through a 32-bit LDS cell again"
+    assert count(sym, "ds_add_u64") >= 4   # per-kind deficits (one per segment of the walk), deadlocks, repeats, won
+    # and the block's cells reach the control block as 64-bit global adds (corr_gen / corr_dead / corr_repeats / corr_won)
+    assert count(sym, "global_atomic_add_x2") > count(plain, "global_atomic_add_x2")
+
+
+def test_kernel_code_identity_ignores_the_source_hash_symbol():
+    """kmc.kernel_code_sha256 = sha256 over .text, .rodata (kernel descriptors) and .note (metadata) of a code object: what
+    bench.py compares before quoting a PMC summary measured on an earlier text of kmc_device.h.  On a synthetic ELF64 image:
+    bytes of other sections (hiprtc's `__hip_cuid_<hash of the source>` lives in .dynstr / .strtab) do not move it, one
+    byte of .text does."""
+    import hashlib
+    import struct
+    from kafka_specification_amd.checker import elf_sections
+
+    def image(text, dynstr):
+        names = b"\0.text\0.rodata\0.note\0.dynstr\0.shstrtab\0.bss\0"
+        secs = [(b".text", 1, text), (b".rodata", 1, b"R" * 64), (b".note", 7, b"N" * 40), (b".dynstr", 3, dynstr),
+                (b".shstrtab", 3, names), (b".bss", 8, b"")]
+        blob = bytearray(64)
+        hdrs = [struct.pack("<IIQQQQIIQQ", 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)]
+        for nm, typ, data in secs:
+            off = len(blob)
+            blob += data
+            hdrs.append(struct.pack("<IIQQQQIIQQ", names.index(nm), typ, 0, 0, off, len(data) if typ != 8 else 4096, 0, 0, 1, 0))
+        shoff = len(blob)
+        for h in hdrs:
+            blob += h
+        blob[:6] = b"\x7fELF\x02\x01"
+        struct.pack_into("<Q", blob, 0x28, shoff)
+        struct.pack_into("<HHH", blob, 0x3A, 64, len(hdrs), 5)
+        return bytes(blob)
+
+    def ident(blob):
+        sec = elf_sections(blob)
+        h = hashlib.sha256()
+        for n in (".text", ".rodata", ".note"):
+            h.update(n.encode() + len(sec[n]).to_bytes(8, "little") + sec[n])
+        return h.hexdigest()
+
+    a = image(b"\x01\x02\x03\x04" * 16, b"\0__hip_cuid_2a988ab646cf56b6\0")
+    b = image(b"\x01\x02\x03\x04" * 16, b"\0__hip_cuid_416cadc9b025235a\0")
+    c = image(b"\x01\x02\x03\x05" + b"\x01\x02\x03\x04" * 15, b"\0__hip_cuid_2a988ab646cf56b6\0")
+    assert a != b and ident(a) == ident(b) != ident(c)
+    assert set(elf_sections(a)) == {".text", ".rodata", ".note", ".dynstr", ".shstrtab"}   # .bss holds no bytes of the file
+    with pytest.raises(ValueError):
+        elf_sections(b"\x7fELF\x01\x01" + bytes(64))

@@ -14,6 +14,14 @@ _h = hashlib.sha256()
 for _f in ("kmc_layout.h", "kmc_device.h"):
     _h.update(open(os.path.join(_root, "kafka_specification_amd", "csrc", _f), "rb").read())
 out["device_source_sha256"] = _h.hexdigest()
+# ... and the identity of the machine code of the headline's kernels (.text + descriptors + metadata of the code object):
+# what bench.py compares when the header's text has moved on in a build the headline does not compile
+try:
+    sys.path.insert(0, _root)
+    import bench as _bench
+    out["kernel_code_sha256"] = _bench.headline_kernel_code_sha256()
+except Exception as _e:
+    out["kernel_code_sha256"] = None
 # kernel trace
 _tr = glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True)
 rows = list(csv.DictReader(open(_tr[0])))
@@ -105,5 +113,7 @@ if len(sys.argv) > 3 and ("dram_bytes" in der or "hbm_bytes_raw" in der):
     if "write_bytes_raw" in der:
         pm["WRITE_SIZE_bytes_as_reported"] = der["write_bytes_raw"]
     pm["device_source_sha256"] = out["device_source_sha256"]
+    if out.get("kernel_code_sha256"):
+        pm["kernel_code_sha256"] = out["kernel_code_sha256"]
     pm["launches"] = n
     open(sys.argv[3], "w").write(json.dumps(pm, indent=1) + "\n")
