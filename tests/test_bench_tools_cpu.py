@@ -37,9 +37,32 @@ def test_traffic_is_quoted_only_for_the_device_code_it_was_measured_on(bench, mo
         # the DRAM-unit counters, not FETCH_SIZE: reads are twice what FETCH_SIZE reports on gfx950
         assert abs(pm["read_bytes"] / pm["FETCH_SIZE_bytes_as_reported"] - 2.0) < 0.01
         assert abs(pm["hbm_bytes"] - (pm["read_bytes"] + pm["write_bytes"] + pm["atomic_bytes"])) < 1.0
+    # the header's text has moved on: quoted only if the headline's kernels are, instruction for instruction, the measured ones
     monkeypatch.setattr(bench, "device_source_sha256", lambda: "0" * 64)
+    monkeypatch.setattr(bench, "headline_kernel_code_sha256", lambda: "1" * 64)
     t2, why = bench.measured_traffic()
     assert t2 is None and "other device code" in why
+    monkeypatch.setattr(bench, "headline_kernel_code_sha256", lambda: None)      # no compiler to ask: not quoted either
+    assert bench.measured_traffic()[0] is None
+    if pm.get("kernel_code_sha256"):
+        monkeypatch.setattr(bench, "headline_kernel_code_sha256", lambda: pm["kernel_code_sha256"])
+        t3, src3 = bench.measured_traffic()
+        assert t3 == pm["hbm_bytes_per_launch"] and "kernel_code_sha256" in src3 and os.path.relpath(newest, ROOT) in src3
+
+
+def test_the_newest_pmc_summary_belongs_to_the_kernels_this_tree_builds(bench):
+    """profiles/r03_pmc_summary.json was measured before the orbit-deficit cells became 64-bit (an edit inside #if KMC_SYMM of
+    kmc_device.h): the PLAIN headline's kernels hiprtc builds from this tree (gfx950, no GPU needed) hash to what the summary
+    records, so bench.py quotes its traffic."""
+    pm = json.load(open(bench.newest_profile("pmc_summary.json")))
+    if "kernel_code_sha256" not in pm:
+        pytest.skip("the newest summary predates kernel_code_sha256")
+    code = bench.headline_kernel_code_sha256()
+    assert code is not None and len(code) == 64
+    if pm["device_source_sha256"] != bench.device_source_sha256():
+        assert code == pm["kernel_code_sha256"], "the headline's kernels changed since the counters were collected: re-measure"
+    t, src = bench.measured_traffic()
+    assert t == pm["hbm_bytes_per_launch"]
 
 
 NEWEST_ROUND = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench.json"))[-1][:3]
