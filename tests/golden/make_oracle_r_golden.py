@@ -50,6 +50,28 @@ def ladder(only=None):
     return out
 
 
+def wide_ladder():
+    """Four to seven replicas (tests/golden/oracle_r_wide.json): where the device's pass 1 is a straight-line block of hundreds of
+    guards, states take several words and orbit counting sorts replica keys — and where BASELINE configs 4 (Kip279, 5 brokers)
+    and 5 (7 brokers, LogSize 8) live.  Exhaustible bindings are run out; the two BASELINE bindings themselves, which Oracle-R
+    cannot exhaust (112 M states / unbounded for practical purposes), are run over a LEVEL BUDGET (`max_levels`: exact level
+    sets of the first levels only; `generated` then counts what the expanded levels produced)."""
+    out = []
+    for m in KAFKA:
+        out.append(dict(module=m, N=4, L=1, R=1, E=0, invariants=KAFKA_INV, size="small"))
+        out.append(dict(module=m, N=5, L=1, R=1, E=0, invariants=KAFKA_INV, size="medium"))
+    out.append(dict(module="Kip320", N=4, L=2, R=1, E=1, invariants=KAFKA_INV, size="large"))     # 155,041 states
+    out.append(dict(module="Kip320", N=6, L=1, R=1, E=0, invariants=KAFKA_INV, size="large"))     # 99,469 states
+    out.append(dict(module="Kip279", N=5, L=2, R=2, E=1, invariants=KAFKA_INV, max_levels=10, size="large"))   # BASELINE config 4
+    out.append(dict(module="Kip320", N=7, L=8, R=8, E=3, invariants=KAFKA_INV, max_levels=6, size="large"))    # BASELINE config 5
+    out.append(dict(module="Kip320", N=7, L=1, R=1, E=0, invariants=KAFKA_INV, max_levels=11, size="large"))
+    out.append(dict(module="Kip279", N=7, L=1, R=1, E=0, invariants=KAFKA_INV, max_levels=10, size="large"))
+    out.append(dict(module="Kip320FirstTry", N=8, L=1, R=1, E=0, invariants=KAFKA_INV, max_levels=8, size="large"))   # the engine's widest
+    if os.environ.get("ORACLE_R_WIDE_EXHAUST_7"):   # an hour on one core: the whole of Kip320 at seven replicas (681,871 states)
+        out.append(dict(module="Kip320", N=7, L=1, R=1, E=0, invariants=KAFKA_INV, size="large"))
+    return out
+
+
 def constants_of(c):
     from oracle.tlar import ModelValue
     m = c["module"]
@@ -72,7 +94,7 @@ def run_one(c):
     ck = Checker(c["module"], consts, [os.path.join(ROOT, "models"), REFERENCE])
     t0 = time.time()
     r = ck.run(invariants=tuple(c["invariants"]), constraint=c.get("constraint"), stop_on_violation=bool(c.get("stop")),
-               keep_states=True)
+               keep_states=True, max_levels=c.get("max_levels"))
     enc = oc.encoder_for(c["module"])
     digests = [oc.level_digest(enc(s, consts) for s in lv) for lv in r["level_states"]]
     v = r["violation"]
@@ -93,11 +115,25 @@ def main():
     ap.add_argument("--jobs", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--only", default=None, help="comma-separated sizes: small,medium,large")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "oracle_r_ladder.json"))
+    ap.add_argument("--wide", action="store_true", help="the 4-7 replica ladder -> tests/golden/oracle_r_wide.json")
     a = ap.parse_args()
-    cfgs = ladder(a.only.split(",") if a.only else None)
+    if a.wide:
+        cfgs = wide_ladder()
+        if a.out.endswith("oracle_r_ladder.json"):
+            a.out = a.out.replace("oracle_r_ladder.json", "oracle_r_wide.json")
+    else:
+        cfgs = ladder(a.only.split(",") if a.only else None)
     cfgs.sort(key=lambda c: {"large": 0, "medium": 1, "small": 2}[c["size"]])
+    kept = []
+    if a.wide and os.path.exists(a.out):   # incremental: entries of the file that the ladder still asks for are kept as they are
+        ident = lambda c: (c["module"], c["N"], c["L"], c["R"], c["E"], c.get("max_levels"), tuple(c["invariants"]))
+        want = {ident(c) for c in cfgs}
+        kept = [e for e in json.load(open(a.out))["entries"] if ident(e) in want]
+        have = {ident(e) for e in kept}
+        cfgs = [c for c in cfgs if ident(c) not in have]
+        print(f"{len(kept)} entries kept, {len(cfgs)} to run", flush=True)
     with ProcessPoolExecutor(max_workers=a.jobs) as ex:
-        entries = list(ex.map(run_one, cfgs))
+        entries = kept + list(ex.map(run_one, cfgs))
     entries.sort(key=lambda e: (e["module"], e.get("N", 0), e.get("L", 0), e.get("R", 0), e.get("E", 0), e.get("K", 0),
                                 e.get("MaxId", 0), e["invariants"]))
     sha = {}

@@ -1,0 +1,59 @@
+"""Oracle-R at four to seven replicas: tests/golden/oracle_r_wide.json (tests/golden/make_oracle_r_golden.py --wide — the
+reference's .tla text executed by oracle/tlar) against the C oracle, on exact per-level state SETS.
+
+The three-replica ladder (test_oracle_r_cpu.py) pins the hand oracles where the headline lives; this one pins them where
+BASELINE configs 4 and 5 live — 5 and 7 brokers — and at 4 and 6: every Kafka module run out at 4/1/1/0 and 5/1/1/0, Kip320 at
+4/2/1/1 (155,041 states) and 6/1/1/0 (99,469), and the BASELINE bindings themselves (Kip279 5/2/2/1, Kip320 7/8/8/3) over the
+level budget Oracle-R can afford.  tests/test_gpu_zzz_oracle_r_wide.py holds the HIP engine to the same file."""
+import json
+import os
+
+import pytest
+
+import kmo
+import oracle_r_canon as oc
+from test_oracle_r_cpu import KAFKA, assert_same_as_oracle_b
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WIDE = os.path.join(ROOT, "tests", "golden", "oracle_r_wide.json")
+ENTRIES = json.load(open(WIDE))["entries"] if os.path.exists(WIDE) else []
+
+
+def _eid(e):
+    return f"{e['module']}-{e['N']}/{e['L']}/{e['R']}/{e['E']}" + (f"-levels{e['max_levels']}" if e.get("max_levels") else "")
+
+
+@pytest.mark.parametrize("entry", [e for e in ENTRIES if not e.get("max_levels")], ids=_eid)
+def test_c_oracle_reproduces_the_executed_reference_at_four_to_six_replicas(entry):
+    assert_same_as_oracle_b(entry, entry, digests=entry["level_digests"])
+
+
+@pytest.mark.parametrize("entry", [e for e in ENTRIES if e.get("max_levels")], ids=_eid)
+def test_c_oracle_reproduces_the_first_levels_of_the_baseline_bindings(entry):
+    """A level budget: Oracle-R stopped after `max_levels` levels (the last one found, not expanded).  The C oracle stops after
+    the level that crosses `max_states`: one state short of the fixture's total makes that the same level."""
+    k = entry["max_levels"]
+    assert entry["verdict"] == "limit" and len(entry["levels"]) == k == len(entry["level_digests"]) and entry["violation"] is None
+    o = kmo.Run(kmo.make_config(entry["module"], N=entry["N"], L=entry["L"], R=entry["R"], E=entry["E"],
+                                invariants=tuple(entry["invariants"]), stop_on_violation=False, threads=4,
+                                max_states=entry["distinct"] - 1))
+    assert o.levels[:k] == entry["levels"] and o.viol_inv is None
+    for lv in range(k):
+        assert oc.level_digest(o.level_states(lv)) == entry["level_digests"][lv], f"level {lv}: state sets differ"
+    if len(o.levels) == k:   # stopped where Oracle-R stopped: the successors of the first k - 1 levels, counted per disjunct
+        assert (o.distinct, o.generated) == (entry["distinct"], entry["generated"])
+        for i, lab in enumerate(entry["actions"]):
+            assert o.action_generated[i] == entry["action_generated"].get(str(lab), 0), f"disjunct {i} ({lab})"
+
+
+def test_wide_fixture_covers_the_baseline_replica_counts():
+    assert ENTRIES, "tests/golden/oracle_r_wide.json is missing: python tests/golden/make_oracle_r_golden.py --wide"
+    by_n = {}
+    for e in ENTRIES:
+        by_n.setdefault(e["N"], set()).add(e["module"])
+    assert set(by_n) == {4, 5, 6, 7}
+    assert by_n[4] == set(KAFKA) == by_n[5]                      # every Kafka root module at four and five replicas
+    assert any(e["module"] == "Kip279" and (e["N"], e["L"], e["R"], e["E"]) == (5, 2, 2, 1) for e in ENTRIES)   # BASELINE config 4
+    assert any(e["module"] == "Kip320" and (e["N"], e["L"], e["R"], e["E"]) == (7, 8, 8, 3) for e in ENTRIES)   # BASELINE config 5
+    ladder = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_r_ladder.json")))
+    assert json.load(open(WIDE))["spec_sha256"] == ladder["spec_sha256"]   # the same revision of the reference's text
