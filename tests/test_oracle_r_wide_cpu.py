@@ -51,9 +51,66 @@ def test_wide_fixture_covers_the_baseline_replica_counts():
     by_n = {}
     for e in ENTRIES:
         by_n.setdefault(e["N"], set()).add(e["module"])
-    assert set(by_n) == {4, 5, 6, 7}
+    assert set(by_n) == {4, 5, 6, 7, 8}                        # 8 = the widest replica set the engine takes
     assert by_n[4] == set(KAFKA) == by_n[5]                      # every Kafka root module at four and five replicas
     assert any(e["module"] == "Kip279" and (e["N"], e["L"], e["R"], e["E"]) == (5, 2, 2, 1) for e in ENTRIES)   # BASELINE config 4
     assert any(e["module"] == "Kip320" and (e["N"], e["L"], e["R"], e["E"]) == (7, 8, 8, 3) for e in ENTRIES)   # BASELINE config 5
     ladder = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_r_ladder.json")))
     assert json.load(open(WIDE))["spec_sha256"] == ladder["spec_sha256"]   # the same revision of the reference's text
+
+
+# ------------------------------------------------------------------------------------------------
+# The DEVICE lowering itself (kmc_device.h's model templates, compiled for the host: tests/host_emu.cpp) against the
+# executed reference — no hand oracle in between — at the bindings BASELINE names for 4 and 8 GPUs.
+# ------------------------------------------------------------------------------------------------
+def _device_entries():
+    import host_emu
+    have = {c[:6] for c in host_emu.configs() if c[6] == 0}
+    out = []
+    for e in ENTRIES:
+        if e["module"] in kmo.MODELS and (kmo.MODELS[e["module"]], e["N"], e["L"], e["R"], e["E"], 0) in have:
+            out.append(e)
+    return out
+
+
+@pytest.mark.parametrize("entry", _device_entries() if ENTRIES else [], ids=_eid)
+def test_device_model_templates_reproduce_the_executed_reference_level_by_level(entry):
+    """A breadth-first search on the CPU whose Init and successor function are the device's own templates (the instantiation
+    the GPU runs at these constants, the automatic layout): every level's state SET (sha256 over the sorted canonical
+    encodings, as Oracle-R wrote it), level sizes, and — where the whole budget is walked — `generated` and its per-disjunct
+    split, against the reference's text as oracle/tlar executed it.  Walks as many levels as hold 40,000 states."""
+    import host_emu
+    from kafka_specification_amd import CheckerConfig, ModelChecker
+    cfg6 = (kmo.MODELS[entry["module"]], entry["N"], entry["L"], entry["R"], entry["E"], 0, 0)
+    budget, total = len(entry["levels"]), 0
+    for k, n in enumerate(entry["levels"]):
+        total += n
+        if total > 40000:
+            budget = max(k, 3)
+            break
+    with host_emu.layout(cfg6), ModelChecker(CheckerConfig(model=entry["module"], device=-1, n_replicas=entry["N"],
+                                                           log_size=entry["L"], max_records=entry["R"],
+                                                           max_leader_epoch=entry["E"])) as mc:
+        init = tuple(host_emu.init(cfg6))
+        seen, frontier = {init}, [init]
+        generated, per_kind = 1, {}
+        for depth in range(budget):
+            assert len(frontier) == entry["levels"][depth], f"level {depth}"
+            assert oc.level_digest(mc.unpack(list(w)) for w in frontier) == entry["level_digests"][depth], \
+                f"level {depth}: the device model's state set differs from the executed reference's"
+            if depth + 1 == budget:
+                break
+            nxt = []
+            for s in frontier:
+                for kind, t in host_emu.successors(cfg6, s):
+                    generated += 1
+                    per_kind[kind] = per_kind.get(kind, 0) + 1
+                    assert not host_emu.violated(cfg6, t, 0b0111)     # TypeOk, WeakIsr, StrongIsr hold (Oracle-R: no violation)
+                    if t not in seen:
+                        seen.add(t)
+                        nxt.append(t)
+            frontier = nxt
+    if budget == len(entry["levels"]) and entry.get("max_levels"):   # the whole level budget: the successors of all but the last level
+        assert generated == entry["generated"]
+        for i, lab in enumerate(entry["actions"]):   # the device numbers the disjuncts of Next in source order
+            assert per_kind.get(i, 0) == entry["action_generated"].get(str(lab), 0), f"disjunct {i} ({lab})"
