@@ -48,14 +48,14 @@ def device_source_sha256():
     return h.hexdigest()
 
 
-def headline_kernel_code_sha256():
+def headline_kernel_code_sha256(symmetry=False):
     """Identity of the MACHINE CODE of the headline's kernels (kmc.kernel_code_sha256: .text + kernel descriptors + metadata
     of the cached code object this very run loads).  kmc_device.h also holds the orbit-counting, verify and profiling
     builds behind #if: an edit there changes the source hash and leaves the headline's instructions as they were."""
     try:
         import kafka_specification_amd as kmc
         c = headline_config()
-        return kmc.kernel_code_sha256(kmc.CheckerConfig(**c))
+        return kmc.kernel_code_sha256(kmc.CheckerConfig(**c, symmetry=symmetry))
     except Exception as e:   # no hiprtc, no library: the source hash alone decides
         sys.stderr.write(f"bench.py: kernel_code_sha256 unavailable ({str(e)[:120]})\n")
         return None
@@ -372,7 +372,7 @@ def main():
                      "useful_fraction_ceiling_of_a_probe": 8.0 / 128.0,
                      "traffic_source": traffic_source, "random_access": random_access, "per_rank": per_rank,
                      "device_source_sha256": device_source_sha256()[:16],
-                     "kernel_code_sha256": (headline_kernel_code_sha256() or "")[:16] or None,
+                     "kernel_code_sha256": ((headline_kernel_code_sha256(symmetry=a.symmetry) or "")[:16] or None) if c == headline_config() else None,
                      "note": "achieved = algorithmic bytes (2*S + 8*g + 8 per distinct state) over the summed durations "
                              "of the step's per-level k_expand launches (HIP events on the engine stream).  traffic = DRAM bytes "
                              "per launch from the gfx950 request-size counters: every random 8-B probe fills one 128-B line "
