@@ -34,6 +34,6 @@ done
 ./oracle/orbit_oracle --model Kip320 --N 7 --L 8 --R 8 --E 3 --levels 17 --last-level-fp --threads 8 --table-log2 29 --max-stored 230000000 --fp-table-log2 30 > tests/golden/orbit_kip320_7_8_8_3_levels17.json
 # The reference's own text, executed (Oracle-R, oracle/tlar; needs /root/reference): two and three replicas (25 CPU-minutes) ...
 # python tests/golden/make_oracle_r_golden.py            # -> tests/golden/oracle_r_ladder.json
-# ... and four to eight (one CPU-hour; incremental: entries already in the file are kept; ORACLE_R_WIDE_EXHAUST_7=1 adds the whole
-# of Kip320 at seven replicas, another hour on one core)
+# ... and four to eight (two CPU-hours, one of them the whole of Kip320 at seven replicas on one core; incremental: entries already
+# in the file are kept)
 # python tests/golden/make_oracle_r_golden.py --wide     # -> tests/golden/oracle_r_wide.json

@@ -27,7 +27,7 @@ def _eid(e):
 
 
 @pytest.mark.parametrize("e", [e for e in ENTRIES if not e.get("max_levels")], ids=_eid)
-def test_gpu_reproduces_the_executed_reference_at_four_to_six_replicas(e):
+def test_gpu_reproduces_the_executed_reference_at_four_to_seven_replicas(e):
     _exhaustive(e)
 
 

@@ -24,7 +24,7 @@ def _eid(e):
 
 
 @pytest.mark.parametrize("entry", [e for e in ENTRIES if not e.get("max_levels")], ids=_eid)
-def test_c_oracle_reproduces_the_executed_reference_at_four_to_six_replicas(entry):
+def test_c_oracle_reproduces_the_executed_reference_at_four_to_seven_replicas(entry):
     assert_same_as_oracle_b(entry, entry, digests=entry["level_digests"])
 
 
