@@ -48,17 +48,20 @@ def device_source_sha256():
     return h.hexdigest()
 
 
-def headline_kernel_code_sha256(symmetry=False):
-    """Identity of the MACHINE CODE of the headline's kernels (kmc.kernel_code_sha256: .text + kernel descriptors + metadata
-    of the cached code object this very run loads).  kmc_device.h also holds the orbit-counting, verify and profiling
-    builds behind #if: an edit there changes the source hash and leaves the headline's instructions as they were."""
+def kernel_code_sha256_of(c, symmetry=False):
+    """Identity of the MACHINE CODE of the kernels configuration c runs (kmc.kernel_code_sha256: .text + kernel descriptors +
+    metadata of the cached code object this very run loads).  kmc_device.h also holds the orbit-counting, verify and
+    profiling builds behind #if: an edit there changes the source hash and leaves a workload's instructions as they were."""
     try:
         import kafka_specification_amd as kmc
-        c = headline_config()
         return kmc.kernel_code_sha256(kmc.CheckerConfig(**c, symmetry=symmetry))
     except Exception as e:   # no hiprtc, no library: the source hash alone decides
         sys.stderr.write(f"bench.py: kernel_code_sha256 unavailable ({str(e)[:120]})\n")
         return None
+
+
+def headline_kernel_code_sha256(symmetry=False):
+    return kernel_code_sha256_of(headline_config(), symmetry)
 
 
 def newest_profile(suffix):
@@ -114,26 +117,28 @@ def claims_per_distinct_state():
     return (float(v), os.path.relpath(path, ROOT)) if v else (None, None)
 
 
-def measured_traffic():
-    """HBM bytes per k_expand launch from the newest committed PMC summary — only when it was measured on THIS
-    device code (the summary carries the sha256 of the device sources); otherwise null, with the reason."""
-    path = newest_profile("pmc_summary.json")
-    if not path:
+def measured_traffic(code=None):
+    """HBM bytes per k_expand launch from a committed PMC summary (profiles/rNN_*pmc_summary.json, newest round first) — only
+    from one that was measured on the MACHINE CODE this run executes (`code` = kernel_code_sha256 of the running workload's
+    kernels; the summaries carry the hash of the kernels they profiled); otherwise null, with the reason."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*pmc_summary.json")), reverse=True)
+    if not files:
         return None, "no PMC summary under profiles/"
-    try:
-        j = json.load(open(path))
-    except Exception as e:
-        return None, f"{os.path.relpath(path, ROOT)}: {e}"
-    if j.get("device_source_sha256") == device_source_sha256():
-        return j.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
-    # other source text: quoted only if the kernels' machine code is what the summary was measured on
-    code = headline_kernel_code_sha256() if j.get("kernel_code_sha256") else None
-    if code and j["kernel_code_sha256"] == code:
-        return j.get("hbm_bytes_per_launch"), (f"{os.path.relpath(path, ROOT)} (device sources edited since, the headline's "
-                                               f"code object is instruction for instruction the measured one: "
+    if not code:
+        return None, "kernel_code_sha256 of the running kernels unavailable: no PMC summary can be matched"
+    seen = []
+    for path in files:
+        try:
+            j = json.load(open(path))
+        except Exception as e:
+            seen.append(f"{os.path.basename(path)}: {str(e)[:40]}")
+            continue
+        if j.get("kernel_code_sha256") == code and j.get("hbm_bytes_per_launch"):
+            return j["hbm_bytes_per_launch"], (f"{os.path.relpath(path, ROOT)} (measured on this machine code: "
                                                f"kernel_code_sha256 {code[:16]})")
-    return None, (f"{os.path.relpath(path, ROOT)} was measured on other device code "
-                  f"({str(j.get('device_source_sha256'))[:12]}..., now {device_source_sha256()[:12]}...): not quoted")
+        seen.append(f"{os.path.basename(path)} {str(j.get('kernel_code_sha256'))[:12]}")
+    return None, f"no PMC summary was measured on this code ({code[:12]}...): " + ", ".join(seen[:6])
 
 
 def device_info():
@@ -304,10 +309,14 @@ def main():
     kernel_s = sum(x.seconds_expand for x in results) / len(results)   # N > 1: the slowest rank's (run_sharded takes the max)
     launches = r.expand_launches
     achieved = alg_bytes_per_state * distinct / max(kernel_s, 1e-12)
-    if c == headline_config() and not a.symmetry and not a.level_budget and world == 1:
-        traffic, traffic_source = measured_traffic()
-    else:   # the committed counters are the headline's plain single-GPU search: never quoted for anything else
-        traffic, traffic_source = None, "PMC counters are collected for the headline's plain single-GPU search only"
+    code_sha = kernel_code_sha256_of(c, symmetry=a.symmetry)
+    if world == 1:   # (a level budget runs the same kernels over fewer launches; the summary's per-launch figure is then of
+        #               the profiled run's own budget — the summaries name theirs in "run")
+        traffic, traffic_source = measured_traffic(code_sha)
+        if traffic and a.level_budget:
+            traffic_source += f"; per-launch average of the profiled run, this run's level budget is {a.level_budget}"
+    else:
+        traffic, traffic_source = None, "PMC counters are collected for single-GPU searches only"
     # Secondary view — the seen-set's probes are uniformly random 8-byte accesses, which this memory system serves
     # at a fraction of its streaming rate.  The ceilings come from tools/membench/randbench (profiles/): loads =
     # mode 1, claims = mode 3 (a load, then a CAS on the slot when it was empty: the claim sequence itself).
@@ -372,7 +381,7 @@ def main():
                      "useful_fraction_ceiling_of_a_probe": 8.0 / 128.0,
                      "traffic_source": traffic_source, "random_access": random_access, "per_rank": per_rank,
                      "device_source_sha256": device_source_sha256()[:16],
-                     "kernel_code_sha256": ((headline_kernel_code_sha256(symmetry=a.symmetry) or "")[:16] or None) if c == headline_config() else None,
+                     "kernel_code_sha256": code_sha,
                      "note": "achieved = algorithmic bytes (2*S + 8*g + 8 per distinct state) over the summed durations "
                              "of the step's per-level k_expand launches (HIP events on the engine stream).  traffic = DRAM bytes "
                              "per launch from the gfx950 request-size counters: every random 8-B probe fills one 128-B line "
@@ -397,6 +406,8 @@ def main():
                 (r.verdict, r.distinct, r.generated, r.depth, r.levels, r.action_generated, r.deadlock_states,
                  r.generated_repeats))
         s_alg = alg_bytes_per_state * sr.orbit_representatives
+        s_code = kernel_code_sha256_of(c, symmetry=True)
+        s_traffic, s_traffic_source = measured_traffic(s_code)
         out["orbit_counting"] = {
             "value": sum(x.distinct for x in sres) / sdt, "unit": "distinct states/s", "ms_per_step": 1e3 * sdt / a.steps,
             "time_to_exhaustive_s": sdt / a.steps, "speedup_over_plain": (dt / a.steps) / (sdt / a.steps),
@@ -407,6 +418,7 @@ def main():
             "kernel_seconds_per_step": sk, "launches_per_step": sr.expand_launches,
             "roofline": {"bound": "hbm", "achieved": s_alg / max(sk, 1e-12) / 1e9, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
                          "frac": s_alg / max(sk, 1e-12) / HBM_PEAK_BPS,
+                         "traffic": s_traffic, "traffic_source": s_traffic_source, "kernel_code_sha256": s_code,
                          "note": "algorithmic bytes of the STORED states (the same per-state figure) over this search's "
                                  "k_expand time; the kernel is instruction-bound here (the representative of every successor "
                                  "is the smallest of its images under the permutations: profiles/r03_symmetry.txt)"}}

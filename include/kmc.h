@@ -221,6 +221,11 @@ int kmc_frontier_states(kmc_handle* h, uint64_t* words, uint64_t cap_states, uin
 /* All successors of one packed state, straight from the device kernels: writes up to cap
  * records of (state_words + 2) uint64: state, fingerprint, action kind. */
 int kmc_successors(kmc_handle* h, const uint64_t* words, uint64_t* out, uint64_t cap, uint64_t* n_out);
+/* The invariants (KMC_INV_* bits of `mask`, whatever cfg->invariant_mask says) each of n packed states violates, from
+ * the device's own predicate — the one k_expand applies to the states it expands (TypeOk / WeakIsr / StrongIsr /
+ * LeaderInIsr: KafkaReplication.tla:101,320,334,345).  With kmc_successors this is the per-state differential surface:
+ * Next and the invariants on any state, reachable or not. */
+int kmc_check_states(kmc_handle* h, const uint64_t* words, uint64_t n, uint32_t mask, uint32_t* violated);
 /* Counterexample of the last run (needs keep_trace): canonical-byte states from the initial
  * state to the witness, with the action kind that produced each (-1 for the initial state). */
 int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap, uint64_t* n_out);

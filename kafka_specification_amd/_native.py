@@ -100,6 +100,7 @@ SYMBOLS = [
     ("kmc_canonical_state", C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     ("kmc_frontier_states", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]),
     ("kmc_successors", C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("kmc_check_states", C.c_int, [_H, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("kmc_trace", C.c_int, [_H, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_uint64, C.POINTER(C.c_uint64)]),
     ("kmc_contains", C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     ("kmc_witness", C.c_int, [_H, C.POINTER(C.c_uint64)]),

@@ -176,6 +176,8 @@ typedef unsigned int u32;
 #define KMC_FLAG_DRY_RAND 256u  // tuning: DRY mode does one load from an uncorrelated random table slot
 #define KMC_FLAG_ENUM_MATCH 512u  // ENUM lists only the successors whose fingerprint is KmcArgs::match_fp, with their parent's fp
 #define KMC_FLAG_META 2u  // the ring carries a meta plane (predecessor fp for traces / kind for ENUM)
+#define KMC_FLAG_INV_ONLY 2048u  // the invariant pass over a frontier that is not expanded (the last level under max_levels,
+                                 // kmc_check_states): a tile ends after the invariants of its states — no guard, no effect
 #define KMC_FLAG_FP128 1024u  // the seen-set's slots are 16 bytes: the fingerprint and a second, independent 64-bit hash of the
                               // state (kmc_config.wide_fingerprint): a 64-bit collision is then recognised, not lost
 
@@ -2462,6 +2464,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
                 if (bad) KmcSink<M>::report_violation(a, bad, kmc_fingerprint<W>(s, a.seed), defl);
             }
         }
+        if (a.flags & KMC_FLAG_INV_ONLY) continue;   // (wave-uniform: a kernel argument)
 
         KMC_T(tp1);
         KMC_TADD(0, tp0, tp1);

@@ -1212,6 +1212,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             KmcArgs d = base_args(h, 2);
             d.fin = h->frontier[h->cur];
             d.mode = KMC_MODE_DRY;
+            d.flags |= KMC_FLAG_INV_ONLY;   // (a full dry expansion of BASELINE config 5's tenth level took 64 ms: twice the search)
             if ((rc = launch(h, h->f_expand, d, expand_grid(h, h->n_cur)))) return rc;
             if ((rc = read_ctl(h, 2))) return rc;
             KmcLevelCtl c = *h->ctl_host;
@@ -1529,6 +1530,39 @@ int kmc_successors(kmc_handle* h, const uint64_t* words, uint64_t* out, uint64_t
     *n_out = n;
     const uint64_t ncopy = n < cap ? n : cap;
     if (ncopy && out) HIP_TRY(hipMemcpy(out, h->enum_out, ncopy * (h->W + 2) * 8, hipMemcpyDeviceToHost));
+    return KMC_OK;
+}
+
+// The invariants of `mask` each of n packed states violates, from the device's own predicate (M::violated_pre, the one
+// k_expand applies to every state it expands): one single-state pass of k_expand per state in its dry mode (successors are
+// generated and dropped, no table or frontier is touched), the per-invariant violation counters of the control block
+// read back.  A differential-testing entry point (states as data), not a search.
+int kmc_check_states(kmc_handle* h, const uint64_t* words, uint64_t n, uint32_t mask, uint32_t* violated) {
+    if (!h || !words || !violated) return fail(KMC_E_ARG, "null argument");
+    if (!h->table) return fail(KMC_E_STATE, "host-only handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    for (uint64_t i = 0; i < n; ++i) {
+        HIP_TRY(hipMemcpyAsync(h->scratch, words + i * h->W, h->W * 8, hipMemcpyHostToDevice, h->stream));
+        if (h->cfg.symmetry) {
+            static const uint64_t one = 1;
+            HIP_TRY(hipMemcpyAsync(h->scratch + h->W, &one, 8, hipMemcpyHostToDevice, h->stream));
+        }
+        int rc = zero_ctl(h, 2);
+        if (rc) return rc;
+        KmcArgs a = base_args(h, 2);
+        a.fin = h->scratch;
+        a.fin_stride = 1;
+        for (int sg = 0; sg < KMC_SEGS; ++sg) a.seg_count[sg] = sg == 0 ? 1 : 0;
+        a.mode = KMC_MODE_DRY;
+        a.flags |= KMC_FLAG_INV_ONLY;
+        a.inv_mask = mask & 15u;
+        if ((rc = launch(h, h->f_expand, a, 1))) return rc;
+        if ((rc = read_ctl(h, 2))) return rc;
+        uint32_t bits = 0;
+        for (int k = 0; k < 4; ++k)
+            if (h->ctl_host->viol_count[k]) bits |= 1u << k;
+        violated[i] = bits;
+    }
     return KMC_OK;
 }
 
@@ -2548,6 +2582,7 @@ int kmc_step_check_frontier(kmc_handle* h, kmc_level_info* info) {
     KmcArgs d = base_args(h, 2);
     d.fin = h->frontier[h->cur];
     d.mode = KMC_MODE_DRY;
+    d.flags |= KMC_FLAG_INV_ONLY;
     if ((rc = launch(h, h->f_expand, d, expand_grid(h, h->n_cur)))) return rc;
     if ((rc = read_ctl(h, 2))) return rc;
     for (int k = 0; k < 4; ++k) {

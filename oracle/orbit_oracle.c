@@ -31,6 +31,8 @@ typedef struct {
     _Atomic uint64_t *fpt;    /* last level, fingerprints only */
     uint64_t fcap;
     int fp_mode;              /* the level being produced is the last one and is not stored */
+    uint32_t inv_mask;        /* --inv: invariants checked on every stored state when it is expanded (a renaming of Replicas
+                                 maps violating states to violating states: the orbit's weight counts them all) */
     _Atomic uint64_t cursor;
     uint64_t lo, hi;
     int overflow;
@@ -41,6 +43,7 @@ typedef struct {
     uint64_t w;                /* weight of the state being expanded */
     uint64_t generated, new_weight, new_states, deadlocks_w, nsucc;
     uint64_t action_generated[KMO_MAX_ACTIONS];
+    uint64_t viol_w[4];        /* --inv: states of the expanded level (weighted) violating each checked invariant */
 } OW;
 
 static void o_permute(const P *p, const int *img, const uint8_t *s, uint8_t *t) {
@@ -189,6 +192,8 @@ static void *o_worker(void *a) {
             const int stab = r[e->sb] | (r[e->sb + 1] << 8);
             w->w = e->nf / (uint64_t)stab;
             w->nsucc = 0;
+            for (int inv = 0; inv < 4; inv++)
+                if ((e->inv_mask >> inv & 1u) && !model_invariant(&e->p, inv, r)) w->viol_w[inv] += w->w;
             model_expand(&e->p, r, o_emit, w);
             if (w->nsucc == 0) w->deadlocks_w += w->w;
         }
@@ -204,6 +209,7 @@ static void *o_map(uint64_t bytes) {
 int main(int argc, char **argv) {
     kmo_config c = {.model = M_KIP320, .N = 3, .L = 2, .R = 2, .E = 1, .K = 2, .MaxId = 10, .inv_mask = 0, .threads = 4};
     int levels = 0, last_fp = 0, tlog = 26, flog = 0;
+    uint32_t inv_mask = 0;
     uint64_t cap_states = 0;
     static const char *names[] = {"IdSequence", "FiniteReplicatedLog", "KafkaTruncateToHighWatermark", "Kip101", "Kip279", "Kip320", "Kip320FirstTry"};
     for (int i = 1; i < argc; i++) {
@@ -218,12 +224,14 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--fp-table-log2")) flog = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--max-stored")) cap_states = strtoull(argv[++i], NULL, 0);
         else if (!strcmp(argv[i], "--last-level-fp")) last_fp = 1;
+        else if (!strcmp(argv[i], "--inv")) inv_mask = (uint32_t)strtoul(argv[++i], NULL, 0);
         else { fprintf(stderr, "unknown arg %s\n", argv[i]); return 2; }
     }
     if (c.model < M_TRUNC_HW || c.model > M_KIP320_FIRST) { fprintf(stderr, "Kafka family only\n"); return 2; }
     OE *e = calloc(1, sizeof *e);
     if (!setup_params(&e->p, &c)) { fprintf(stderr, "bad constants\n"); return 2; }
     e->N = c.N; e->sb = e->p.sb; e->rs = e->sb + 2;
+    e->inv_mask = inv_mask;
     e->nf = 1;
     for (int i = 2; i <= c.N; i++) e->nf *= (uint64_t)i;
     e->tcap = 1ull << tlog;
@@ -242,6 +250,8 @@ int main(int argc, char **argv) {
     int nl = 1, exhausted = 0;
     lv_w[0] = distinct; lv_n[0] = 1;
     uint64_t lo = 0, hi = 1;
+    uint64_t viol_total[4] = {0}, viol_first_count[4] = {0};
+    int viol_first_depth[4] = {0};
     OW *ws = calloc((size_t)c.threads, sizeof *ws);
     pthread_t th[256];
     while (!levels || nl < levels) {
@@ -254,6 +264,12 @@ int main(int argc, char **argv) {
             pthread_join(th[t], NULL);
             generated += ws[t].generated; nw += ws[t].new_weight; nn += ws[t].new_states; deadlocks += ws[t].deadlocks_w;
             for (int a = 0; a < KMO_MAX_ACTIONS; a++) action_generated[a] += ws[t].action_generated[a];
+        }
+        for (int inv = 0; inv < 4; inv++) {   /* the level just expanded is depth nl */
+            uint64_t v = 0;
+            for (int t = 0; t < c.threads; t++) v += ws[t].viol_w[inv];
+            if (v && !viol_first_depth[inv]) { viol_first_depth[inv] = nl; viol_first_count[inv] = v; }
+            viol_total[inv] += v;
         }
         if (e->overflow) { fprintf(stderr, "orbit_oracle: table or arena full at level %d\n", nl + 1); return 3; }
         if (nn == 0) { exhausted = 1; break; }
@@ -273,6 +289,14 @@ int main(int argc, char **argv) {
     for (int i = 0; i < nl; i++) printf("%s%llu", i ? ", " : "", (unsigned long long)lv_n[i]);
     printf("], \"action_generated\": [");
     for (int a = 0; a < KMO_MAX_ACTIONS; a++) printf("%s%llu", a ? ", " : "", (unsigned long long)action_generated[a]);
+    /* (on a level budget the last level is stored but not expanded, hence not checked: as the device's kmc_run leaves it
+     * to the invariant pass over the last frontier) */
+    printf("], \"inv_mask\": %u, \"violating_states\": [%llu, %llu, %llu, %llu], \"first_violation_depth\": [%d, %d, %d, %d], "
+           "\"violating_at_first_depth\": [%llu, %llu, %llu, %llu",
+           inv_mask, (unsigned long long)viol_total[0], (unsigned long long)viol_total[1], (unsigned long long)viol_total[2],
+           (unsigned long long)viol_total[3], viol_first_depth[0], viol_first_depth[1], viol_first_depth[2], viol_first_depth[3],
+           (unsigned long long)viol_first_count[0], (unsigned long long)viol_first_count[1], (unsigned long long)viol_first_count[2],
+           (unsigned long long)viol_first_count[3]);
     printf("], \"threads\": %d, \"seconds\": %.1f}\n", c.threads, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
     return 0;
 }

@@ -31,7 +31,7 @@ KEYWORDS = {
 }
 BACKSLASH_WORDS = {
     "in", "notin", "union", "cup", "cap", "intersect", "subseteq", "leq", "geq", "E", "A", "div", "lnot", "land",
-    "lor", "X", "times", "o", "neg",
+    "lor", "X", "times", "o", "neg", "equiv",
 }
 # longest first
 SYMBOLS = [
@@ -230,7 +230,7 @@ class ModuleAst:
 
 # binary operators: text -> (left binding power, right binding power, op name)
 BINOPS = {
-    "=>": (1, 1, "implies"), "<=>": (2, 3, "equiv"),
+    "=>": (1, 1, "implies"), "<=>": (2, 3, "equiv"), "\\equiv": (2, 3, "equiv"),
     "\\/": (3, 4, "or"), "\\lor": (3, 4, "or"), "/\\": (5, 6, "and"), "\\land": (5, 6, "and"),
     "=": (9, 10, "eq"), "#": (9, 10, "ne"), "/=": (9, 10, "ne"),
     "<": (9, 10, "lt"), ">": (9, 10, "gt"), "<=": (9, 10, "le"), "=<": (9, 10, "le"), "\\leq": (9, 10, "le"),
@@ -408,7 +408,10 @@ class Parser:
 
     @staticmethod
     def _adjacent_apply_ok(left):
-        return left.kind in ("ident", "fapp", "dot", "at", "apply", "inst", "prime", "paren")
+        # (a bracketed constructor applied on the spot — [f EXCEPT ![a] = b][c], <<x, y>>[1], [a |-> 1]["a"] — is ordinary
+        # function application too; the reference never writes it, tests/test_tlar_semantics_cpu.py does)
+        return left.kind in ("ident", "fapp", "dot", "at", "apply", "inst", "prime", "paren", "except", "record", "fcons",
+                             "tuple")
 
     def junction(self, t):
         kind = "and" if t.text in ("/\\", "\\land") else "or"

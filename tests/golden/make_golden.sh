@@ -23,6 +23,13 @@ done
 for m in Kip101 Kip279 Kip320FirstTry; do
   ./oracle/kmc_oracle --model $m --N 3 --L 6 --R 6 --E 2 --threads 8 --inv 1 --fp-only --table-log2 31 > tests/golden/oracle_fp_$(echo $m | tr A-Z a-z)_3_6_6_2.json
 done
+# ... and EXACTLY (round 4): Oracle-O stores one full state per orbit of the permutations of Replicas (a sixth of the states at
+# three replicas: 101-135 M stored states, ~11 GB, 3-5 minutes on 4 threads) and weighs every count, so the four models whose plain
+# exact search outgrows this box are pinned without a hash in sight; the fp-only files above stay as a third witness.  Kip320 itself
+# too (46,636,681 stored states = what the GPU's orbit-counting search stores).  --inv 7: TypeOk, WeakIsr, StrongIsr in continue mode.
+for m in KafkaTruncateToHighWatermark:thw Kip101:kip101 Kip279:kip279 Kip320FirstTry:kip320firsttry Kip320:kip320; do
+  ./oracle/orbit_oracle --model ${m%%:*} --N 3 --L 6 --R 6 --E 2 --threads 4 --inv 7 --table-log2 29 --max-stored 170000000 > tests/golden/orbit_${m##*:}_3_6_6_2.json
+done
 # BASELINE config 5 (7 brokers, LogSize 8) cannot be exhausted: the exact oracle's PREFIX of ten levels (197,561,008 states,
 # 2.5 minutes, ~25 GB) — what the plain and the orbit-counting GPU searches are held to over a level budget of 10
 # (written through tests/kmo.py: kmo.Run(make_config("Kip320", N=7, L=8, R=8, E=3, threads=8, max_states=41002348)) -> levels, generated,

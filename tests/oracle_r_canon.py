@@ -124,3 +124,35 @@ def level_digest(byte_states):
 
 def kafka_constants(N, L, R, E):
     return dict(Replicas=frozenset(ModelValue(f"b{i + 1}") for i in range(N)), LogSize=L, MaxRecords=R, MaxLeaderEpoch=E)
+
+
+def kafka_state_from_bytes(b, constants):
+    """Inverse of kafka_state_bytes: canonical bytes -> the TLA+ values of KafkaReplication.tla:75's variables (what Oracle-R's
+    evaluator takes as a state).  Lets the reference's text be evaluated on ANY state — a deep sample of a C-oracle walk, an
+    arbitrary bit pattern — not only on those its own search reaches."""
+    idx = replica_order(constants)
+    name = {i: r for r, i in idx.items()}
+    N, L, E = len(idx), constants["LogSize"], constants["MaxLeaderEpoch"]
+    assert len(b) == N * (5 + L) + 5 + 2 * (E + 1)
+
+    def unmask(m):
+        return frozenset(name[i] for i in range(N) if m >> i & 1)
+
+    def leader(x):
+        return "NONE" if x == 0 else name[x - 1]
+
+    logs, states = {}, {}
+    for i in range(N):
+        o = i * (5 + L)
+        recs = {}
+        for k in range(L):
+            c = b[o + 5 + k]
+            recs[k] = -1 if c == 0 else Fn({"id": (c - 1) // (E + 1), "epoch": (c - 1) % (E + 1)})
+        logs[name[i]] = Fn({"endOffset": b[o], "records": Fn(recs)})
+        states[name[i]] = Fn({"hw": b[o + 1], "leaderEpoch": b[o + 2] - 1, "leader": leader(b[o + 3]), "isr": unmask(b[o + 4])})
+    g = N * (5 + L)
+    reqs = frozenset(Fn({"leaderEpoch": e, "leader": leader(b[g + 5 + 2 * e]), "isr": unmask(b[g + 6 + 2 * e])})
+                     for e in range(b[g + 1]))
+    return dict(replicaLog=Fn(logs), replicaState=Fn(states), nextRecordId=b[g], nextLeaderEpoch=b[g + 1],
+                quorumState=Fn({"leaderEpoch": b[g + 2] - 1, "leader": leader(b[g + 3]), "isr": unmask(b[g + 4])}),
+                leaderAndIsrRequests=reqs)

@@ -28,41 +28,36 @@ def test_dram_bytes_per_access_are_read_from_the_committed_calibration(bench):
     assert bench.calibrated_bytes_per_access(42) is None     # a mode the file does not hold
 
 
-def test_traffic_is_quoted_only_for_the_device_code_it_was_measured_on(bench, monkeypatch):
-    t, src = bench.measured_traffic()
-    newest = bench.newest_profile("pmc_summary.json")
-    pm = json.load(open(newest))
-    if pm["device_source_sha256"] == bench.device_source_sha256():
-        assert t == pm["hbm_bytes_per_launch"] and src == os.path.relpath(newest, ROOT)
-        # the DRAM-unit counters, not FETCH_SIZE: reads are twice what FETCH_SIZE reports on gfx950
-        assert abs(pm["read_bytes"] / pm["FETCH_SIZE_bytes_as_reported"] - 2.0) < 0.01
-        assert abs(pm["hbm_bytes"] - (pm["read_bytes"] + pm["write_bytes"] + pm["atomic_bytes"])) < 1.0
-    # the header's text has moved on: quoted only if the headline's kernels are, instruction for instruction, the measured ones
-    monkeypatch.setattr(bench, "device_source_sha256", lambda: "0" * 64)
-    monkeypatch.setattr(bench, "headline_kernel_code_sha256", lambda: "1" * 64)
-    t2, why = bench.measured_traffic()
-    assert t2 is None and "other device code" in why
-    monkeypatch.setattr(bench, "headline_kernel_code_sha256", lambda: None)      # no compiler to ask: not quoted either
-    assert bench.measured_traffic()[0] is None
-    if pm.get("kernel_code_sha256"):
-        monkeypatch.setattr(bench, "headline_kernel_code_sha256", lambda: pm["kernel_code_sha256"])
-        t3, src3 = bench.measured_traffic()
-        assert t3 == pm["hbm_bytes_per_launch"] and "kernel_code_sha256" in src3 and os.path.relpath(newest, ROOT) in src3
+def test_traffic_is_quoted_only_for_the_machine_code_it_was_measured_on(bench):
+    """bench.measured_traffic(code): a committed PMC summary is quoted for a run only when it carries the kernel_code_sha256 of
+    the kernels that run executes — whatever the workload (headline, orbit counting, BASELINE configs 4 and 5)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*pmc_summary.json")), reverse=True)
+    stamped = [(f, json.load(open(f))) for f in files]
+    stamped = [(f, j) for f, j in stamped if j.get("kernel_code_sha256")]
+    assert stamped, "no PMC summary carries a code identity"
+    first = {}
+    for f, j in stamped:   # newest round first wins for a given code
+        first.setdefault(j["kernel_code_sha256"], (f, j))
+    for code, (f, j) in first.items():
+        t, src = bench.measured_traffic(code)
+        assert t == j["hbm_bytes_per_launch"] and os.path.relpath(f, ROOT) in src and code[:16] in src
+        if "FETCH_SIZE_bytes_as_reported" in j and "atomic_bytes" in j:
+            # the DRAM-unit counters, not FETCH_SIZE: reads are twice what FETCH_SIZE reports on gfx950
+            assert abs(j["read_bytes"] / j["FETCH_SIZE_bytes_as_reported"] - 2.0) < 0.02
+            assert abs(j["hbm_bytes"] - (j["read_bytes"] + j["write_bytes"] + j["atomic_bytes"])) < 1.0
+    t2, why = bench.measured_traffic("1" * 64)          # other machine code: not quoted, and the reason says so
+    assert t2 is None and "no PMC summary was measured on this code" in why
+    assert bench.measured_traffic(None)[0] is None      # no compiler to ask: not quoted either
 
 
-def test_the_newest_pmc_summary_belongs_to_the_kernels_this_tree_builds(bench):
-    """profiles/r03_pmc_summary.json was measured before the orbit-deficit cells became 64-bit (an edit inside #if KMC_SYMM of
-    kmc_device.h): the PLAIN headline's kernels hiprtc builds from this tree (gfx950, no GPU needed) hash to what the summary
-    records, so bench.py quotes its traffic."""
-    pm = json.load(open(bench.newest_profile("pmc_summary.json")))
-    if "kernel_code_sha256" not in pm:
-        pytest.skip("the newest summary predates kernel_code_sha256")
+def test_a_committed_pmc_summary_belongs_to_the_headline_kernels_this_tree_builds(bench):
+    """The PLAIN headline's kernels hiprtc builds from this tree (gfx950, no GPU needed) hash to what a committed summary
+    records, so bench.py's default line quotes measured traffic; the same for the orbit-counting leg."""
     code = bench.headline_kernel_code_sha256()
     assert code is not None and len(code) == 64
-    if pm["device_source_sha256"] != bench.device_source_sha256():
-        assert code == pm["kernel_code_sha256"], "the headline's kernels changed since the counters were collected: re-measure"
-    t, src = bench.measured_traffic()
-    assert t == pm["hbm_bytes_per_launch"]
+    t, src = bench.measured_traffic(code)
+    assert t, f"the headline's kernels changed since the counters were collected: re-measure ({src})"
 
 
 NEWEST_ROUND = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench.json"))[-1][:3]

@@ -1,4 +1,8 @@
-"""GPU: the second binding SURVEY 8d names for "KafkaReplication.tla, 3 brokers, maxLogLen=6" — KafkaTruncateToHighWatermark,
+"""GPU: every Kafka model at the headline's own constants against EXACT fixtures (round 4: Oracle-O, oracle/orbit_oracle.c — full
+states, one per orbit of the permutations of Replicas, weighted counts: tests/golden/orbit_*_3_6_6_2.json), the plain search and
+the orbit-counting one, verdicts and violation counts included; the C oracle's fingerprint-only files stay as a third witness.
+
+The second binding SURVEY 8d names for "KafkaReplication.tla, 3 brokers, maxLogLen=6" — KafkaTruncateToHighWatermark,
 whose Next (KafkaTruncateToHighWatermark.tla:33-42) is built purely from KafkaReplication.tla's actions — at the headline's
 own constants.  810,380,080 distinct states: more than the exact CPU oracle can hold, so the fixture comes from the oracle's
 fingerprint-only mode (tests/golden/oracle_fp_thw_3_6_6_2.json: another hash over another state encoding, another table,
@@ -59,3 +63,52 @@ def test_the_other_kafka_models_at_the_headline_constants(model, fixture):
     assert (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
     assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
     assert r.deadlock_states == g["deadlock_states"]
+
+
+# ---- round 4: the same constants against EXACT fixtures (Oracle-O stores full states; nothing here is a hash against a hash) ----
+EXACT = [("KafkaTruncateToHighWatermark", "orbit_thw_3_6_6_2.json", "oracle_fp_thw_3_6_6_2.json"),
+         ("Kip101", "orbit_kip101_3_6_6_2.json", "oracle_fp_kip101_3_6_6_2.json"),
+         ("Kip279", "orbit_kip279_3_6_6_2.json", "oracle_fp_kip279_3_6_6_2.json"),
+         ("Kip320FirstTry", "orbit_kip320firsttry_3_6_6_2.json", "oracle_fp_kip320firsttry_3_6_6_2.json"),
+         ("Kip320", "orbit_kip320_3_6_6_2.json", "oracle_kip320_3_6_6_2.json")]
+
+
+@pytest.mark.parametrize("symmetry", [False, True], ids=["plain", "orbit-counting"])
+@pytest.mark.parametrize("model,fixture", [(m, e) for m, e, _ in EXACT], ids=[m for m, _, _ in EXACT])
+def test_every_kafka_model_at_the_headline_constants_matches_the_exact_orbit_oracle(model, fixture, symmetry):
+    g = json.load(open(os.path.join(GOLDEN, fixture)))
+    cfg = CheckerConfig(model=model, n_replicas=3, log_size=6, max_records=6, max_leader_epoch=2, invariants=("TypeOk",),
+                        table_capacity=1 << (29 if symmetry else 31), frontier_capacity=1 << (25 if symmetry else 27),
+                        symmetry=symmetry)
+    with ModelChecker(cfg) as mc:
+        r = mc.run()
+    assert r.verdict == "ok" and r.queue_left == 0
+    assert (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
+    assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
+    assert r.deadlock_states == g["deadlock_states"]
+    if symmetry:
+        assert r.orbit_representatives == g["stored"]      # the two orbit searches choose representatives differently, not orbits
+
+
+@pytest.mark.parametrize("symmetry", [False, True], ids=["plain", "orbit-counting"])
+@pytest.mark.parametrize("model,fixture", [(m, e) for m, e, _ in EXACT], ids=[m for m, _, _ in EXACT])
+def test_first_violation_at_the_headline_constants_matches_the_exact_orbit_oracle(model, fixture, symmetry):
+    """TypeOk, WeakIsr and StrongIsr, stopping at the first violation: the depth and how many states of that level violate
+    each invariant (Kip320: none — KafkaReplication.tla:320-340 hold, Kip320.tla:168-171)."""
+    g = json.load(open(os.path.join(GOLDEN, fixture)))
+    cfg = CheckerConfig(model=model, n_replicas=3, log_size=6, max_records=6, max_leader_epoch=2,
+                        invariants=("TypeOk", "WeakIsr", "StrongIsr"), table_capacity=1 << 28, frontier_capacity=1 << 25,
+                        symmetry=symmetry, max_levels=0 if model == "Kip320" else 16)
+    with ModelChecker(cfg) as mc:
+        r = mc.run()
+    depths = [d for d in g["first_violation_depth"][:3] if d]
+    if not depths:
+        assert r.verdict == "ok" and sum(g["violating_states"]) == 0 and r.distinct == g["distinct"]
+        return
+    first = min(depths)
+    assert r.verdict == "invariant" and r.violation_depth == first
+    want = {n: (g["violating_at_first_depth"][k] if g["first_violation_depth"][k] == first else 0)
+            for k, n in enumerate(("TypeOk", "WeakIsr", "StrongIsr"))}
+    got = {n: r.violation_count.get(n, 0) for n in want}
+    assert got == want
+    assert r.violated_invariant == next(n for n in ("TypeOk", "WeakIsr", "StrongIsr") if want[n])

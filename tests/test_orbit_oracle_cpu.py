@@ -90,3 +90,46 @@ def test_config5_seven_levels_live():
     r = orbit_oracle("Kip320", 7, 8, 8, 3, "--levels", "8")
     g10 = json.load(open(os.path.join(GOLDEN, "oracle_kip320_7_8_8_3_levels10.json")))
     assert r["levels"] == g10["levels"][:8] and r["stored_per_level"][:5] == [1, 2, 6, 24, 117]
+
+
+# ---- round 4: exact pins at the headline's own constants (tests/golden/orbit_*_3_6_6_2.json) ------------------------------------
+EXACT = [("KafkaTruncateToHighWatermark", "orbit_thw_3_6_6_2.json", "oracle_fp_thw_3_6_6_2.json"),
+         ("Kip101", "orbit_kip101_3_6_6_2.json", "oracle_fp_kip101_3_6_6_2.json"),
+         ("Kip279", "orbit_kip279_3_6_6_2.json", "oracle_fp_kip279_3_6_6_2.json"),
+         ("Kip320FirstTry", "orbit_kip320firsttry_3_6_6_2.json", "oracle_fp_kip320firsttry_3_6_6_2.json"),
+         ("Kip320", "orbit_kip320_3_6_6_2.json", "oracle_kip320_3_6_6_2.json")]
+
+
+def test_the_exact_orbit_fixtures_and_the_older_witnesses_agree():
+    """Oracle-O's exact numbers equal the C oracle's
+    fingerprint-only ones (and, for Kip320, the plain exact oracle's) — three searches that share a successor function
+    and nothing else (seen-set, state encoding, what is stored)."""
+    for model, exact, other in EXACT:
+        g, f = json.load(open(os.path.join(GOLDEN, exact))), json.load(open(os.path.join(GOLDEN, other)))
+        assert g["model"] == model and (g["N"], g["L"], g["R"], g["E"]) == (3, 6, 6, 2) and g["exhausted"]
+        assert not g["last_level_fingerprints_only"]
+        assert (g["distinct"], g["generated"], g["depth"], g["levels"], g["deadlock_states"]) == \
+            (f["distinct"], f["generated"], f["depth"], f["levels"], f["deadlock_states"])
+        assert g["action_generated"][:len(f["action_generated"])] == f["action_generated"]
+        assert sum(g["levels"]) == g["distinct"] and sum(g["action_generated"]) + 1 == g["generated"]
+
+
+
+
+@pytest.mark.parametrize("model", KAFKA)
+def test_invariant_counts_of_the_orbit_search_equal_the_plain_oracles(model):
+    """--inv: violating states weighted by their orbits = the plain oracle's violation counts in continue mode (first depth and
+    the count there; the plain oracle reports nothing more), on a configuration where every model but Kip320 violates."""
+    r = orbit_oracle(model, 3, 3, 3, 2, "--inv", "7", "--table-log2", "24")
+    o = kmo.Run(kmo.make_config(model, N=3, L=3, R=3, E=2, invariants=("TypeOk", "WeakIsr", "StrongIsr"), stop_on_violation=False,
+                                threads=4))
+    assert (r["distinct"], r["generated"], r["levels"]) == (o.distinct, o.generated, o.levels)
+    depths = [d for d in r["first_violation_depth"][:3] if d]
+    if model == "Kip320":
+        assert not depths and o.viol_inv is None and r["violating_states"] == [0, 0, 0, 0]
+        return
+    first = min(depths)
+    assert o.viol_depth == first
+    for k, n in enumerate(("TypeOk", "WeakIsr", "StrongIsr")):
+        assert o.viol_count[n] == (r["violating_at_first_depth"][k] if r["first_violation_depth"][k] == first else 0)
+    assert r["violating_states"][0] == 0 and all(r["violating_states"][k] >= r["violating_at_first_depth"][k] for k in (1, 2))

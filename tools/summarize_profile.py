@@ -14,14 +14,16 @@ _h = hashlib.sha256()
 for _f in ("kmc_layout.h", "kmc_device.h"):
     _h.update(open(os.path.join(_root, "kafka_specification_amd", "csrc", _f), "rb").read())
 out["device_source_sha256"] = _h.hexdigest()
-# ... and the identity of the machine code of the headline's kernels (.text + descriptors + metadata of the code object):
-# what bench.py compares when the header's text has moved on in a build the headline does not compile
+# ... and the identity of the machine code of the kernels the profiled run executed (.text + descriptors + metadata of the
+# code object): the profiled bench line names it (roofline.kernel_code_sha256, any workload, with or without orbit
+# counting) — what bench.py compares before it quotes a summary
+out["kernel_code_sha256"] = None
 try:
-    sys.path.insert(0, _root)
-    import bench as _bench
-    out["kernel_code_sha256"] = _bench.headline_kernel_code_sha256()
-except Exception as _e:
-    out["kernel_code_sha256"] = None
+    for _line in open(os.path.join(d, "trace.log")):
+        if _line.startswith('{"metric"'):
+            out["kernel_code_sha256"] = json.loads(_line)["roofline"].get("kernel_code_sha256")
+except (OSError, ValueError, KeyError):
+    pass
 # kernel trace
 _tr = glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True)
 rows = list(csv.DictReader(open(_tr[0])))
@@ -80,7 +82,8 @@ try:
     for line in open(os.path.join(d, "trace.log")):
         if line.startswith('{"metric"'):
             run = json.loads(line)
-            out["run"] = {k: run["config"].get(k) for k in ("workload", "distinct_states", "states_generated", "seen_set_probes")}
+            out["run"] = {k: run["config"].get(k) for k in ("workload", "parallelism", "distinct_states", "states_generated",
+                                                            "seen_set_probes", "stored_states", "level_budget", "depth")}
             if "TCC_EA0_ATOMIC_sum" in ctr and run["config"].get("distinct_states"):
                 der["claims_per_distinct_state"] = ctr["TCC_EA0_ATOMIC_sum"] / run["config"]["distinct_states"]
 except OSError:
@@ -116,4 +119,7 @@ if len(sys.argv) > 3 and ("dram_bytes" in der or "hbm_bytes_raw" in der):
     if out.get("kernel_code_sha256"):
         pm["kernel_code_sha256"] = out["kernel_code_sha256"]
     pm["launches"] = n
+    pm["run"] = out.get("run")
+    pm["dominant_kernel"] = exp
+    pm["kernel_seconds_total"] = t
     open(sys.argv[3], "w").write(json.dumps(pm, indent=1) + "\n")
