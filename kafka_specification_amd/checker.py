@@ -43,7 +43,7 @@ class CheckerConfig:
     symmetry: bool = False                  # orbit counting: store / expand one state per orbit of the permutations of Replicas,
                                             # weigh every count by the orbit's size — the plain search's numbers (TLC without a
                                             # SYMMETRY set) from ~1/|Replicas|! of the probes.  Kafka family and
-                                            # FiniteReplicatedLog, at most 4 replicas, one GPU
+                                            # FiniteReplicatedLog, at most 7 replicas (KMC_SYMMETRY_MAX_REPLICAS), one GPU
 
     def to_native(self) -> nat.KmcConfig:
         if self.model not in nat.MODELS:

@@ -715,6 +715,10 @@ bool absorb(kmc_handle* h, const KmcLevelCtl& c, const u64* parent_frontier, con
 
 // Produce Init and insert it on its owner.  Leaves level = 1.
 int do_begin(kmc_handle* h) {
+    // a stepped search that stopped on a verdict never reached kmc_step_finish: a pipelined level's last transfer and insert
+    // may still be in flight on the second stream, and its records are still booked — neither belongs to the new search
+    if (h->xstream) HIP_TRY(hipStreamSynchronize(h->xstream));
+    h->inserted_level = 0;
     int rc = reset_run(h);
     if (rc) return rc;
     KmcArgs a = base_args(h, 0);
@@ -973,6 +977,10 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     bool want_filter = h->cfg.n_shards > 1 && h->cfg.n_shards <= 4;
     if (const char* e = getenv("KMC_SEND_FILTER")) want_filter = h->cfg.n_shards > 1 && atoi(e) != 0;
     if (getenv("KMC_NO_SEND_FILTER") && atoi(getenv("KMC_NO_SEND_FILTER"))) want_filter = false;
+    // 128-bit entries: the sender-side filter remembers 64-bit fingerprints only — a second distinct remote state with the
+    // same fingerprint would be dropped at the sender and never meet the owner's check-word comparison, and the conservation
+    // law (probed is counted before the filter) could not see it.  No filter then, whatever the environment asks for.
+    if (h->cfg.wide_fingerprint) want_filter = false;
     if (want_filter) {
         // it may meet up to ~2x as many distinct remote fingerprints as it owns
         h->sent_cap = tcap * 2;
@@ -1641,6 +1649,7 @@ int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap
     if (!h->have_witness) return fail(KMC_E_STATE, "no violation witness recorded");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->xstream) HIP_TRY(hipStreamSynchronize(h->xstream));   // (a pipelined level's inserts write the table on that stream)
     // 1. walk predecessor fingerprints back to the initial state (pred == 0)
     std::vector<uint64_t> chain;
     uint64_t fp = h->res.violation_fp;
@@ -1733,6 +1742,7 @@ int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     // the next kmc_step_expand; the driver keeps the global counters (sharded.py) and sets the verdict first
     if (h->cfg.n_shards != 1 && (!h->stepping || h->step_expanded))
         return fail(KMC_E_STATE, "a shard is checkpointed between kmc_step_finish and the next kmc_step_expand");
+    if (h->xstream) HIP_TRY(hipStreamSynchronize(h->xstream));
     if (h->levels.empty()) return fail(KMC_E_STATE, "nothing to checkpoint: run first");
     // Only a level boundary is a consistent state: after a stop inside a level (invariant, deadlock, table / frontier
     // full) the table already holds the fingerprints of the rolled-back or partial level while the frontier is still

@@ -328,7 +328,10 @@ class RcclExchange:
     def expand_and_exchange(self, engines, stats, level_states=0):
         """The level's expansion and its count exchange in one call under the ABI (kmc_step_expand_counts): the send counts
         go from k_expand's control block into the all-gather on the device, and the host waits once.  `level_states`: the
-        global size of the level being expanded (identical on every rank) — decides one shot or pipeline."""
+        global size of the newest level whose statistics have been REDUCED (identical on every rank) — the level before the
+        one being expanded, whose own size is still in `stats`, unreduced: the choice between one shot and pipeline therefore
+        lags one BFS level (levels grow by less than 6 x here, so the first level past the threshold runs one-shot), and the
+        first level after a resume (0) is never pipelined."""
         (st,) = stats
         st = np.ascontiguousarray(st, dtype=np.int64)
         out = np.zeros(N_STATS, dtype=np.int64)
@@ -556,8 +559,9 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
         # the engines hold level depth+1 (complete); like kmc_run, level l is expanded iff l < max_levels
         can_expand = depth + 1 < max_levels
         if can_expand and pipelined and hasattr(exchange, "expand_and_exchange"):
-            # fused under the ABI: one host wait (or, for a very wide level, a pipeline of parts: RcclExchange).  The size of
-            # the level being expanded is the global one, the same on every rank.
+            # fused under the ABI: one host wait (or, for a very wide level, a pipeline of parts: RcclExchange).  `new` is the
+            # global size of the last level RECORDED (the one before the level being expanded, whose statistics are still in
+            # `pending`): the same on every rank, one level behind.
             st, deliver = exchange.expand_and_exchange(engines, pending, level_states=new)
         elif can_expand and pipelined:
             sends = [e.expand() for e in engines]

@@ -41,7 +41,7 @@ def test_the_sample_reaches_what_small_exhaustive_runs_cannot(entry):
     if L >= 5:
         assert sum(f[3] >= 5 and f[2] >= 3 for f in feats) >= 2000   # a log >= 5 deep with >= 2 epochs, some hw >= 3
         assert sum(f[0] == L for f in feats) >= 1000                  # full logs
-    assert sum(f[1] >= 2 for f in feats) >= 2000
+    assert sum(f[1] >= 2 for f in feats) >= (2000 if L >= 5 else 500)   # (LogSize 2, two epochs: fewer ways to mix them)
     assert int((fx["nsucc"] == 0).sum()) >= 1                         # terminal states
     assert all(int(fx["per_action"][:, k].sum()) > 0 for k in range(len(m["actions"])))   # every disjunct of Next fires
     assert m["coverage"]["states_with_a_twice_generated_successor"] == 0 or m["module"] in ("Kip279", "Kip320", "Kip320FirstTry")
