@@ -178,6 +178,34 @@ def expected_counts(c):
     return None
 
 
+def cold_start(c):
+    """What a CLI user waits for (wall time-to-exhaustive): ONE fresh process of the native front end —
+    kafka_specification_amd/tlc models/Kip320.tla — from exec to exit: loading libkmc.so and the cached code object, hipMalloc and
+    first touch of the seen-set and the frontiers, the search, the verdict printed.  Two runs: as a user types it (traces
+    kept: 8 more bytes per table slot) and with -notrace (what the timed steps above run).  Never part of `value`."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "kafka_specification_amd", "tlc")
+    spec = os.path.join(ROOT, "models", c["model"] + ".tla")
+    if c != headline_config() or not os.path.exists(exe):
+        return None
+    out = {"command": "kafka_specification_amd/tlc models/%s.tla -table %d -frontier %d [-notrace]" % (c["model"], 1 << 30, 1 << 26)}
+    for key, extra in (("wall_s", []), ("wall_s_notrace", ["-notrace"])):
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([exe, spec, "-table", str(1 << 30), "-frontier", str(1 << 26)] + extra, capture_output=True,
+                               text=True, timeout=300)
+        except Exception as e:   # the bench line does not depend on it
+            out[key] = None
+            out["error"] = str(e)[:120]
+            continue
+        out[key] = time.perf_counter() - t0
+        m = re.search(r"(\d+) states generated, (\d+) distinct states found", p.stdout)
+        out["distinct_states" if key == "wall_s" else "distinct_states_notrace"] = int(m.group(2)) if m else None
+        out["exit_code"] = p.returncode
+    return out
+
+
 def cpu_baseline(c, budget_states, total_states):
     """The C oracle (exact-state BFS, a port — TLC itself cannot run here) on all host cores,
     on a bounded prefix of the same workload: it stops after the BFS level that crosses
@@ -256,6 +284,7 @@ def main():
                     help="the timed region runs the orbit-counting search (kmc_config.symmetry) instead of the plain one: for "
                          "profiling that kernel; the default line times the plain search and reports orbit counting beside it")
     ap.add_argument("--no-orbit-counting", action="store_true", help="skip the orbit_counting leg of the default line")
+    ap.add_argument("--no-cold-start", action="store_true", help="skip the cold_start leg (one fresh CLI process, exec to exit)")
     ap.add_argument("--backend", default=os.environ.get("KMC_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
                     help="process-group backend of the N>1 leg: nccl (= RCCL, the product) or gloo (CPU launch-path test)")
     a = ap.parse_args()
@@ -422,6 +451,10 @@ def main():
                          "note": "algorithmic bytes of the STORED states (the same per-state figure) over this search's "
                                  "k_expand time; the kernel is instruction-bound here (the representative of every successor "
                                  "is the smallest of its images under the permutations: profiles/r03_symmetry.txt)"}}
+    if world == 1 and not a.symmetry and not a.level_budget and not a.no_cold_start:
+        cs = cold_start(c)
+        if cs:
+            out["cold_start"] = cs
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(c, a.cpu_states or max(1_000_000, distinct // 4), distinct)
     print(json.dumps(out))

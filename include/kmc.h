@@ -111,13 +111,17 @@ typedef struct kmc_config {
                                    state's orbit: distinct / generated / per-level / per-disjunct / deadlock / violation
                                    counts, verdict and depth are those of the plain search (and of TLC WITHOUT a SYMMETRY
                                    set — TLC's own SYMMETRY reports the reduced counts) from ~1/|Replicas|! of the probes.
-                                   Kafka family and FiniteReplicatedLog, |Replicas| <= KMC_SYMMETRY_MAX_REPLICAS, n_shards = 1.  Traces are real
-                                   behaviours (each step a successor of the one before), not chains of representatives */
+                                   Kafka family and FiniteReplicatedLog, |Replicas| <= KMC_SYMMETRY_MAX_REPLICAS.  Traces are real
+                                   behaviours (each step a successor of the one before), not chains of representatives.
+                                   n_shards > 1: successors travel as representatives, every shard weighs the counters of
+                                   kmc_step_finish / kmc_step_check_frontier itself (the states it claimed, the expansions
+                                   it ran), so the sums over the shards are the plain search's numbers; no keep_trace there */
 } kmc_config;
 
 typedef struct kmc_level_info {
     uint64_t depth;             /* 1-based: the initial state is depth 1 */
-    uint64_t new_states;        /* distinct states first seen at this depth (this shard) */
+    uint64_t new_states;        /* distinct states first seen at this depth (this shard); kmc_config.symmetry: as the plain
+                                   search counts them (orbit sizes summed), like every count below */
     uint64_t generated_total;   /* running total, TLC's "states generated" (initial state included) */
     uint64_t distinct_total;    /* running total, TLC's "distinct states found" */
     double seconds;             /* wall time since kmc_run started */

@@ -145,6 +145,13 @@ typedef unsigned int u32;
                           //    successor in lane 5 between the ring and the seen-set — the failure class of round 1's miscompiled
                           //    kernel.  The conservation check (generated = probed) and KMC_VERIFY's checksum must both catch it
 #endif
+#ifndef KMC_GROUPED_GUARDS_MIN_INSTANCES
+#define KMC_GROUPED_GUARDS_MIN_INSTANCES 1000000   // Kafka configurations with MORE action instances than this evaluate pass 1
+                                   // group by group (KmcKafka::group_pre): the guards of a leader's bindings only if some lane
+                                   // of the tile has that replica presuming leadership, those of a (request, leader) pair only
+                                   // if some lane's request of that epoch names that leader — a wave-uniform branch on a
+                                   // ballot around each group, the instances' own guards (inst<I>) inside
+#endif
 #ifndef KMC_RT_GUARDS_MIN_INSTANCES
 #define KMC_RT_GUARDS_MIN_INSTANCES 1000000   // Kafka configurations with MORE action instances than this evaluate their guards
                                           // in per-kind loops over a run-time binding (KmcKafka::guard<K>) instead of one
@@ -360,7 +367,7 @@ KMC_HD inline u32 kmc_owner(u64 fp, u32 nshards) { return (u32)((((fp >> 40) & 0
 // ========================================================================================
 template <long long MAXID> struct KmcIdSequence {
     static constexpr int W = 1, NKINDS = 1, NINST = 1;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false, RUNTIME_GUARDS = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false, RUNTIME_GUARDS = false, GROUPED_GUARDS = false;
     struct Pre { u64 nextId; };
     static KMC_DEV void init(u64* w) { w[0] = 0; }  // IdSequence.tla:37
     static KMC_DEV Pre extract(const u64* s) { return Pre{s[0]}; }
@@ -384,7 +391,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
     static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_FINITE_REPLICATED_LOG, N, L, 0, 0, K);
     static_assert(Y.valid, "FiniteReplicatedLog parameters cannot be packed");
     static constexpr int W = Y.W, NKINDS = 3;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false, RUNTIME_GUARDS = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false, RUNTIME_GUARDS = false, GROUPED_GUARDS = false;
     static constexpr int C_APPEND = N * K, C_TRUNC = N * L, C_REPL = N * (N - 1);
     static constexpr int NINST = C_APPEND + C_TRUNC + C_REPL;
     static constexpr u64 MR = (1ull << Y.BR) - 1;
@@ -459,7 +466,7 @@ template <int N, int MO, int V> struct KmcAsyncIsr {
     static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_ASYNC_ISR, N, MO, 0, V, 0);
     static_assert(Y.valid, "AsyncIsr parameters cannot be packed (need N <= 6, MaxVersion <= 7)");
     static constexpr int W = Y.W, NKINDS = 7;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = true, KIND_MAJOR = false, RUNTIME_GUARDS = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = true, KIND_MAJOR = false, RUNTIME_GUARDS = false, GROUPED_GUARDS = false;
     static constexpr int NS = 1 << N;  // isr masks = request bits per version
     // Next (AsyncIsr.tla:152-159) flattened into instances, one per binding of each disjunct's \E
     static constexpr int B0 = 0;             // ControllerShrinkIsr        (replica # Leader)
@@ -1164,6 +1171,65 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
     // The expressions are inst<I>'s, line by line; tests/host_emu.cpp compares the two on EVERY binding (enabled or not)
     // of every visited state.
     static constexpr bool RUNTIME_GUARDS = KIND_MAJOR && NINST > KMC_RT_GUARDS_MIN_INSTANCES;
+    // ---- guard groups (pass 1 of the wide configurations, KMC_GROUPED_GUARDS_MIN_INSTANCES) ---------------------------
+    // The instances of Next fall into groups that share a cheap NECESSARY condition:
+    //   group 0                 kinds 0, 1, 5, 6 (one binding per replica: 4N instances), always evaluated;
+    //   group 1 + e*N + l       the bindings that act on the LeaderAndIsr request with epoch e naming leader l — BecomeLeader
+    //                           (e, l) and BecomeFollower* (l, r, e) for every r # l: all need that request to exist and to name
+    //                           l (KafkaReplication.tla:186-188, :281-284; Kip320.tla:134-137);
+    //   group 1 + (E+1)N + l    the bindings a PRESUMED leader l takes part in — Leader*ExpandIsr (l, r), Leader*ShrinkIsr (l, r),
+    //                           FollowerReplicate / *Fetch (l, f), FollowerTruncate (l, f): all need ReplicaPresumesLeadership(l)
+    //                           (:126; IsTrueLeader :128-131, IsFollowingLeaderEpoch Kip320.tla:39-42, FollowerReplicate
+    //                           KafkaReplication.tla:302-304, IsFollowerCaughtUpToLeaderEpoch Kip320FirstTry.tla:49-51).
+    // A tile's 64 states are neighbours in the frontier (children of neighbouring parents): most groups are dead for the whole
+    // wave.  tests/host_emu.cpp holds "inst<I> enabled => group_pre<group of I>" on every instance of every visited state and
+    // the partition of 0..NINST-1 into the groups' lists at compile time.
+    static constexpr bool GROUPED_GUARDS = KIND_MAJOR && !RUNTIME_GUARDS && NINST > KMC_GROUPED_GUARDS_MIN_INSTANCES;
+    static constexpr int NGROUPS = 1 + (E + 1) * N + N;
+    static constexpr int G_REQ0 = 1, G_LDR0 = 1 + (E + 1) * N;
+    static constexpr int group_size(int g) {
+        return g == 0 ? 4 * N : g < G_LDR0 ? N : N + (N - 1) * (FIRST ? 3 : 2);
+    }
+    static constexpr int group_inst(int g, int j) {   // the j-th instance of group g
+        if (g == 0) return j < N ? B0 + j : j < 2 * N ? B1 + (j - N) : j < 3 * N ? B5 + (j - 2 * N) : B6 + (j - 3 * N);
+        if (g < G_LDR0) {
+            const int e = (g - G_REQ0) / N, l = (g - G_REQ0) % N;
+            if (j == 0) return B2 + e * N + l;
+            return B7 + (l * (N - 1) + (j - 1)) * (E + 1) + e;
+        }
+        const int l = g - G_LDR0;
+        if (j < N) return B3 + l * N + j;
+        j -= N;
+        if (j < N - 1) return B4 + l * (N - 1) + j;
+        j -= N - 1;
+        if (j < N - 1) return B8 + l * (N - 1) + j;
+        j -= N - 1;
+        return B9 + l * (N - 1) + j;
+    }
+    static constexpr int group_of(int i) {
+        for (int g = 0; g < NGROUPS; ++g)
+            for (int j = 0; j < group_size(g); ++j)
+                if (group_inst(g, j) == i) return g;
+        return -1;
+    }
+    static constexpr bool groups_partition_the_instances() {
+        int total = 0;
+        for (int g = 0; g < NGROUPS; ++g) total += group_size(g);
+        if (total != NINST) return false;
+        for (int i = 0; i < NINST; ++i)
+            if (group_of(i) < 0) return false;
+        return true;
+    }
+    template <int G> static KMC_DEV u32 group_pre(const Pre& p) {
+        if constexpr (G == 0) {
+            return 1u;
+        } else if constexpr (G < G_LDR0) {
+            constexpr int e = (G - G_REQ0) / N, l = (G - G_REQ0) % N;
+            return (p.rldr1(e) == (u32)(l + 1) && (u32)e < p.nextEp()) ? 1u : 0u;
+        } else {
+            return kmc_bit(p.pm, G - G_LDR0);
+        }
+    }
     template <int K> static KMC_DEV u32 guard(const Pre& p, const u64* s, u32 b) {
         if constexpr (K == 0) {
             // ControllerElectLeader (KafkaReplication.tla:176-179)
@@ -2215,6 +2281,9 @@ template <class M> struct KmcSink {
             // the (P-1)/P that belong elsewhere travel
             const u32 dst = valid ? kmc_owner(fp, a.nshards) : ~0u;
             const bool isnew = dst == a.shard && claim_any(a, t, fp, meta);
+#if KMC_SYMM
+            out.corr_won += isnew ? KmcSymm<M>::deficit(stab) : 0u;   // (remote successors are weighed where they are claimed: k_insert)
+#endif
             out.push(a, isnew, t, stab);
             // bucket the rest by owner: one wave-aggregated atomicAdd per destination present in this batch
             const u32 sub = blockIdx.x % KMC_SEGS;
@@ -2477,6 +2546,32 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
         for (int h = 0; h < 2 * NW; ++h) en32[h] = 0;
         const u32 valid01 = valid ? 1u : 0u;
         u32 nsucc = 0;
+        if constexpr (M::GROUPED_GUARDS) {
+        // (wide configurations) group by group: a group's guards are evaluated only if its necessary condition holds in some
+        // lane of the tile — a scalar branch on a ballot; the blocks between the branches are what the scheduler sees at a time
+        static_assert(M::groups_partition_the_instances(), "guard groups must list every action instance exactly once");
+        kmc_static_for<0, M::NGROUPS>([&](auto GG) {
+            constexpr int g = decltype(GG)::value;
+            const u32 c = M::template group_pre<g>(pre) & valid01;
+            if (g == 0 || __ballot(c != 0u)) {
+                // (opaque redefinition of the state words: a group extracts the fields it reads itself — shared with the
+                // other groups, the seventy fields of seven replicas stayed in registers across the whole of pass 1)
+#pragma unroll
+                for (int q2 = 0; q2 < W; ++q2) kmc_launder(s[q2]);
+                kmc_static_for<0, M::group_size(g)>([&](auto JJ) {
+                    constexpr int i = M::group_inst(g, decltype(JJ)::value);
+                    u64 tt[W];
+                    int kd;
+                    u32 ex;
+                    const u32 g01 = M::template inst<i>(pre, s, tt, kd, ex) & valid01;
+                    en32[i >> 5] |= g01 << (i & 31);
+                    kmc_launder(en32[i >> 5]);
+                });
+            }
+        });
+#pragma unroll
+        for (int h = 0; h < 2 * NW; ++h) nsucc += __popc(en32[h]);
+        } else
         if constexpr (!M::RUNTIME_GUARDS) {   // (the wide Kafka configurations evaluate their guards per kind, in pass 2's walk)
         kmc_static_for<0, M::NINST>([&](auto I) {
             constexpr int i = decltype(I)::value;

@@ -234,10 +234,13 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
                                "L*bits(record)<=64, E<=7 (AsyncIsr: N<=6, MaxVersion<=7)", cfg.model, cfg.n_replicas, cfg.log_size,
                     cfg.max_records, cfg.max_leader_epoch, cfg.n_log_records);
     *kname = name;
-    if (cfg.symmetry && (!kmc_model_symmetric(cfg.model) || cfg.n_replicas > KMC_SYMMETRY_MAX_REPLICAS || cfg.n_shards > 1))
-        return fail(KMC_E_ARG, "symmetry (orbit counting) is for the Kafka family and FiniteReplicatedLog with at most 7 replicas "
-                               "on one GPU: %s singles out a replica, or N = %d > %d, or n_shards = %d > 1",
-                    MODEL_NAMES[cfg.model], cfg.n_replicas, KMC_SYMMETRY_MAX_REPLICAS, cfg.n_shards);
+    if (cfg.symmetry && (!kmc_model_symmetric(cfg.model) || cfg.n_replicas > KMC_SYMMETRY_MAX_REPLICAS))
+        return fail(KMC_E_ARG, "symmetry (orbit counting) is for the Kafka family and FiniteReplicatedLog with at most 7 replicas: "
+                               "%s singles out a replica, or N = %d > %d",
+                    MODEL_NAMES[cfg.model], cfg.n_replicas, KMC_SYMMETRY_MAX_REPLICAS);
+    if (cfg.symmetry && cfg.n_shards > 1 && cfg.keep_trace)
+        return fail(KMC_E_ARG, "symmetry (orbit counting) across shards keeps no traces: a chain of representatives' predecessors "
+                               "is walked on one GPU only (kmc_trace); run the counterexample's configuration on one shard");
     // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_MIN_WAVES=5 -DKMC_PROFILE=1"
     std::vector<std::string> defines;
     std::string defines_key;
@@ -1853,7 +1856,6 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
 // ---- level-step interface ---------------------------------------------------------------
 int kmc_step_begin(kmc_handle* h) {
     if (!h) return fail(KMC_E_ARG, "null handle");
-    if (h->cfg.symmetry) return fail(KMC_E_STATE, "symmetry (orbit counting) runs through kmc_run; the level-step interface does not weigh its counts");
     if (!h->table) return fail(KMC_E_STATE, "host-only handle (device = -1) cannot run");
     HIP_TRY(hipSetDevice(h->cfg.device));
     int rc = do_begin(h);
@@ -1951,39 +1953,47 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
     uint64_t new_seg[KMC_SEGS];
     const uint64_t produced = produced_segments(h, c, new_seg);
     kmc_result& r = h->res;
+    // kmc_config.symmetry: every count of this shard is weighed as book_level / absorb weigh kmc_run's — N! x the stored
+    // states' count less the summed deficits of their orbits (KmcLevelCtl::corr_*).  A state is weighed where it is CLAIMED
+    // (its owner: corr_won of k_expand's local path or of k_insert), an expansion where it is EXPANDED (this shard), so the
+    // sums over the shards are the plain search's numbers.
+    uint64_t gen_w[KMC_MAX_KINDS];
     for (int k = 0; k < KMC_MAX_KINDS; ++k) {
-        r.generated += c.generated[k];
-        r.action_generated[k] += c.generated[k];
+        gen_w[k] = weighted(h, c.generated[k], c.corr_gen[k]);
+        r.generated += gen_w[k];
+        r.action_generated[k] += gen_w[k];
     }
-    r.generated_repeats += c.repeats;
-    r.deadlock_states += c.deadlock_count;
+    r.generated_repeats += weighted(h, c.repeats, c.corr_repeats);
+    const uint64_t dead_w = weighted(h, c.deadlock_count, c.corr_dead);
+    r.deadlock_states += dead_w;
+    const uint64_t produced_w = weighted(h, produced, c.corr_won);
     h->cur = nxt;
     h->n_cur = produced;
     for (int sg = 0; sg < KMC_SEGS; ++sg) { h->prev_seg_n[sg] = h->seg_n[sg]; h->seg_n[sg] = new_seg[sg]; }
     h->level++;
     if (produced) r.depth = h->level;
-    r.distinct += produced;
+    r.distinct += produced_w;
     r.orbit_representatives += produced;
-    h->levels.push_back(produced);
+    h->levels.push_back(produced_w);
     h->step_expanded = false;
     r.seconds_total = now_s() - h->t_start;
     if (info) {
         memset(info, 0, sizeof *info);
         info->depth = h->level;
-        info->new_states = produced;
+        info->new_states = produced_w;   // (symmetry: the states of the level as the plain search counts them; 0 iff none stored)
         info->generated_total = r.generated;
         info->distinct_total = r.distinct;
         info->seconds = r.seconds_total;
-        for (int k = 0; k < KMC_MAX_KINDS; ++k) info->generated_level[k] = c.generated[k];
+        for (int k = 0; k < KMC_MAX_KINDS; ++k) info->generated_level[k] = gen_w[k];
         for (int k = 0; k < 4; ++k) {
-            info->violation_count[k] = c.viol_count[k];
+            info->violation_count[k] = weighted(h, c.viol_count[k], c.corr_viol[k]);
             info->violation_fp[k] = c.viol_count[k] ? ~c.viol_fp_inv[k] : 0;
         }
         for (int k = 0; k < 4; ++k) {
             info->outside_violation_count[k] = c.oviol_count[k];
             info->outside_violation_fp[k] = c.oviol_count[k] ? ~c.oviol_fp_inv[k] : 0;
         }
-        info->deadlocks_level = c.deadlock_count;
+        info->deadlocks_level = dead_w;
         info->send_filtered = c.send_filtered;
         info->error_flags = c.err;
     }
@@ -2585,7 +2595,7 @@ int kmc_step_check_frontier(kmc_handle* h, kmc_level_info* info) {
     HIP_TRY(hipSetDevice(h->cfg.device));
     memset(info, 0, sizeof *info);
     info->depth = h->level;
-    info->new_states = h->n_cur;
+    info->new_states = queue_now(h);
     if (h->n_cur == 0 || h->cfg.invariant_mask == 0) return KMC_OK;
     int rc = zero_ctl(h, 2);
     if (rc) return rc;
@@ -2596,7 +2606,7 @@ int kmc_step_check_frontier(kmc_handle* h, kmc_level_info* info) {
     if ((rc = launch(h, h->f_expand, d, expand_grid(h, h->n_cur)))) return rc;
     if ((rc = read_ctl(h, 2))) return rc;
     for (int k = 0; k < 4; ++k) {
-        info->violation_count[k] = h->ctl_host->viol_count[k];
+        info->violation_count[k] = weighted(h, h->ctl_host->viol_count[k], h->ctl_host->corr_viol[k]);
         info->violation_fp[k] = h->ctl_host->viol_count[k] ? ~h->ctl_host->viol_fp_inv[k] : 0;
     }
     return KMC_OK;

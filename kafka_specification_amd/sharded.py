@@ -612,6 +612,8 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
         outside = viol_depth > len(levels)   # a witness outside the state constraint: in no shard's table
         trace = _sharded_trace(engines, exchange, inv_names.index(viol_inv), action_names, outside)
     local = [e.result() for e in engines]
+    tail = exchange.all_reduce_sum([np.array([sum(r.generated_repeats for r in local),
+                                              sum(r.orbit_representatives for r in local)], dtype=np.int64)])
     run_sharded.last_send_filtered = filtered  # observability for tests / bench
     return CheckResult(
         generated=generated, distinct=sum(levels), depth=len(levels),
@@ -622,7 +624,10 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
         seconds_total=time.perf_counter() - t0, seconds_expand=max(r.seconds_expand for r in local),
         expand_launches=max(r.expand_launches for r in local), state_words=local[0].state_words,
         state_bits=local[0].state_bits, trace=trace,
-        generated_repeats=int(exchange.all_reduce_sum([np.array([sum(r.generated_repeats for r in local)], dtype=np.int64)])[0]))
+        generated_repeats=int(tail[0]),
+        # CheckerConfig.symmetry: every shard weighs its own counts (kmc_step_finish: N! x stored - deficits), so the sums
+        # above are the plain search's numbers; what the shards actually stored and expanded, summed:
+        orbit_representatives=int(tail[1]))
 
 
 def _split64(x):

@@ -5,7 +5,7 @@ concurrent rank: each thread drives its own HipShardEngine through sharded.run_s
 rank does; only the transport under the nccl* calls is the stand-in (tests/mock_rccl.cpp).  Checked against the C oracle.
 Run by tests/test_gpu_native_exchange_threads.py in a fresh process (the engine binds "RCCL" once per process).
 
-usage: native_exchange_threads.py MODEL N L R E P inv1,inv2 [trace] [levels=K] [pipeline=PARTS]   -> one JSON line, exit code 0 when everything agrees
+usage: native_exchange_threads.py MODEL N L R E P inv1,inv2 [trace] [levels=K] [pipeline=PARTS] [symmetry] [golden=FILE] [table=LOG2] [frontier=LOG2] [send=LOG2]   -> one JSON line, exit code 0 when everything agrees
 (levels=K: stop after K BFS levels and compare with the oracle's prefix — for constants nothing can exhaust;
  pipeline=PARTS: every level runs as a pipeline of PARTS parts, kmc_step_level_parts, instead of in one shot)"""
 import ctypes as C
@@ -74,7 +74,21 @@ def main():
     inv = tuple(x for x in sys.argv[7].split(",") if x)
     trace = "trace" in sys.argv[8:]
     K = next((int(a[7:]) for a in sys.argv[8:] if a.startswith("levels=")), 0)
-    if K:   # a prefix: the oracle stops after the level that crosses max_states; o2 stops right after producing level K
+    opt = lambda name, dflt: next((int(a[len(name) + 1:]) for a in sys.argv[8:] if a.startswith(name + "=")), dflt)
+    symmetry = "symmetry" in sys.argv[8:]      # orbit counting on every rank (kmc_step_finish weighs, run_sharded sums)
+    golden = next((a[7:] for a in sys.argv[8:] if a.startswith("golden=")), None)   # an Oracle-O fixture instead of a live oracle run
+    if golden:
+        g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", golden)))
+        assert (g["model"], g["N"], g["L"], g["R"], g["E"]) == (model, N, L, R, E) and K and len(g["levels"]) >= K
+
+        class _G:   # the two views the comparison below reads: o.levels (prefix), o2.generated / action_generated (after K levels)
+            levels = g["levels"] + [0]
+            generated = g["generated"]
+            action_generated = g["action_generated"]
+            viol_inv = None
+        assert len(g["levels"]) == K, "the fixture's generated counts belong to exactly its own number of levels"
+        o = o2 = _G
+    elif K:   # a prefix: the oracle stops after the level that crosses max_states; o2 stops right after producing level K
         o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv, threads=8, max_states=1_500_000))
         assert len(o.levels) > K
         o2 = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv, threads=8, max_states=sum(o.levels[:K - 1]) + 1))
@@ -84,8 +98,9 @@ def main():
     consts = dict(n_replicas=N, log_size=L, max_leader_epoch=E)      # AsyncIsr: (N, MaxOffset, MaxVersion); R is unused
     if model != "AsyncIsr":
         consts["max_records"] = R
-    cfg = CheckerConfig(model=model, **consts, invariants=inv, keep_trace=trace, table_capacity=1 << (22 if K else 20),
-                        frontier_capacity=1 << (20 if K else 18), send_capacity=1 << 16, max_levels=K)
+    cfg = CheckerConfig(model=model, **consts, invariants=inv, keep_trace=trace, table_capacity=1 << opt("table", 22 if K else 20),
+                        frontier_capacity=1 << opt("frontier", 20 if K else 18), send_capacity=1 << opt("send", 16), max_levels=K,
+                        symmetry=symmetry)
     lib = nat.lib()
     uid = (C.c_uint8 * nat.KMC_COMM_ID_BYTES)()
     nat.check(lib.kmc_comm_unique_id(uid))          # main thread: also the one-time binding of "librccl"
@@ -106,7 +121,7 @@ def main():
     for t in threads:
         t.start()
     for t in threads:
-        t.join(150 if K else 90)
+        t.join(300 if K else 90)
     hung = [r for r, t in enumerate(threads) if t.is_alive()]
     out = dict(model=model, N=N, L=L, R=R, E=E, P=P, trace=trace, errors=errors, hung=hung)
     ok = not hung and not any(errors)
@@ -125,6 +140,12 @@ def main():
         if o.viol_inv and not K:
             matches = matches and r0.violation_depth == o.viol_depth and r0.violation_count == o.viol_count
         out["pipelined_levels"] = _parts and min(getattr(ex, "pipelined_levels", 0) for ex in exchanges)
+        if symmetry:
+            out["stored"] = r0.orbit_representatives
+            if golden:
+                matches = matches and r0.orbit_representatives == g["stored"] and r0.deadlock_states == g["deadlock_states"]
+            else:
+                matches = matches and 0 < r0.orbit_representatives < max(r0.distinct, 2)
         out.update(verdict=r0.verdict, distinct=r0.distinct, generated=r0.generated, depth=r0.depth,
                    same_on_every_rank=same_everywhere, matches_oracle=matches,
                    exchange=type(engines[0]).__name__ + " + ThreadRcclExchange over " + os.path.basename(os.environ["KMC_RCCL_LIB"]))

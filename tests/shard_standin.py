@@ -42,7 +42,27 @@ class OracleShardEngine:
         self._viol_fp = [0, 0, 0, 0]
         self._oviol_fp = [0, 0, 0, 0]
         self.retired = []                                             # the level the last finish() retired
+        # CheckerConfig.symmetry: this stand-in weighs as kmc_step_finish does — only orbit representatives are kept, shipped
+        # and expanded; what a state's expansion counts is multiplied by its orbit's size N!/|Stab|, a new state counts its
+        # orbit's size where it is admitted (its owner).  Representative and stabiliser come from the product's HOST-ONLY
+        # handle (kmc_canonical_state needs no device); the successor function stays the oracle's.
+        self.sym = bool(getattr(cfg, "symmetry", False))
+        self.next_weight = 0
+        self.weight = {}                                              # stored state -> its orbit's size
+        if self.sym:
+            import math
+            from dataclasses import replace
+            from kafka_specification_amd import ModelChecker
+            self.nfact = math.factorial(cfg.n_replicas)
+            self._mc = ModelChecker(replace(cfg, device=-1, symmetry=False, n_shards=1, shard_id=0))
         self.reset_level()
+
+    def _canon(self, s: bytes):
+        """-> (representative of s's orbit as canonical bytes, the orbit's size)"""
+        if not self.sym:
+            return s, 1
+        stab, rep = self._mc.canonical(self._mc.pack(s))
+        return self._mc.unpack(rep), self.nfact // stab
 
     def reset_level(self):
         self.st = np.zeros(N_STATS, dtype=np.int64)
@@ -78,12 +98,17 @@ class OracleShardEngine:
             return
         self.seen[s] = pred
         self.next.append(s)
+        w = self._canon(s)[1]
+        self.weight[s] = w
+        self.next_weight += w
 
     def begin(self):
         self.seen, self.frontier, self.next = {}, [], []   # like kmc_step_begin: a fresh search
         self.reset_level()
-        if self.owner(self.fp(self.init)) == self.rank:
-            self._admit(self.init, 0)
+        self.weight, self.next_weight = {}, 0
+        init = self._canon(self.init)[0]
+        if self.owner(self.fp(init)) == self.rank:
+            self._admit(init, 0)
             self.st[16] = 1
         return self._close_level()
 
@@ -94,16 +119,18 @@ class OracleShardEngine:
         buckets = [[] for _ in range(self.world)]
         for s in self.frontier:
             fps = self.fp(s)
+            w = self.weight.get(s, 1)     # everything this expansion counts stands for the whole orbit of s
             for name in self.cfg.invariants:  # like the GPU engine: a state is checked when it is expanded
                 if not kmo.check_invariant(self.kcfg, INV_INDEX[name], s):
                     k = INV_INDEX[name]
-                    self.st[17 + k] += 1
+                    self.st[17 + k] += w
                     viol[k] = fps if viol[k] == 0 else min(viol[k], fps)
             succ = kmo.successors(self.kcfg, s, self.sb)
             if not succ:
-                self.st[21] += 1
+                self.st[21] += w
             for a, t in succ:
-                self.st[1 + a] += 1
+                self.st[1 + a] += w
+                t = self._canon(t)[0]     # (symmetry) successors travel as representatives
                 if self.cfg.model == "AsyncIsr" and (t[6] > self.cfg.log_size or t[1] > self.cfg.max_leader_epoch):
                     # outside the state constraint: invariant-checked, neither kept nor shipped
                     for name in self.cfg.invariants:
@@ -153,7 +180,7 @@ class OracleShardEngine:
             for name in self.cfg.invariants:
                 if not kmo.check_invariant(self.kcfg, INV_INDEX[name], s):
                     k = INV_INDEX[name]
-                    st[17 + k] += 1
+                    st[17 + k] += self.weight.get(s, 1)
                     viol[k] = self.fp(s) if viol[k] == 0 else min(viol[k], self.fp(s))
         self._viol_fp = viol
         return st
@@ -171,12 +198,14 @@ class OracleShardEngine:
 
     def _close_level(self):
         self.frontier, self.next = self.next, []
-        self.st[0] = len(self.frontier)
+        self.st[0] = self.next_weight if self.sym else len(self.frontier)
+        self.next_weight = 0
         return self.st
 
     def result(self):
         from kafka_specification_amd.checker import CheckResult
-        return CheckResult(0, len(self.seen), 0, 0, "ok", None, 0, {}, 0, 0, {}, [], 0, 0, 0.0, 0.0, 0, self.words, 0)
+        return CheckResult(0, len(self.seen), 0, 0, "ok", None, 0, {}, 0, 0, {}, [], 0, 0, 0.0, 0.0, 0, self.words, 0,
+                           orbit_representatives=len(self.seen))
 
     # -- trace hooks -----------------------------------------------------------------------------
     def violation_fp(self, k):

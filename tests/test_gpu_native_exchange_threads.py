@@ -28,7 +28,7 @@ def _build_mock():
 def _run(*args):
     _build_mock()
     p = subprocess.run([sys.executable, os.path.join(HERE, "native_exchange_threads.py"), *map(str, args)],
-                       capture_output=True, text=True, timeout=240)
+                       capture_output=True, text=True, timeout=400)
     line = next((l for l in p.stdout.splitlines() if l.startswith("RESULT ")), None)
     assert line, (p.stdout[-800:], p.stderr[-1500:])
     out = json.loads(line[7:])
@@ -86,3 +86,31 @@ def test_pipelined_levels_with_traces_a_violation_and_the_sender_side_filter():
 def test_pipelined_levels_on_config5_with_eight_ranks():
     out = _run("Kip320", 7, 8, 8, 3, 8, "TypeOk", "trace", "levels=7", "pipeline=4")
     assert out["matches_oracle"] and out["same_on_every_rank"] and out["verdict"] == "level_limit"
+
+
+# ---- round 4: orbit counting (CheckerConfig.symmetry) through the level-step interface and the exchange under the ABI ----------
+@pytest.mark.parametrize("P", [2, 3, 8])
+@pytest.mark.parametrize("model,N,L,R,E,inv", [("Kip320", 3, 2, 2, 1, "TypeOk,WeakIsr,StrongIsr"), ("Kip279", 4, 1, 1, 1, "TypeOk"),
+                                               ("Kip101", 3, 2, 2, 2, "TypeOk,StrongIsr")])
+def test_orbit_counting_across_concurrent_ranks_reports_the_plain_oracles_numbers(P, model, N, L, R, E, inv):
+    """Every rank stores and expands orbit representatives only and weighs its own counters (kmc_step_finish: N! x stored
+    less the orbits' deficits); the sums over the ranks are the PLAIN oracle's levels, generated, deadlocks, verdict, violation
+    depth and counts."""
+    out = _run(model, N, L, R, E, P, inv, "symmetry")
+    assert out["matches_oracle"] and out["same_on_every_rank"] and out["stored"] < out["distinct"]
+
+
+def test_orbit_counting_pipelined_levels():
+    out = _run("Kip320", 3, 2, 2, 1, 4, "TypeOk,WeakIsr,StrongIsr", "symmetry", "pipeline=4")
+    assert out["matches_oracle"] and out["same_on_every_rank"] and out["pipelined_levels"] >= 10
+
+
+def test_baseline_config5_with_orbit_counting_on_eight_ranks_equals_the_orbit_oracle_over_14_levels():
+    """BASELINE config 5 (Kip320, 7 brokers, LogSize 8) is specified on 8 GPUs and its plain search stalls at level 11 on any
+    hardware: with orbit counting through the exchange, 8 concurrent ranks reach level 14 — 50,390,682,994 states from
+    18,908,685 stored ones — and report Oracle-O's numbers (tests/golden/orbit_kip320_7_8_8_3_levels14.json: exact level
+    sizes, generated per action, deadlocks, stored states), identically on every rank."""
+    out = _run("Kip320", 7, 8, 8, 3, 8, "TypeOk", "symmetry", "levels=14", "golden=orbit_kip320_7_8_8_3_levels14.json",
+               "table=23", "frontier=22", "send=18")
+    assert out["matches_oracle"] and out["same_on_every_rank"] and out["verdict"] == "level_limit"
+    assert out["distinct"] == 50390682994 and out["stored"] == 18908685

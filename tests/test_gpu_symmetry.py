@@ -333,3 +333,69 @@ def test_baseline_config5_deep_levels_against_the_orbit_counting_oracle(depth):
         pytest.xfail(f"generated is {res.generated - g['generated']} = k * 2^32 too large: a 32-bit deficit sum still wraps")
     assert res.generated == g["generated"]
     assert list(res.action_generated.values()) == g["action_generated"][:len(res.action_generated)]
+
+
+# ---- round 4: orbit counting through the level-step interface (logical shards on one GPU; thread-ranks: test_gpu_native_exchange_threads.py) ----
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
+@pytest.mark.parametrize("model,N,L,R,E,inv", [("Kip320", 3, 2, 2, 1, ("TypeOk", "WeakIsr", "StrongIsr")),
+                                               ("Kip279", 3, 2, 2, 2, ("TypeOk", "StrongIsr")),
+                                               ("KafkaTruncateToHighWatermark", 4, 1, 1, 1, ("TypeOk",)),
+                                               ("Kip320FirstTry", 3, 2, 2, 1, ("TypeOk", "WeakIsr"))])
+def test_orbit_counting_on_logical_shards_reports_the_plain_oracles_numbers(P, model, N, L, R, E, inv):
+    """kmc_step_finish weighs this shard's counters (N! x stored less the orbits' deficits: the states it CLAIMED, the
+    expansions it RAN), sharded.run_sharded sums the shards: levels, generated per action, deadlocks, verdict, violation depth
+    and counts of the plain search — here against the C oracle, with and without a violation."""
+    import kmo
+    from kafka_specification_amd.sharded import check_loopback
+    o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv))
+    cfg = CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, invariants=inv, symmetry=True,
+                        table_capacity=1 << 18, frontier_capacity=1 << 16, send_capacity=1 << 14)
+    r = check_loopback(cfg, P)
+    assert (r.verdict, r.violated_invariant) == (o.verdict, o.viol_inv)
+    if o.verdict == "ok":
+        assert (r.distinct, r.generated, r.depth, r.levels) == (o.distinct, o.generated, o.depth, o.levels)
+        assert list(r.action_generated.values()) == o.action_generated[:len(r.action_generated)]
+        assert r.deadlock_states == o.deadlock_states
+        from dataclasses import replace
+        with ModelChecker(replace(cfg, send_capacity=0)) as mc:    # one GPU, kmc_run: the same orbits
+            one = mc.run()
+        assert r.orbit_representatives == one.orbit_representatives < o.distinct
+        assert r.generated_repeats == one.generated_repeats
+    else:
+        assert r.violation_depth == o.viol_depth and r.violation_count == o.viol_count
+
+
+def test_orbit_counting_on_shards_under_a_level_budget_checks_the_last_frontier():
+    import kmo
+    from kafka_specification_amd.sharded import check_loopback
+    inv = ("TypeOk", "WeakIsr", "StrongIsr")
+    o = kmo.Run(kmo.make_config("Kip101", N=3, L=2, R=2, E=2, invariants=inv))
+    assert o.verdict == "invariant"
+    cfg = CheckerConfig(model="Kip101", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=2, invariants=inv, symmetry=True,
+                        max_levels=o.viol_depth, table_capacity=1 << 18, frontier_capacity=1 << 16, send_capacity=1 << 14)
+    r = check_loopback(cfg, 3)      # the violating level is the LAST one: found by the invariant-only pass, weighed
+    assert (r.verdict, r.violated_invariant, r.violation_depth, r.violation_count) == ("invariant", o.viol_inv, o.viol_depth, o.viol_count)
+
+
+def test_orbit_counting_across_shards_refuses_traces():
+    from kafka_specification_amd import KmcError
+    from kafka_specification_amd.sharded import check_loopback
+    cfg = CheckerConfig(model="Kip101", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=2, invariants=("StrongIsr",),
+                        symmetry=True, keep_trace=True, table_capacity=1 << 18, frontier_capacity=1 << 16)
+    with pytest.raises(KmcError, match="keeps no traces"):
+        check_loopback(cfg, 2)
+
+
+def test_baseline_config5_with_orbit_counting_on_eight_logical_shards_equals_the_orbit_oracle():
+    """BASELINE config 5 (7 brokers, LogSize 8; specified on 8 GPUs) with orbit counting through the exchange under the ABI on
+    P = 8 logical shards: 14 levels = 50,390,682,994 states from 18,908,685 stored ones, every number Oracle-O's
+    (tests/golden/orbit_kip320_7_8_8_3_levels14.json)."""
+    from kafka_specification_amd.sharded import check_loopback
+    g = json.load(open(os.path.join(GOLDEN, "orbit_kip320_7_8_8_3_levels14.json")))
+    cfg = CheckerConfig(model="Kip320", n_replicas=7, log_size=8, max_records=8, max_leader_epoch=3, invariants=("TypeOk",),
+                        symmetry=True, max_levels=14, table_capacity=1 << 23, frontier_capacity=1 << 22, send_capacity=1 << 18)
+    r = check_loopback(cfg, 8)
+    assert r.verdict == "level_limit" and r.levels == g["levels"] and r.distinct == g["distinct"] == 50390682994
+    assert r.generated == g["generated"] and r.deadlock_states == g["deadlock_states"]
+    assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
+    assert r.orbit_representatives == g["stored"] == 18908685

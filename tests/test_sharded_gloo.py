@@ -39,7 +39,7 @@ def _worker(rank, world, port, cfg_kw, out, round_bytes=None):
         out[rank] = dict(distinct=r.distinct, generated=r.generated, depth=r.depth, levels=r.levels, verdict=r.verdict,
                          viol=r.violated_invariant, viol_depth=r.violation_depth, viol_count=r.violation_count,
                          deadlocks=r.deadlock_states, actions=list(r.action_generated.values()),
-                         local_seen=len(eng.seen), trace=[(a, bytes(b)) for a, b in r.trace])
+                         local_seen=len(eng.seen), trace=[(a, bytes(b)) for a, b in r.trace], stored=r.orbit_representatives)
     finally:
         dist.destroy_process_group()
 
@@ -236,3 +236,32 @@ def test_sharded_checkpoint_and_recover(tmp_path):
     assert (r["verdict"], r["distinct"], r["generated"], r["depth"], r["levels"]) == \
         ("ok", o.distinct, o.generated, o.depth, o.levels)
     assert r["deadlocks"] == o.deadlock_states and r["actions"] == o.action_generated[:len(r["actions"])]
+
+
+@pytest.mark.parametrize("model,N,L,R,E,inv", [("Kip320", 3, 2, 2, 1, ("TypeOk", "WeakIsr", "StrongIsr")),
+                                               ("Kip101", 3, 2, 2, 1, ("TypeOk", "WeakIsr")),
+                                               ("Kip279", 4, 1, 1, 1, ("TypeOk",))])
+def test_two_rank_gloo_with_orbit_counting_reports_the_plain_searchs_numbers(model, N, L, R, E, inv):
+    """CheckerConfig.symmetry across shards (round 4: kmc_step_finish weighs its counters — N! x stored less the orbits'
+    deficits — and run_sharded sums the shards' weighted numbers): two gloo ranks whose stand-in engines weigh the same way
+    (tests/shard_standin.py: representatives and stabilisers from the product's host-only kmc_canonical_state, successors
+    from the oracle) report what the plain oracle reports, from about 1/N! of the stored states — the count Oracle-O stores."""
+    import json
+    import subprocess
+    kw = dict(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, invariants=inv, symmetry=True)
+    out = _run_world(kw, world=2)
+    o = kmo.Run(kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv))
+    assert out[0] == {**out[1], "local_seen": out[0]["local_seen"]}
+    r = out[0]
+    assert r["verdict"] == o.verdict and r["viol"] == o.viol_inv
+    if o.verdict == "ok":
+        assert r["levels"] == o.levels and r["distinct"] == o.distinct and r["generated"] == o.generated
+        assert r["depth"] == o.depth and r["deadlocks"] == o.deadlock_states
+        assert r["actions"] == o.action_generated[:len(r["actions"])]
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        oo = json.loads(subprocess.run([os.path.join(root, "oracle", "orbit_oracle"), "--model", model, "--N", str(N), "--L", str(L),
+                                        "--R", str(R), "--E", str(E), "--threads", "2", "--table-log2", "20"],
+                                       capture_output=True, text=True, check=True).stdout)
+        assert r["stored"] == oo["stored"] == out[0]["local_seen"] + out[1]["local_seen"] and r["stored"] < o.distinct
+    else:
+        assert r["viol_depth"] == o.viol_depth and r["viol_count"] == o.viol_count
