@@ -191,18 +191,22 @@ def cold_start(c):
         return None
     out = {"command": "kafka_specification_amd/tlc models/%s.tla -table %d -frontier %d [-notrace]" % (c["model"], 1 << 30, 1 << 26)}
     for key, extra in (("wall_s", []), ("wall_s_notrace", ["-notrace"])):
-        t0 = time.perf_counter()
-        try:
-            p = subprocess.run([exe, spec, "-table", str(1 << 30), "-frontier", str(1 << 26)] + extra, capture_output=True,
-                               text=True, timeout=300)
-        except Exception as e:   # the bench line does not depend on it
-            out[key] = None
-            out["error"] = str(e)[:120]
-            continue
-        out[key] = time.perf_counter() - t0
-        m = re.search(r"(\d+) states generated, (\d+) distinct states found", p.stdout)
-        out["distinct_states" if key == "wall_s" else "distinct_states_notrace"] = int(m.group(2)) if m else None
-        out["exit_code"] = p.returncode
+        best, found = None, None
+        for _attempt in range(2):   # a fresh process each time; the smaller of two (the first also pages the binaries in)
+            t0 = time.perf_counter()
+            try:
+                p = subprocess.run([exe, spec, "-table", str(1 << 30), "-frontier", str(1 << 26)] + extra, capture_output=True,
+                                   text=True, timeout=300)
+            except Exception as e:   # the bench line does not depend on it
+                out["error"] = str(e)[:120]
+                break
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            m = re.findall(r"(\d+) states generated, (\d+) distinct states found, (\d+) states left on queue", p.stdout)
+            found = int(m[-1][1]) if m else None      # the closing line, not a progress line
+            out["exit_code"] = p.returncode
+        out[key] = best
+        out["distinct_states" if key == "wall_s" else "distinct_states_notrace"] = found
     return out
 
 
@@ -423,7 +427,7 @@ def main():
     }
     if (world == 1 and not a.symmetry and not a.no_orbit_counting and not a.level_budget and c["n_replicas"] <= KMC_SYMMETRY_MAX_REPLICAS
             and r.verdict == "ok"):
-        # The same check with symmetry reduction by orbit counting (kmc_config.symmetry, DESIGN.md section 10): one stored
+        # The same check with symmetry reduction by orbit counting (kmc_config.symmetry, DESIGN.md section 8): one stored
         # state per orbit of the permutations of Replicas, every count weighted by the orbit's size.  It must report the
         # plain run's numbers — compared here, count by count and level by level — and is timed the same way; it is NOT
         # `value` (SURVEY rules TLC's SYMMETRY out because it changes the counts; this one does not, but it is another search).

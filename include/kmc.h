@@ -223,7 +223,9 @@ int kmc_canonical_state(kmc_handle* h, const uint64_t* words, uint64_t* represen
 /* Copy the current frontier (the last completed level) to the host as packed AoS records. */
 int kmc_frontier_states(kmc_handle* h, uint64_t* words, uint64_t cap_states, uint64_t* n_out);
 /* All successors of one packed state, straight from the device kernels: writes up to cap
- * records of (state_words + 2) uint64: state, fingerprint, action kind. */
+ * records of (state_words + 2) uint64: state, fingerprint, action kind — TLC's enumeration of Next on that state: one
+ * record per satisfying binding AND disjunct (a successor that two disjuncts of one binding yield, Kip279.tla:47-51 /
+ * Kip320.tla:82-83, is listed twice, as `generated` counts it). */
 int kmc_successors(kmc_handle* h, const uint64_t* words, uint64_t* out, uint64_t cap, uint64_t* n_out);
 /* The invariants (KMC_INV_* bits of `mask`, whatever cfg->invariant_mask says) each of n packed states violates, from
  * the device's own predicate — the one k_expand applies to the states it expands (TypeOk / WeakIsr / StrongIsr /

@@ -49,7 +49,7 @@ typedef unsigned int u32;
 
 #define KMC_MODE_LOCAL 0u    // probe/insert the local table, append winners to the next frontier
 #define KMC_MODE_SHARDED 1u  // bucket successors by owner(fp) into per-destination send buffers
-#define KMC_MODE_ENUM 2u     // write every successor (state, fp, kind) to a list: trace replay
+#define KMC_MODE_ENUM 2u     // write every successor (state, fp, kind | further bindings with this successor << 8) to a list
 #define KMC_MODE_DRY 3u      // tuning aid: generate + fingerprint successors, touch no table or frontier
 
 #define KMC_ERR_FRONTIER_FULL 1u
@@ -2672,7 +2672,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #pragma unroll
                     for (int q2 = 0; q2 < W; ++q2) q[q2 * KMC_RING + pos] = t[q2];
                     if (has_meta)
-                        q[W * KMC_RING + pos] = (a.mode == KMC_MODE_ENUM && !(a.flags & KMC_FLAG_ENUM_MATCH)) ? (u64)k : parent;
+                        q[W * KMC_RING + pos] = (a.mode == KMC_MODE_ENUM && !(a.flags & KMC_FLAG_ENUM_MATCH)) ? ((u64)k | ((u64)extra << 8)) : parent;
                 }
                 count += n;
                 if (count >= KMC_FLUSH_N) {
@@ -2749,7 +2749,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 #pragma unroll
                 for (int k = 0; k < W; ++k) q[k * KMC_RING + pos] = t[k];
                 if (has_meta)
-                    q[W * KMC_RING + pos] = (a.mode == KMC_MODE_ENUM && !(a.flags & KMC_FLAG_ENUM_MATCH)) ? (u64)kind : parent;
+                    q[W * KMC_RING + pos] = (a.mode == KMC_MODE_ENUM && !(a.flags & KMC_FLAG_ENUM_MATCH)) ? ((u64)kind | ((u64)extra << 8)) : parent;
             }
             count += __popcll(mk);
             if (count >= KMC_FLUSH_N) {

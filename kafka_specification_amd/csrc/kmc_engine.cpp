@@ -262,15 +262,18 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
     }
     std::string src = strip_for_concat(KMC_SRC_LAYOUT) + strip_for_concat(KMC_SRC_DEVICE) + "\nKMC_INSTANTIATE(" +
                       name + ", " + inst + ")\n";
-    // The PyTorch wheel bundles its own hiprtc/comgr next to the system ROCm's; both report
-    // the same hiprtcVersion, so the HIP runtime build number is part of the cache key too.
-    int rtc_major = 0, rtc_minor = 0, hip_ver = 0;
+    // ONE code object per (source, architecture, defines), whoever compiled it.  The PyTorch wheel bundles its own
+    // hiprtc / comgr next to the system ROCm's (same hiprtcVersion, different LLVM builds: from round 4's source on they emit
+    // different instructions for the same text), and a process binds to one or the other (_native.py).  Rounds 1-3 keyed the
+    // cache by the HIP runtime's build number too, so the bench (torch's runtime) and a rocprofv3 run (system ROCm) each
+    // compiled and ran their own object — a profile then described other machine code than the line it is quoted beside.
+    // A gfx950 code object loads under either runtime: the cache is keyed by what is compiled, not by who asks.
+    int rtc_major = 0, rtc_minor = 0;
     hiprtcVersion(&rtc_major, &rtc_minor);
-    hipRuntimeGetVersion(&hip_ver);
     char key[64];
     snprintf(key, sizeof key, "%016llx",
              (unsigned long long)fnv1a(src + "|" + arch + "|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
-                                       "|" + std::to_string(hip_ver) + "|" + defines_key));
+                                       "|" + defines_key));
     const std::string dir = cfg.cache_dir ? std::string(cfg.cache_dir) : default_cache_dir();
     const std::string path = dir + "/" + name + "-" + arch + "-" + key + ".hsaco";
     if (path_out) *path_out = path;
@@ -605,7 +608,7 @@ int reset_run(kmc_handle* h) {
 //   what pass 2 of k_expand dispatched, less the repeats (one successor, two bindings) and the successors outside the state
 //   constraint, plus the records k_insert was handed, must be what entered the sink:  generated - repeats - outside + inserted = probed
 //   and every claim the sink won must have been appended to the next frontier:       won = sum(next_count).
-// Round 1 met a build of k_expand that LOST successors between dispatch and sink; every counter the old
+// Round 1 met a build of k_expand that LOST successors between dispatch and sink (docs/TUNING_LOG_r1-r3.md §2); every counter the old
 // self-check compared is bumped before that point.  These two are taken on either side of it.
 // kmc_config.symmetry: a device counter counts orbit representatives and comes with the summed deficits of their orbits
 // (KmcLevelCtl::corr_*): the plain search's count is N! * raw - corr.
@@ -1538,9 +1541,20 @@ int kmc_successors(kmc_handle* h, const uint64_t* words, uint64_t* out, uint64_t
     if ((rc = launch(h, h->f_expand, a, 1))) return rc;
     if ((rc = read_ctl(h, 2))) return rc;
     const uint64_t n = h->ctl_host->enum_count < h->enum_cap ? h->ctl_host->enum_count : h->enum_cap;
-    *n_out = n;
-    const uint64_t ncopy = n < cap ? n : cap;
-    if (ncopy && out) HIP_TRY(hipMemcpy(out, h->enum_out, ncopy * (h->W + 2) * 8, hipMemcpyDeviceToHost));
+    // The kind word of a record also says how many FURTHER satisfying bindings of the same disjunct yield this very successor
+    // (Kip279.tla:47-51, Kip320.tla:82-83: two disjuncts of one binding hold at once): the list handed out repeats such a
+    // record, so that it is TLC's enumeration of Next on this state — one entry per generated successor, as `generated` counts.
+    const uint64_t rw = (uint64_t)h->W + 2;
+    std::vector<uint64_t> recs(n * rw);
+    if (n) HIP_TRY(hipMemcpy(recs.data(), h->enum_out, n * rw * 8, hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t reps = 1 + (recs[i * rw + h->W + 1] >> 8);
+        recs[i * rw + h->W + 1] &= 0xFFull;
+        for (uint64_t k = 0; k < reps; ++k, ++total)
+            if (out && total < cap) memcpy(out + total * rw, &recs[i * rw], rw * 8);
+    }
+    *n_out = total;
     return KMC_OK;
 }
 

@@ -3,7 +3,7 @@
  * kmc_config.symmetry where the plain search no longer fits anybody's memory (BASELINE config 5: 7 brokers, LogSize 8).
  * TEST INFRASTRUCTURE ONLY: nothing in the product links, loads or runs it.
  *
- * It shares the IDEA with the device (one stored state per orbit, weights N!/|Stab|; DESIGN.md section 10) and nothing else:
+ * It shares the IDEA with the device (one stored state per orbit, weights N!/|Stab|; DESIGN.md section 8) and nothing else:
  *   - states are the oracle's canonical bytes, renamed by permute() below (the device renames bit fields through LDS tables);
  *   - the representative of an orbit is the lexicographically smallest BYTE STRING among the images whose replicas stand in
  *     ascending order of (end, hw, epoch, log) — all arrangements of replicas with equal keys are tried (the device sorts by a

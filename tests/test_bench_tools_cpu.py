@@ -170,3 +170,22 @@ def test_ladder_tool_configurations_are_valid_bindings():
     for name, levels in ladder.ORACLE_PREFIX.items():
         assert name in ladder.RUNS
         assert levels[:2] == [1, 2 * ladder.RUNS[name]["n_replicas"]]
+
+
+def test_one_code_object_whoever_compiles():
+    """A process under the PyTorch wheel's HIP runtime (the bench, the tests) and one on the system ROCm (KMC_NO_TORCH=1: the
+    native CLI, rocprofv3 runs) resolve a configuration to the SAME cached code object — the two toolchains emit different
+    instructions for the same source, so a profile must load what the bench loads, not compile its own (round 4)."""
+    import subprocess
+    import sys
+    prog = ("import sys; sys.path.insert(0, %r); import kafka_specification_amd as kmc; "
+            "c = kmc.CheckerConfig(model='Kip320', n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1); "
+            "print(kmc.code_object_path(c, 'gfx950')); print(kmc.kernel_code_sha256(c))" % ROOT)
+    outs = []
+    for no_torch in ("0", "1"):
+        env = dict(os.environ, KMC_NO_TORCH=no_torch)
+        env.pop("KMC_JIT_DEFINES", None)
+        p = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode == 0, p.stderr[-800:]
+        outs.append(p.stdout.strip().splitlines()[-2:])
+    assert outs[0] == outs[1]

@@ -97,7 +97,10 @@ def test_first_violation_at_the_headline_constants_matches_the_exact_orbit_oracl
     each invariant (Kip320: none — KafkaReplication.tla:320-340 hold, Kip320.tla:168-171)."""
     g = json.load(open(os.path.join(GOLDEN, fixture)))
     cfg = CheckerConfig(model=model, n_replicas=3, log_size=6, max_records=6, max_leader_epoch=2,
-                        invariants=("TypeOk", "WeakIsr", "StrongIsr"), table_capacity=1 << 28, frontier_capacity=1 << 25,
+                        invariants=("TypeOk", "WeakIsr", "StrongIsr"),
+                        # (Kip320 violates nothing: that leg runs the whole graph out, 279,753,922 states)
+                        table_capacity=1 << (30 if model == "Kip320" and not symmetry else 28),
+                        frontier_capacity=1 << (26 if model == "Kip320" and not symmetry else 25),
                         symmetry=symmetry, max_levels=0 if model == "Kip320" else 16)
     with ModelChecker(cfg) as mc:
         r = mc.run()

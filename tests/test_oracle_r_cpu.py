@@ -264,7 +264,7 @@ Small == x + y * 2 <= 4 /\\ {x, y} \\subseteq 0 .. 2
 
 
 # ------------------------------------------------------------------------------------------------
-# The premise of orbit counting (DESIGN.md section 10), checked by EXECUTING the reference's text
+# The premise of orbit counting (DESIGN.md section 8), checked by EXECUTING the reference's text
 # ------------------------------------------------------------------------------------------------
 def _rename(v, m):
     """The TLA+ value v with every model value renamed through m (functions, records, tuples, sets, nested)."""

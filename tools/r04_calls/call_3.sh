@@ -1,13 +1,13 @@
 #!/bin/bash
-# round 4, call 2b: first GPU execution of this round's new tests, then fresh rocprofv3 evidence on the final device code
+# round 4, call 3: first GPU execution of this round's new tests, then fresh rocprofv3 evidence on the final device code
 # (kmc_device.h changed: KMC_FLAG_INV_ONLY in every k_expand) for every kernel a bench line quotes.
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/r04_calls/call_2b.sh'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/r04_calls/call_3.sh'
 cd "${GRAFT_REPO_ROOT:-.}"
-O=gpurun_out/r04_2b; mkdir -p $O
+O=gpurun_out/r04_3; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_oracle_r_successors.py -q -x -n 4 > $O/t_successors.log 2>&1; tail -2 $O/t_successors.log
 timeout 900 python -m pytest tests/test_gpu_symmetry.py -q -n 4 -k "logical_shards or level_budget_checks or refuses_traces or eight_logical" > $O/t_sym_shards.log 2>&1; tail -2 $O/t_sym_shards.log
 timeout 900 python -m pytest tests/test_gpu_native_exchange_threads.py -q -n 2 -k "orbit" > $O/t_sym_threads.log 2>&1; tail -2 $O/t_sym_threads.log
-timeout 900 python -m pytest tests/test_gpu_zz_beyond_the_exact_oracle.py -q -k "exact_orbit or first_violation" > $O/t_exact.log 2>&1; tail -2 $O/t_exact.log
+timeout 900 python -m pytest tests/test_gpu_zz_beyond_the_exact_oracle.py -q -k "exact_orbit or first_violation or orbit_oracle" > $O/t_exact.log 2>&1; tail -2 $O/t_exact.log
 export KMC_NO_TORCH=1
 bash tools/profile.sh r04 > $O/profile_plain.log 2>&1; tail -1 $O/profile_plain.log
 PROFILE_BENCH_ARGS=--symmetry bash tools/profile.sh r04_sym > $O/profile_sym.log 2>&1; tail -1 $O/profile_sym.log
