@@ -315,7 +315,7 @@ def test_baseline_config5_deep_levels_against_the_orbit_counting_oracle(depth):
     """BASELINE config 5 beyond anything a plain search fits, against the orbit-counting CPU oracle (oracle/orbit_oracle.c — the
     idea of kmc_config.symmetry with states, renaming, representatives and seen-set of its own; tests/test_orbit_oracle_cpu.py
     holds it to the plain oracle).  14 levels: 50,390,682,994 states; 17 levels: 1,955,261,362,188.  Capacities and invariants
-    are those of the measured runs (profiles/r03_config5_orbit_counting.jsonl)."""
+    are those of the measured runs (profiles/r04_config5_orbit_counting.jsonl)."""
     g = json.load(open(os.path.join(GOLDEN, f"orbit_kip320_7_8_8_3_levels{depth}.json")))
     res = sym_run("Kip320", invariants=("TypeOk", "WeakIsr", "StrongIsr"), n_replicas=7, log_size=8, max_records=8,
                   max_leader_epoch=3, max_levels=depth, table_capacity=1 << 31, frontier_capacity=1 << 29)
