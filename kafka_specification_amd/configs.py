@@ -56,6 +56,9 @@ def precompile_list():
             for m in ("KafkaTruncateToHighWatermark", "Kip101", "Kip279")]
     out += [dict(model="Kip320FirstTry", n_replicas=3, log_size=2, max_records=3, max_leader_epoch=2)]
     out += [dict(model="Kip279", n_replicas=5, log_size=2, max_records=2, max_leader_epoch=2)]  # the non-exhaustible twin (prefix test)
+    # two small bindings the -m gpu suite opens (found by listing what a fresh box still had to specialise, round 4)
+    out += [dict(model="Kip320", n_replicas=2, log_size=1, max_records=1, max_leader_epoch=1),
+            dict(model="Kip320", n_replicas=3, log_size=2, max_records=3, max_leader_epoch=1)]
     # tests/golden/oracle_r_wide.json (the reference's text executed at 4-7 replicas): every Kafka module at 4/1/1/0 and 5/1/1/0,
     # Kip320 at 6/1/1/0 (4/2/1/1, 7/1/1/0 and the BASELINE bindings are above / below)
     out += [dict(model=m, n_replicas=N, log_size=1, max_records=1, max_leader_epoch=0) for m in KAFKA for N in (4, 5)]

@@ -129,3 +129,26 @@ def test_wide_table_tells_colliding_fingerprints_apart():
         del os.environ["KMC_JIT_DEFINES"]
     assert narrow.distinct <= 1024 < o.distinct
     assert (wide.verdict, wide.distinct, wide.generated, wide.levels) == (o.verdict, o.distinct, o.generated, o.levels)
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_wide_table_across_shards_loses_no_colliding_state_to_the_sender_side_filter(P):
+    """with 128-bit entries on shards the sender-side duplicate filter (on by default for 2-4 shards) remembered
+    64-bit fingerprints only — a second distinct remote state with the same fingerprint was dropped at the sender and never
+    met its owner's check-word comparison, unseen by the conservation law.  The filter is off under wide_fingerprint now.
+    Collisions on demand (-DKMC_TEST_FP_BITS=10: 39,619 states share 1,024 fingerprints): P logical shards find all of them,
+    and nothing was filtered."""
+    import os
+    from dataclasses import replace
+    from kafka_specification_amd import sharded
+    o = kmo.Run(kmo.make_config("Kip320", N=3, L=2, R=2, E=1, invariants=("TypeOk",)))
+    os.environ["KMC_JIT_DEFINES"] = "-DKMC_TEST_FP_BITS=10"
+    try:
+        cfg = replace(CheckerConfig(**SMALL), wide_fingerprint=True, table_capacity=1 << 18, frontier_capacity=1 << 16,
+                      send_capacity=1 << 14)
+        r = sharded.check_loopback(cfg, P)
+        filtered = sharded.run_sharded.last_send_filtered
+    finally:
+        del os.environ["KMC_JIT_DEFINES"]
+    assert (r.verdict, r.distinct, r.generated, r.levels) == (o.verdict, o.distinct, o.generated, o.levels)
+    assert filtered == 0
