@@ -316,8 +316,9 @@ def main():
         from kafka_specification_amd.sharded import bench_sharded
         if world != a.gpus:
             raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
-        results, dt, extra = bench_sharded(c, a.steps, a.warmup, backend=a.backend)
-        scaling, parallelism = "strong", f"fingerprint-sharded x{world}, all-to-all per BFS level"
+        results, dt, extra = bench_sharded(c, a.steps, a.warmup, backend=a.backend, symmetry=a.symmetry)
+        scaling, parallelism = "strong", (f"fingerprint-sharded x{world}, all-to-all per BFS level" +
+                                          (", orbit counting over the permutations of Replicas" if a.symmetry else ""))
     else:
         results, dt = run_single(c, a.steps, a.warmup, symmetry=a.symmetry)
         extra = {}

@@ -115,7 +115,8 @@ typedef struct kmc_config {
                                    behaviours (each step a successor of the one before), not chains of representatives.
                                    n_shards > 1: successors travel as representatives, every shard weighs the counters of
                                    kmc_step_finish / kmc_step_check_frontier itself (the states it claimed, the expansions
-                                   it ran), so the sums over the shards are the plain search's numbers; no keep_trace there */
+                                   it ran), so the sums over the shards are the plain search's numbers; predecessor links are those of the
+                                   representatives, and a trace is replayed through kmc_successors like any other */
 } kmc_config;
 
 typedef struct kmc_level_info {

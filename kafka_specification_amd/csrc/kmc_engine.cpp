@@ -238,9 +238,7 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
         return fail(KMC_E_ARG, "symmetry (orbit counting) is for the Kafka family and FiniteReplicatedLog with at most 7 replicas: "
                                "%s singles out a replica, or N = %d > %d",
                     MODEL_NAMES[cfg.model], cfg.n_replicas, KMC_SYMMETRY_MAX_REPLICAS);
-    if (cfg.symmetry && cfg.n_shards > 1 && cfg.keep_trace)
-        return fail(KMC_E_ARG, "symmetry (orbit counting) across shards keeps no traces: a chain of representatives' predecessors "
-                               "is walked on one GPU only (kmc_trace); run the counterexample's configuration on one shard");
+
     // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_MIN_WAVES=5 -DKMC_PROFILE=1"
     std::vector<std::string> defines;
     std::string defines_key;

@@ -146,11 +146,6 @@ def main(argv=None) -> int:
                     wide_fingerprint=a.fp128, symmetry=a.symmetry)
         if a.deadlock:
             over["check_deadlock"] = False
-        if a.symmetry and (a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1) and over["keep_trace"]:
-            # orbit counting across shards keeps no predecessor chains (kmc.h, kmc_config.symmetry): the verdict, the depth and
-            # the counts are reported; for the behaviour itself run the configuration on one GPU
-            print("Note: -symmetry across shards reports the verdict without a trace (-gpus 1 prints the behaviour)", file=sys.stderr)
-            over["keep_trace"] = False
         cc = to_checker_config(module, mcfg, **over)
     except CfgError as e:
         print(f"Error: {e}", file=sys.stderr)

@@ -40,6 +40,21 @@ def test_bench_gpus2_self_launches_and_prints_one_line():
     assert "cpu_baseline" not in r                         # N>1 lines carry no CPU leg
 
 
+def test_bench_gpus2_with_orbit_counting_prints_the_plain_searchs_numbers():
+    """`bench.py --gpus 2 --symmetry`: orbit counting on every rank (round 4: the level-step interface weighs its counters) —
+    the line carries the PLAIN search's counts, the stored states beside them."""
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo", "--no-cpu-baseline", "--symmetry",
+              "--workload", "Kip320,3,2,2,1"], {"KMC_SHARD_ENGINE": "shard_standin:make_engine"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    o = kmo.Run(kmo.make_config("Kip320", N=3, L=2, R=2, E=1, invariants=("TypeOk", "WeakIsr", "StrongIsr")))
+    assert r["config"]["distinct_states"] == o.distinct and r["config"]["states_generated"] == o.generated
+    assert r["config"]["depth"] == o.depth and r["config"]["verdict"] == "ok" and r["config"]["shards"] == 2
+    assert 0 < r["config"]["stored_states"] < o.distinct and "orbit counting" in r["config"]["parallelism"]
+
+
 def test_bench_gpus2_without_gpus_fails_loudly():
     # the product path (backend nccl, HipShardEngine): no device => every rank raises; nothing is printed as a result
     p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--workload", "Kip320,2,2,2,2"])

@@ -114,3 +114,10 @@ def test_baseline_config5_with_orbit_counting_on_eight_ranks_equals_the_orbit_or
                "table=23", "frontier=22", "send=18")
     assert out["matches_oracle"] and out["same_on_every_rank"] and out["verdict"] == "level_limit"
     assert out["distinct"] == 50390682994 and out["stored"] == 18908685
+
+
+def test_orbit_counting_with_traces_across_concurrent_ranks():
+    """symmetry + keep_trace through the native exchange: the records carry the predecessor word, every rank reconstructs the
+    same behaviour (owner by owner, replayed through the raw successor relation), of the oracle's length."""
+    out = _run("Kip101", 3, 2, 2, 2, 3, "TypeOk,StrongIsr", "trace", "symmetry")
+    assert out["matches_oracle"] and out["same_on_every_rank"] and out["verdict"] == "invariant" and out["trace_len"] >= 2

@@ -377,13 +377,31 @@ def test_orbit_counting_on_shards_under_a_level_budget_checks_the_last_frontier(
     assert (r.verdict, r.violated_invariant, r.violation_depth, r.violation_count) == ("invariant", o.viol_inv, o.viol_depth, o.viol_count)
 
 
-def test_orbit_counting_across_shards_refuses_traces():
-    from kafka_specification_amd import KmcError
+@pytest.mark.parametrize("P", [2, 3])
+@pytest.mark.parametrize("model", ["Kip101", "Kip279", "Kip320FirstTry"])
+def test_counterexample_trace_across_shards_under_orbit_counting(P, model):
+    """keep_trace + symmetry on P shards: the predecessor links are those of the representatives and live on their owners; the
+    chain is walked owner by owner and replayed from Init through the raw successor relation (kmc_successors lists a successor
+    itself with its representative's fingerprint) — a real behaviour of the oracle's length, ending in a violating state."""
+    import kmo
     from kafka_specification_amd.sharded import check_loopback
-    cfg = CheckerConfig(model="Kip101", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=2, invariants=("StrongIsr",),
-                        symmetry=True, keep_trace=True, table_capacity=1 << 18, frontier_capacity=1 << 16)
-    with pytest.raises(KmcError, match="keeps no traces"):
-        check_loopback(cfg, 2)
+    N, L, R, E = 3, 2, 2, 2
+    inv = ("TypeOk", "StrongIsr")
+    ocfg = kmo.make_config(model, N=N, L=L, R=R, E=E, invariants=inv)
+    o = kmo.Run(ocfg)
+    assert o.verdict == "invariant"
+    cfg = CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, invariants=inv, symmetry=True,
+                        keep_trace=True, table_capacity=1 << 20, frontier_capacity=1 << 18, send_capacity=1 << 16)
+    r = check_loopback(cfg, P)
+    assert (r.verdict, r.violated_invariant, r.violation_depth, r.violation_count) == ("invariant", o.viol_inv, o.viol_depth, o.viol_count)
+    trace = r.trace
+    assert len(trace) == o.viol_depth and trace[0] == (None, o.state(0))
+    with ModelChecker(CheckerConfig(model=model, n_replicas=N, log_size=L, max_records=R, max_leader_epoch=E, device=-1)) as mc:
+        names = mc.action_names()
+    for (_, prev), (act, cur) in zip(trace, trace[1:]):
+        assert (names.index(act), cur) in kmo.successors(ocfg, prev, o.sb)
+        assert all(kmo.check_invariant(ocfg, INV_INDEX[i], prev) for i in inv)
+    assert not kmo.check_invariant(ocfg, INV_INDEX[o.viol_inv], trace[-1][1])
 
 
 def test_baseline_config5_with_orbit_counting_on_eight_logical_shards_equals_the_orbit_oracle():
