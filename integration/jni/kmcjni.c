@@ -2,9 +2,13 @@
  * libkmc.so (include/kmc.h).  No logic lives here: every native method marshals its arguments, makes ONE
  * kmc_* call and turns a non-zero status into a Java exception carrying kmc_last_error().
  *
- * NOT RUN HERE (no JDK / JVM in this image).  It is compiled by tests/test_jni_shim.py against
+ * NEVER RUN UNDER A JVM (no JDK in this image).  It is compiled by tests/test_jni_shim.py against
  * tests/jni_stub/jni.h — a stand-in that declares the JNI functions used below with the signatures of the
- * JNI specification — so at least its C is checked and its undefined symbols are exactly kmc_* entry points.
+ * JNI specification — its undefined symbols are exactly kmc_* entry points, and since round 4 it is EXECUTED:
+ * tests/jni_stub/fake_jvm.c implements that function table over a toy object model and plays the Java half,
+ * so every line below runs against libkmc.so (tests/test_gpu_jni_harness.py on the GPU; the failed-open
+ * exception path on any box).  A stand-in is not a JVM: class loading, the real jni.h and KmcModelChecker.java
+ * itself remain unexercised.
  * Build against a real JDK:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include kmcjni.c \
  *       -L../../kafka_specification_amd -lkmc -o libkmcjni.so

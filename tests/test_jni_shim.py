@@ -33,3 +33,30 @@ def test_jni_glue_compiles_and_binds_only_the_c_abi(tmp_path):
                          capture_output=True, text=True, check=True).stdout
     for s in kmc_used:
         assert re.search(rf" T {s}$", lib, flags=re.M), f"libkmc.so does not export {s}"
+
+
+HARNESS = os.path.join(ROOT, "tests", "_jni_harness")
+
+
+def build_harness():
+    """tests/jni_stub/fake_jvm.c (a JNIEnv implemented over a toy object model + a C main playing the Java half) linked with
+    the real kmcjni.c and libkmc.so: every line of the glue executes — against a stand-in, not a JVM."""
+    src = [os.path.join(ROOT, "tests", "jni_stub", "fake_jvm.c"), SRC]
+    lib = os.path.join(ROOT, "kafka_specification_amd")
+    if not os.path.exists(HARNESS) or any(os.path.getmtime(HARNESS) < os.path.getmtime(s) for s in src):
+        subprocess.check_call(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "tests", "jni_stub"),
+                               "-I" + os.path.join(ROOT, "include"), *src, "-L" + lib, "-lkmc", "-Wl,-rpath," + lib,
+                               "-o", HARNESS])
+    return HARNESS
+
+
+def test_jni_glue_executes_and_turns_a_failed_open_into_a_java_exception():
+    """No GPU here: kmc_open fails ("no HIP device ... no CPU fallback"), and the glue must hand that to the caller as an
+    IllegalStateException carrying kmc_last_error() — after marshalling all seventeen Config fields through GetFieldID /
+    Get<Type>Field without an exception of its own (a misspelt field would surface as NoSuchFieldError instead)."""
+    import json
+    env = dict(os.environ, KMC_NO_TORCH="1", HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="")
+    p = subprocess.run([build_harness(), "5", "3", "2", "2", "1", "7", "device=0"], capture_output=True, text=True, env=env, timeout=120)
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert p.returncode == 3 and out["exception"] == "java/lang/IllegalStateException"
+    assert out["message"].startswith("kmc_open: ") and "no CPU fallback" in out["message"]
