@@ -64,3 +64,27 @@ def compare(meta, fx, i, records, inv_bits, who):
     assert inv_bits == int(fx["inv"][i]), (
         f"{who}: invariants violated by {state.hex()}: {inv_bits:04b}, the reference's text {int(fx['inv'][i]):04b} "
         f"(bit k = {meta['invariants']}[k])")
+
+
+MUTANTS_INDEX = os.path.join(GOLDEN, "oracle_r_mutants_index.json")
+
+
+def mutant_entries():
+    """[(file, meta)] of tests/golden/oracle_r_mutants_*.npz: the invariants on arbitrary (mutated) states, by Oracle-R."""
+    if not os.path.exists(MUTANTS_INDEX):
+        return []
+    ix = json.load(open(MUTANTS_INDEX))["entries"]
+    return [(fn, ix[fn]) for fn in sorted(ix) if os.path.exists(os.path.join(GOLDEN, fn))]
+
+
+def comparable_invariants(inv_bits, undefined_bits):
+    """The invariant bits of a mutated state on which the lowerings are held to the reference's text.  TypeOk (bit 0) and
+    LeaderInIsr (bit 3): always.  WeakIsr / StrongIsr (bits 1, 2): on the states that satisfy TypeOk.  The text asks for
+    `\\E record \\in LogRecords : HasEntry(r1, record, offset) /\\ HasEntry(r2, record, offset)` (KafkaReplication.tla:320-340);
+    the lowerings compare the two slots, which is the same thing exactly when a written slot holds a member of LogRecords —
+    ReplicaLog!TypeOk (FiniteReplicatedLog.tla:90-95).  On a state that breaks TypeOk the text can fail where slot equality
+    holds; TLC reports TypeOk there (it is the first invariant of every .cfg twin), and no model of the reference reaches one."""
+    keep = 15 & ~undefined_bits
+    if inv_bits & 1:
+        keep &= ~6
+    return keep

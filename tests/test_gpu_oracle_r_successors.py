@@ -40,3 +40,30 @@ def test_engine_equals_the_executed_reference_state_by_state(entry, symmetry):
             bits = C.c_uint32()
             nat.check(lib.kmc_check_states(mc._h, wa, 1, 15, C.byref(bits)))
             ors.compare(m, fx, i, recs, int(bits.value), "HIP engine" + (" (orbit counting)" if symmetry else ""))
+
+
+MUTANTS = ors.mutant_entries()
+
+
+@pytest.mark.parametrize("entry", MUTANTS, ids=ors.ids)
+def test_engine_invariants_on_arbitrary_states_equal_the_executed_reference(entry):
+    """kmc_check_states — the predicate k_expand applies to the states it expands — on tests/golden/oracle_r_mutants_*.npz:
+    deep states with fields overwritten by values in or just outside their ranges, where every one of the four invariants
+    fails hundreds of times, judged by the reference's own text (Oracle-R).  WeakIsr / StrongIsr are compared where TypeOk
+    holds (oracle_r_successors.comparable_invariants)."""
+    fn, m = entry
+    fx = ors.load(fn)
+    cfg = CheckerConfig(model=m["module"], n_replicas=m["N"], log_size=m["L"], max_records=m["R"], max_leader_epoch=m["E"],
+                        table_capacity=1 << 16, frontier_capacity=1 << 12)
+    n = len(fx["states"])
+    with ModelChecker(cfg) as mc:
+        W = mc.state_words
+        words = (C.c_uint64 * (n * W))()
+        for i in range(n):
+            words[i * W:(i + 1) * W] = mc.pack(bytes(fx["states"][i]))
+        bits = (C.c_uint32 * n)()
+        nat.check(nat.lib().kmc_check_states(mc._h, words, n, 15, bits))     # one call, n single-state passes
+    for i in range(n):
+        keep = ors.comparable_invariants(int(fx["inv"][i]), int(fx["undefined"][i]))
+        assert int(bits[i]) & keep == int(fx["inv"][i]) & keep, (
+            f"HIP engine: {bytes(fx['states'][i]).hex()} violates {int(bits[i]):04b}, the reference's text {int(fx['inv'][i]):04b}")

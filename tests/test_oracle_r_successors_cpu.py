@@ -92,3 +92,39 @@ def test_guard_groups_never_hide_an_enabled_instance(entry):
             assert enabled <= int(fx["nsucc"][i])
             total += enabled
     assert total > 0
+
+
+# ---- the invariants on ARBITRARY states (tests/golden/oracle_r_mutants_*.npz, make_oracle_r_mutants.py) -------------------------
+MUTANTS = ors.mutant_entries()
+
+
+def test_mutant_fixtures_make_every_invariant_fail_somewhere():
+    assert len(MUTANTS) >= 7
+    for fn, m in MUTANTS:
+        assert m["states"] >= 3000 and all(v >= 100 for v in m["violating"]), m    # TypeOk, WeakIsr, StrongIsr, LeaderInIsr
+        inv = ors.load(fn)["inv"]
+        typeok = (inv & 1) == 0       # ... and WeakIsr / StrongIsr fail on states that DO satisfy TypeOk (where they are compared)
+        assert int(((inv & 2) != 0)[typeok].sum()) >= 50 and int(((inv & 4) != 0)[typeok].sum()) >= 50
+
+
+@pytest.mark.parametrize("entry", MUTANTS, ids=ors.ids)
+def test_invariants_on_arbitrary_states_equal_the_executed_reference(entry):
+    """TypeOk is true on every reachable state (and WeakIsr / StrongIsr on every reachable state of Kip320): only unreachable
+    states can tell a lowered invariant from `return true`.  On 3,000 mutated deep states per binding — fields overwritten with
+    values in or just outside their ranges — the C oracle's and the device templates' four predicates equal Oracle-R's, i.e.
+    the reference's own KafkaReplication.tla:101,320,334,345 evaluated on that state (WeakIsr / StrongIsr where TypeOk holds:
+    oracle_r_successors.comparable_invariants says why)."""
+    fn, m = entry
+    fx = ors.load(fn)
+    ocfg = kmo.make_config(m["module"], N=m["N"], L=m["L"], R=m["R"], E=m["E"], invariants=())
+    cfg6 = (kmo.MODELS[m["module"]], m["N"], m["L"], m["R"], m["E"], 0)
+    consts = dict(n_replicas=m["N"], log_size=m["L"], max_records=m["R"], max_leader_epoch=m["E"])
+    with ModelChecker(CheckerConfig(model=m["module"], device=-1, **consts)) as mc:
+        for i in range(len(fx["states"])):
+            s = bytes(fx["states"][i])
+            keep = ors.comparable_invariants(int(fx["inv"][i]), int(fx["undefined"][i]))
+            want = int(fx["inv"][i]) & keep
+            got_c = sum((0 if kmo.check_invariant(ocfg, k, s) else 1) << k for k in range(4)) & keep
+            got_d = host_emu.violated(cfg6, mc.pack(s), 15) & keep
+            assert got_c == want, f"C oracle: {s.hex()} violates {got_c:04b}, the reference's text says {want:04b}"
+            assert got_d == want, f"device templates: {s.hex()} violates {got_d:04b}, the reference's text says {want:04b}"
