@@ -417,3 +417,21 @@ def test_baseline_config5_with_orbit_counting_on_eight_logical_shards_equals_the
     assert r.generated == g["generated"] and r.deadlock_states == g["deadlock_states"]
     assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
     assert r.orbit_representatives == g["stored"] == 18908685
+
+
+def test_sharded_checkpoint_and_recover_under_orbit_counting(tmp_path):
+    """P shards with orbit counting stop at max_levels, save their tables / frontiers (stored representatives + the stabiliser
+    plane) and the driver its weighted counters; fresh shards finish with the numbers of the uninterrupted plain search."""
+    import kmo
+    from kafka_specification_amd.sharded import check_loopback
+    base = dict(model="Kip320", n_replicas=3, log_size=3, max_records=3, max_leader_epoch=1, symmetry=True,
+                invariants=("TypeOk", "WeakIsr", "StrongIsr"), table_capacity=1 << 20, frontier_capacity=1 << 17,
+                send_capacity=1 << 16)
+    o = kmo.Run(kmo.make_config("Kip320", N=3, L=3, R=3, E=1, invariants=base["invariants"], threads=8))
+    ckpt = str(tmp_path / "ckpt")
+    part = check_loopback(CheckerConfig(**base, max_levels=11), 3, checkpoint_dir=ckpt)
+    assert part.verdict == "level_limit" and part.levels == o.levels[:11]
+    rest = check_loopback(CheckerConfig(**base), 3, resume_dir=ckpt)
+    assert (rest.verdict, rest.distinct, rest.generated, rest.depth, rest.levels) == (o.verdict, o.distinct, o.generated, o.depth, o.levels)
+    assert list(rest.action_generated.values()) == o.action_generated[:len(rest.action_generated)]
+    assert rest.deadlock_states == o.deadlock_states
