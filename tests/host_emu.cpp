@@ -197,7 +197,7 @@ const Entry TABLE[] = {
     // small enough for the orbit-counting search to be replayed state by state on the CPU (tests/test_symmetry_cpu.py)
     KAFKA(KMC_MODEL_TRUNCATE_TO_HW, 3, 2, 2, 1), KAFKA(KMC_MODEL_KIP101, 3, 2, 2, 1), KAFKA(KMC_MODEL_KIP320, 3, 2, 2, 1),
     KAFKA(KMC_MODEL_KIP320_FIRST_TRY, 3, 2, 2, 1), KAFKA(KMC_MODEL_KIP320, 4, 1, 1, 1), KAFKA(KMC_MODEL_KIP279, 2, 2, 2, 2),
-    ASYNC(3, 2, 2), ASYNC(4, 2, 2), ASYNC(2, 3, 7), ASYNC(1, 4, 0),
+    ASYNC(3, 2, 2), ASYNC(4, 2, 2), ASYNC(2, 3, 7), ASYNC(1, 4, 0), ASYNC(4, 3, 4), ASYNC(3, 3, 4),   // (the last two: models/MCAsyncIsr.cfg, MCAsyncIsr_small.cfg — the per-state fixtures)
     FRL(2, 4, 2), FRL(3, 2, 2),
 };
 

@@ -156,3 +156,25 @@ def kafka_state_from_bytes(b, constants):
     return dict(replicaLog=Fn(logs), replicaState=Fn(states), nextRecordId=b[g], nextLeaderEpoch=b[g + 1],
                 quorumState=Fn({"leaderEpoch": b[g + 2] - 1, "leader": leader(b[g + 3]), "isr": unmask(b[g + 4])}),
                 leaderAndIsrRequests=reqs)
+
+
+def async_state_from_bytes(b, constants):
+    """Inverse of async_state_bytes: canonical bytes -> the TLA+ values of AsyncIsr.tla:30-34's variables."""
+    idx = replica_order(constants)
+    name = {i: r for r, i in idx.items()}
+    N, E = len(idx), constants["MaxVersion"]
+    rb = ((1 << N) + 7) // 8
+    a_req = 6 + N
+    a_upd = a_req + (E + 1) * rb
+    assert len(b) == a_upd + E + 1
+
+    def unmask(m):
+        return frozenset(name[i] for i in range(N) if m >> i & 1)
+
+    controller = Fn({"isr": unmask(b[0]), "version": b[1]})
+    leader = Fn({"isr": unmask(b[2]), "version": b[3], "pendingIsr": unmask(b[4]), "pendingVersion": b[5] - 1,
+                 "offsets": Fn({name[i]: b[6 + i] for i in range(N)})})
+    requests = frozenset(Fn({"isr": unmask(m), "version": v}) for v in range(E + 1) for m in range(1 << N)
+                         if b[a_req + v * rb + (m >> 3)] >> (m & 7) & 1)
+    updates = frozenset(Fn({"isr": unmask(b[a_upd + v - 1]), "version": v}) for v in range(1, b[1] + 1))
+    return dict(controllerState=controller, leaderState=leader, requests=requests, updates=updates)

@@ -88,3 +88,16 @@ def comparable_invariants(inv_bits, undefined_bits):
     if inv_bits & 1:
         keep &= ~6
     return keep
+
+
+def engine_model(meta):
+    """(engine / C-oracle model name, CheckerConfig constants, kmo.make_config constants) of a fixture entry."""
+    if meta["module"] == "MCAsyncIsr":   # AsyncIsr.tla under models/MCAsyncIsr.tla: (N, MaxOffset, MaxVersion)
+        return ("AsyncIsr", dict(n_replicas=meta["N"], log_size=meta["L"], max_leader_epoch=meta["E"]),
+                dict(N=meta["N"], L=meta["L"], E=meta["E"]))
+    return (meta["module"], dict(n_replicas=meta["N"], log_size=meta["L"], max_records=meta["R"], max_leader_epoch=meta["E"]),
+            dict(N=meta["N"], L=meta["L"], R=meta["R"], E=meta["E"]))
+
+
+def is_kafka(entry):
+    return entry[1]["module"] != "MCAsyncIsr"

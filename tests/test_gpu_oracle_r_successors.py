@@ -25,10 +25,12 @@ def test_engine_equals_the_executed_reference_state_by_state(entry, symmetry):
     """(under orbit counting kmc_successors lists the successors themselves — the raw Next relation of the state it is
     given — so the same file applies; a quarter of the states suffices there)"""
     fn, m = entry
+    if symmetry and not ors.is_kafka(entry):
+        pytest.skip("AsyncIsr singles out the Leader: no orbit counting")
     fx = ors.load(fn)
-    cfg = CheckerConfig(model=m["module"], n_replicas=m["N"], log_size=m["L"], max_records=m["R"], max_leader_epoch=m["E"],
-                        invariants=("TypeOk", "WeakIsr", "StrongIsr"), table_capacity=1 << 16, frontier_capacity=1 << 12,
-                        symmetry=symmetry)
+    model, consts, _ = ors.engine_model(m)
+    cfg = CheckerConfig(model=model, **consts, table_capacity=1 << 16, frontier_capacity=1 << 12, symmetry=symmetry)
+    mask = (1 << len(m["invariants"])) - 1
     step = 4 if symmetry else 1
     with ModelChecker(cfg) as mc:
         W = mc.state_words
@@ -38,7 +40,7 @@ def test_engine_equals_the_executed_reference_state_by_state(entry, symmetry):
             recs = [(k, mc.unpack(t)) for (t, _fp, k) in mc.successors(w)]
             wa = (C.c_uint64 * W)(*w)
             bits = C.c_uint32()
-            nat.check(lib.kmc_check_states(mc._h, wa, 1, 15, C.byref(bits)))
+            nat.check(lib.kmc_check_states(mc._h, wa, 1, mask, C.byref(bits)))
             ors.compare(m, fx, i, recs, int(bits.value), "HIP engine" + (" (orbit counting)" if symmetry else ""))
 
 

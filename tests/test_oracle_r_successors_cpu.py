@@ -19,6 +19,7 @@ import oracle_r_successors as ors
 from kafka_specification_amd import CheckerConfig, ModelChecker
 
 ENTRIES = ors.entries()
+KAFKA_ENTRIES = [e for e in ENTRIES if ors.is_kafka(e)]
 
 
 def test_the_fixtures_exist_for_every_binding_the_bench_and_baseline_name():
@@ -26,9 +27,10 @@ def test_the_fixtures_exist_for_every_binding_the_bench_and_baseline_name():
     for mod in ("KafkaTruncateToHighWatermark", "Kip101", "Kip279", "Kip320", "Kip320FirstTry"):
         assert (mod, 3, 6, 6, 2) in have
     assert ("Kip279", 5, 2, 2, 1) in have and ("Kip320", 7, 8, 8, 3) in have
+    assert ("MCAsyncIsr", 4, 3, 0, 4) in have     # models/MCAsyncIsr.cfg: AsyncIsr.tla under the state constraint
 
 
-@pytest.mark.parametrize("entry", ENTRIES, ids=ors.ids)
+@pytest.mark.parametrize("entry", KAFKA_ENTRIES, ids=ors.ids)
 def test_the_sample_reaches_what_small_exhaustive_runs_cannot(entry):
     """Recomputed from the state bytes, not read from the index: deep logs with mixed epochs under a high watermark >= 3."""
     fn, m = entry
@@ -51,11 +53,12 @@ def test_the_sample_reaches_what_small_exhaustive_runs_cannot(entry):
 def test_c_oracle_equals_the_executed_reference_state_by_state(entry):
     fn, m = entry
     fx = ors.load(fn)
-    ocfg = kmo.make_config(m["module"], N=m["N"], L=m["L"], R=m["R"], E=m["E"], invariants=())
+    model, _consts, oconsts = ors.engine_model(m)
+    ocfg = kmo.make_config(model, **oconsts, invariants=())
     sb = fx["states"].shape[1]
     for i in range(len(fx["states"])):
         s = bytes(fx["states"][i])
-        inv = sum((0 if kmo.check_invariant(ocfg, k, s) else 1) << k for k in range(4))
+        inv = sum((0 if kmo.check_invariant(ocfg, k, s) else 1) << k for k in range(len(m["invariants"])))
         ors.compare(m, fx, i, kmo.successors(ocfg, s, sb), inv, "C oracle")
 
 
@@ -63,18 +66,19 @@ def test_c_oracle_equals_the_executed_reference_state_by_state(entry):
 def test_device_model_templates_equal_the_executed_reference_state_by_state(entry):
     fn, m = entry
     fx = ors.load(fn)
-    cfg6 = (kmo.MODELS[m["module"]], m["N"], m["L"], m["R"], m["E"], 0)
+    model, consts, _ = ors.engine_model(m)
+    cfg6 = (kmo.MODELS[model], m["N"], m["L"], m["R"], m["E"], 0)
     assert host_emu.lib().emu_words(*cfg6) > 0, "tests/host_emu.cpp does not instantiate this binding"
-    consts = dict(n_replicas=m["N"], log_size=m["L"], max_records=m["R"], max_leader_epoch=m["E"])
     step = int(os.environ.get("KMC_SUCC_FIXTURE_STRIDE", "1"))
-    with ModelChecker(CheckerConfig(model=m["module"], device=-1, **consts)) as mc:   # host-only handle: pack / unpack
+    mask = (1 << len(m["invariants"])) - 1
+    with ModelChecker(CheckerConfig(model=model, device=-1, **consts)) as mc:   # host-only handle: pack / unpack
         for i in range(0, len(fx["states"]), step):
             w = mc.pack(bytes(fx["states"][i]))
             recs = [(k, mc.unpack(t)) for (k, t) in host_emu.successors(cfg6, w)]
-            ors.compare(m, fx, i, recs, host_emu.violated(cfg6, w, 15), "device templates on the host")
+            ors.compare(m, fx, i, recs, host_emu.violated(cfg6, w, mask), "device templates on the host")
 
 
-@pytest.mark.parametrize("entry", ENTRIES, ids=ors.ids)
+@pytest.mark.parametrize("entry", KAFKA_ENTRIES, ids=ors.ids)
 def test_guard_groups_never_hide_an_enabled_instance(entry):
     """Pass 1 of the wide configurations evaluates the guards group by group and SKIPS a group whose necessary condition
     (KmcKafka::group_pre: the request of that epoch names that leader / that replica presumes leadership) fails in every lane
