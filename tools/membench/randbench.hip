@@ -9,6 +9,10 @@
 //   mode 6: random agent-scope (sc1, L2-bypassing) loads
 //   mode 7: the seen-set's own mix: a random load, and for 35 % of the accesses a CAS on the slot just read
 //           (the headline run claims 312 M of its 888 M probes)
+//   mode 8..11: random ALIGNED plain stores of 16 / 32 / 64 / 128 bytes (one lane writes the whole unit with dwordx4 stores):
+//           does a write that covers a whole 32-byte sector / 64-byte half line / 128-byte line escape the read-modify-write
+//           that an 8-byte store into an untouched DRAM line pays?  (round 4: what a claim protocol with wider slots could hope for)
+//   mode 12: load, then a plain 8-byte store when the slot was empty (a claim without the atomic)
 // Prints G accesses/s.  Build: hipcc --offload-arch=gfx950 -O3 randbench.hip -o randbench
 // Usage: randbench [first_mode [log2_slots ...]]  — with sizes given, every mode runs on a table of
 // each size (footprint sweep: does a seen-set partition that fits L2 / Infinity Cache probe faster?)
@@ -46,11 +50,27 @@ __global__ __launch_bounds__(256) void k(u64* table, u64 mask, int iters, int mo
     } else if (mode == 6) {
         for (int i = 0; i < iters; ++i) { x = mix(x + __hip_atomic_load(&table[x & mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
         acc = x;
-    } else {
+    } else if (mode == 7) {
         for (int i = 0; i < iters; ++i) {
             x = mix(x + 1);
             u64 v = table[x & mask];
             if (((x >> 40) & 0xFF) < 90) v = atomicCAS(&table[x & mask], v, x | 1);  // 35 %: claim whatever is there
+            acc ^= v;
+        }
+    } else if (mode >= 8 && mode <= 11) {
+        const int quads = 1 << (mode - 8);              // 16-byte pieces per store unit: 1, 2, 4, 8
+        const u64 unit_mask = mask & ~(u64)(2 * quads - 1);   // slot index aligned to the unit
+        for (int i = 0; i < iters; ++i) {
+            x = mix(x + 1);
+            uint4* p = (uint4*)&table[x & unit_mask];
+            const uint4 v = make_uint4((unsigned)x, (unsigned)(x >> 32), (unsigned)i, 1u);
+            for (int q = 0; q < quads; ++q) p[q] = v;
+        }
+    } else {
+        for (int i = 0; i < iters; ++i) {
+            x = mix(x + 1);
+            u64 v = table[x & mask];
+            if (v == 0) table[x & mask] = x | 1;
             acc ^= v;
         }
     }
@@ -66,7 +86,7 @@ int main(int argc, char** argv) {
     for (int si = 0; si < nsizes; ++si) {
     const u64 slots = 1ull << (sizes[si] < 10 ? 10 : sizes[si] > 30 ? 30 : sizes[si]);
     if (nsizes > 1 || argc > 2) printf("# table of 2^%d slots = %.1f MiB\n", sizes[si], slots * 8 / 1048576.0);
-    for (int mode = (argc > 1 ? atoi(argv[1]) : 0); mode < 8; ++mode)
+    for (int mode = (argc > 1 ? atoi(argv[1]) : 0); mode < 13; ++mode)
         for (int bpc : {8}) {
             hipMemset(table, 0, slots * 8);
             const int blocks = 256 * bpc, iters = (mode == 0 || mode == 6) ? 400 : 800;
