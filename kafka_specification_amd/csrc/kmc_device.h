@@ -65,6 +65,14 @@ typedef unsigned int u32;
 #define KMC_QCAP 64   // per-wave output-stager capacity (winners) = the drain granularity: a push that would overflow it
                       // fills it, drains it and stages the rest (KmcStager::push) — half the LDS of a 128-entry ring,
                       // which is what lets 8 blocks (8 waves per SIMD) share a CU's 160 KB
+#ifndef KMC_QCAP_WIDE
+#define KMC_QCAP_WIDE 64   // ... for states of KMC_QCAP_WIDE_FROM words or more.  A 10-word state (BASELINE config 5) needs
+                           // 4 x (10 x 128 + 10 x 64) x 8 = 60 KB of LDS per block: TWO blocks per CU whatever the registers
+                           // allow; with 32 it is 50 KB and three fit (measured in round 4: profiles/r04_wide_kernel.txt)
+#endif
+#define KMC_QCAP_WIDE_FROM 8
+// the stager's capacity for a state of W words (host and device agree on it: kmc_expand_lds_bytes)
+constexpr int kmc_qcap(int W, int wide = KMC_QCAP_WIDE) { return W >= KMC_QCAP_WIDE_FROM ? wide : KMC_QCAP; }
 #define KMC_SEGS 8    // frontier segments, each with its own append counter (block b appends to b % KMC_SEGS)
 
 // tuning knobs (the host may override them per code object through KMC_JIT_DEFINES)
@@ -1968,8 +1976,9 @@ template <int W> struct KmcStager {
     // for free when its representative was chosen (KmcSymm::canon) — in plane W of the stager and of the frontiers, so that
     // the expansion does not have to walk through its N! images again to know how many states it stands for
     static constexpr int PL = W + (KMC_SYMM ? 1 : 0);
-    u64* planes;   // LDS, [PL][KMC_QCAP]
-    u32 count;     // wave-uniform; < KMC_QCAP between pushes (entries 0 .. count-1 are staged)
+    static constexpr int QCAP = kmc_qcap(W);
+    u64* planes;   // LDS, [PL][QCAP]
+    u32 count;     // wave-uniform; < QCAP between pushes (entries 0 .. count-1 are staged)
     u32 filtered;  // SHARDED: remote successors this wave's sender-side filter dropped (added to the level's counter once,
                    // in finish(): one atomicAdd per flush on that single line capped the sharded kernel at ~90 M flushes/s,
                    // 5.6x the time of the local kernel for the same work)
@@ -2012,7 +2021,7 @@ template <int W> struct KmcStager {
             if (base + lane < a.seg_cap) {
                 const u64 idx = (u64)seg * a.seg_cap + base + lane;
 #pragma unroll
-                for (int k = 0; k < PL; ++k) KMC_FRONTIER_STORE(&a.fout[(u64)k * a.fout_stride + idx], planes[k * KMC_QCAP + lane]);
+                for (int k = 0; k < PL; ++k) KMC_FRONTIER_STORE(&a.fout[(u64)k * a.fout_stride + idx], planes[k * QCAP + lane]);
             } else {
                 atomicOr(&a.ctl->err, KMC_ERR_FRONTIER_FULL);
             }
@@ -2027,23 +2036,41 @@ template <int W> struct KmcStager {
         const u32 n = __popcll(m);
         won += n;
         const u32 rank = kmc_rank_in(m);
-        const u32 room = KMC_QCAP - count;   // >= 1
+        if constexpr (QCAP < 64) {
+            // a batch may hold more winners than the stager: fill, drain, fill ... (wave-uniform; at most 64 / QCAP + 1 rounds)
+            u32 done = 0;
+            for (;;) {
+                const u32 room = (u32)QCAP - count;   // >= 1
+                const u32 take = n - done < room ? n - done : room;
+                if (isnew && rank >= done && rank < done + take) {
+#pragma unroll
+                    for (int k = 0; k < W; ++k) planes[k * QCAP + count + (rank - done)] = t[k];
+                    if constexpr (PL > W) planes[W * QCAP + count + (rank - done)] = tag;
+                }
+                count += take;
+                done += take;
+                if (count == (u32)QCAP) drain(a, QCAP);
+                if (done == n) return;
+            }
+        } else {
+        const u32 room = QCAP - count;   // >= 1
         if (isnew && rank < room) {
 #pragma unroll
-            for (int k = 0; k < W; ++k) planes[k * KMC_QCAP + count + rank] = t[k];
-            if constexpr (PL > W) planes[W * KMC_QCAP + count + rank] = tag;
+            for (int k = 0; k < W; ++k) planes[k * QCAP + count + rank] = t[k];
+            if constexpr (PL > W) planes[W * QCAP + count + rank] = tag;
         }
         if (n < room) {
             count += n;
             return;
         }
-        drain(a, KMC_QCAP);
+        drain(a, QCAP);
         if (isnew && rank >= room) {
 #pragma unroll
-            for (int k = 0; k < W; ++k) planes[k * KMC_QCAP + (rank - room)] = t[k];
-            if constexpr (PL > W) planes[W * KMC_QCAP + (rank - room)] = tag;
+            for (int k = 0; k < W; ++k) planes[k * QCAP + (rank - room)] = t[k];
+            if constexpr (PL > W) planes[W * QCAP + (rank - room)] = tag;
         }
         count = n - room;
+        }
     }
     KMC_DEV void finish(const KmcArgs& a, bool publish_counters = true) {
         if (count) drain(a, count);
@@ -2350,7 +2377,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
     const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, keep it scalar
     const bool has_meta = (a.flags & KMC_FLAG_META) != 0;
     const u32 ring_planes = W + (has_meta ? 1u : 0u);
-    u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + KmcStager<W>::PL * KMC_QCAP);  // q[k*KMC_RING + pos]
+    u64* q = kmc_lds + (size_t)wib * (ring_planes * KMC_RING + KmcStager<W>::PL * KmcStager<W>::QCAP);  // q[k*KMC_RING + pos]
     KmcStager<W> out;
     out.init(q + ring_planes * KMC_RING);
     u32 head = 0, count = 0;  // wave-uniform: ring read position / number of QUEUED successors
@@ -2845,15 +2872,15 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 }
 
 // dynamic LDS bytes k_expand needs for a state of W words
-KMC_HD inline unsigned kmc_expand_lds_bytes(int W, bool has_meta, bool symmetry = false) {
-    return (unsigned)(KMC_WAVES * ((W + (has_meta ? 1 : 0)) * KMC_RING + (W + (symmetry ? 1 : 0)) * KMC_QCAP) * 8);
+KMC_HD inline unsigned kmc_expand_lds_bytes(int W, bool has_meta, bool symmetry = false, int qcap_wide = KMC_QCAP_WIDE) {
+    return (unsigned)(KMC_WAVES * ((W + (has_meta ? 1 : 0)) * KMC_RING + (W + (symmetry ? 1 : 0)) * kmc_qcap(W, qcap_wide)) * 8);
 }
 
 // Inserts a list of AoS records (W state words + predecessor fp) into the local table:
 // the initial state, and the receive side of the multi-GPU exchange.
 template <class M> KMC_DEV void kmc_insert_body(const KmcArgs& a) {
     constexpr int W = M::W;
-    __shared__ u64 stage[KMC_WAVES][KmcStager<W>::PL][KMC_QCAP];
+    __shared__ u64 stage[KMC_WAVES][KmcStager<W>::PL][KmcStager<W>::QCAP];
     KmcStager<W> out;
     out.init(&stage[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0][0]);
 #if KMC_PROFILE
