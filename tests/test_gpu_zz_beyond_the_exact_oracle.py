@@ -115,3 +115,23 @@ def test_first_violation_at_the_headline_constants_matches_the_exact_orbit_oracl
     got = {n: r.violation_count.get(n, 0) for n in want}
     assert got == want
     assert r.violated_invariant == next(n for n in ("TypeOk", "WeakIsr", "StrongIsr") if want[n])
+
+
+@pytest.mark.parametrize("symmetry", [False, True], ids=["plain", "orbit-counting"])
+def test_one_step_beyond_the_headline_kip320_with_logsize_7_matches_the_exact_orbit_oracle(symmetry):
+    """Kip320, 3 brokers, LogSize 7, MaxRecords 7, MaxLeaderEpoch 2: 973,929,178 distinct states / 3,222,426,940 generated /
+    depth 52 — the largest exhaustive check with an EXACT CPU witness (Oracle-O: 162,341,877 stored full states,
+    tests/golden/orbit_kip320_3_7_7_2.json): level sizes, per-disjunct counts, deadlocks, no violation."""
+    g = json.load(open(os.path.join(GOLDEN, "orbit_kip320_3_7_7_2.json")))
+    cfg = CheckerConfig(model="Kip320", n_replicas=3, log_size=7, max_records=7, max_leader_epoch=2,
+                        invariants=("TypeOk", "WeakIsr", "StrongIsr"),
+                        table_capacity=1 << (30 if symmetry else 32), frontier_capacity=1 << (26 if symmetry else 28),
+                        symmetry=symmetry)
+    with ModelChecker(cfg) as mc:
+        r = mc.run()
+    assert r.verdict == "ok" and r.queue_left == 0 and sum(g["violating_states"]) == 0
+    assert (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
+    assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
+    assert r.deadlock_states == g["deadlock_states"]
+    if symmetry:
+        assert r.orbit_representatives == g["stored"]
