@@ -130,7 +130,7 @@ constexpr int kmc_qcap(int W, int wide = KMC_QCAP_WIDE) { return W >= KMC_QCAP_W
 #ifndef KMC_RING_FENCE
 #define KMC_RING_FENCE 0  // 1 (diagnostic): an explicit workgroup-scope fence between the LDS ring writes of a push and the
                           //    reads of a flush / drain.  A wave's LDS operations are executed in order, so this must change
-                          //    nothing; it exists to rule the cross-lane ring idiom out when results differ
+                          //    nothing; it exists to rule the cross-lane ring idiom out when results differ (docs/TUNING_LOG_r1-r3.md §2)
 #endif
 #if KMC_RING_FENCE
 #define KMC_FENCE_LDS() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
@@ -2629,7 +2629,7 @@ template <class M> KMC_DEV void kmc_expand_body(const KmcArgs& a) {
 
         KMC_T(tp2);
         KMC_TADD(1, tp1, tp2);
-        // Pass 2 — the effects.  (with the table untouched the kernel takes 20 ms in the kind-major form and
+        // Pass 2 — the effects.  (profiles/r03_ablation.txt, docs/TUNING_LOG_r1-r3.md §9: with the table untouched the kernel takes 20 ms in the kind-major form and
         // 26 ms in the instance-major one; the memory system needs ~31 ms for the run's probes and claims.)
         if constexpr (M::KIND_MAJOR) {
         // Kind-major walk (replica-major layouts, KmcKafka::apply<K>): for every action kind, every lane applies ITS OWN
