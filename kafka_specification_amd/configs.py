@@ -58,6 +58,7 @@ def precompile_list():
     out += [dict(model="Kip279", n_replicas=5, log_size=2, max_records=2, max_leader_epoch=2)]  # the non-exhaustible twin (prefix test)
     # tests/golden/oracle_r_ladder.json's 3/3/3/1 entries (round 4: the reference's text executed with logs three deep)
     out += [dict(model=m, n_replicas=3, log_size=3, max_records=3, max_leader_epoch=1) for m in KAFKA]
+    out += [dict(model="Kip320", n_replicas=3, log_size=2, max_records=3, max_leader_epoch=2)]   # oracle_r_ladder.json: 1.69 M states
     # two small bindings the -m gpu suite opens (found by listing what a fresh box still had to specialise, round 4)
     out += [dict(model="Kip320", n_replicas=2, log_size=1, max_records=1, max_leader_epoch=1),
             dict(model="Kip320", n_replicas=3, log_size=2, max_records=3, max_leader_epoch=1)]

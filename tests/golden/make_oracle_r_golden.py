@@ -35,6 +35,7 @@ def ladder(only=None):
             out.append(dict(module=m, N=c[0], L=c[1], R=c[2], E=c[3], invariants=KAFKA_INV, size="small" if c[0] == 2 else "medium"))
         out.append(dict(module=m, N=2, L=2, R=2, E=1, invariants=("LeaderInIsr",), stop=True, size="small"))
     out.append(dict(module="Kip320", N=3, L=2, R=2, E=2, invariants=KAFKA_INV, size="large"))
+    out.append(dict(module="Kip320", N=3, L=2, R=3, E=2, invariants=KAFKA_INV, size="large"))   # round 4: 1,694,476 states, 1.8 CPU-hours
     for m in KAFKA:   # round 4: three brokers with logs three deep, exhaustively (176 K - 310 K states, ~10 CPU-minutes each)
         out.append(dict(module=m, N=3, L=3, R=3, E=1, invariants=KAFKA_INV, size="large"))
     for M in (0, 10, 1000):
