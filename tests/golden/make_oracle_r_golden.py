@@ -9,7 +9,8 @@ level over the sorted canonical encodings of that level's states (tests/oracle_r
 
     python tests/golden/make_oracle_r_golden.py [--jobs 8] [--only small]
 
-About 25 CPU-minutes on 8 cores for the full ladder (the 737,794-state Kip320 3/2/2/2 run alone takes that long).
+About 25 CPU-minutes on 8 cores for the small and medium entries; the large ones (round 4: up to 2.0 M states) take one to
+three CPU-hours EACH, one process per entry.
 """
 import argparse
 import hashlib
@@ -36,6 +37,8 @@ def ladder(only=None):
         out.append(dict(module=m, N=2, L=2, R=2, E=1, invariants=("LeaderInIsr",), stop=True, size="small"))
     out.append(dict(module="Kip320", N=3, L=2, R=2, E=2, invariants=KAFKA_INV, size="large"))
     out.append(dict(module="Kip320", N=3, L=2, R=3, E=2, invariants=KAFKA_INV, size="large"))   # round 4: 1,694,476 states, 1.8 CPU-hours
+    for m in ("KafkaTruncateToHighWatermark", "Kip101", "Kip279", "Kip320FirstTry"):   # round 4: 1.4 - 2.0 M states, ~2 CPU-hours each
+        out.append(dict(module=m, N=3, L=2, R=2, E=2, invariants=KAFKA_INV, size="large"))
     for m in KAFKA:   # round 4: three brokers with logs three deep, exhaustively (176 K - 310 K states, ~10 CPU-minutes each)
         out.append(dict(module=m, N=3, L=3, R=3, E=1, invariants=KAFKA_INV, size="large"))
     for M in (0, 10, 1000):
