@@ -43,7 +43,7 @@ def device_source_sha256():
     """Identity of the device code the numbers belong to (profiles record it; a stale profile is not quoted)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kmc_layout.h", "kmc_device.h"):
+    for f in ("kmc_layout.h", "kmc_common.h", "kmc_models_small.h", "kmc_kafka.h", "kmc_symm.h", "kmc_sink.h", "kmc_kernels.h"):
         h.update(open(os.path.join(ROOT, "kafka_specification_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -117,10 +117,12 @@ def claims_per_distinct_state():
     return (float(v), os.path.relpath(path, ROOT)) if v else (None, None)
 
 
-def measured_traffic(code=None):
+def measured_traffic(code=None, level_budget=None, depth=None):
     """HBM bytes per k_expand launch from a committed PMC summary (profiles/rNN_*pmc_summary.json, newest round first) — only
     from one that was measured on the MACHINE CODE this run executes (`code` = kernel_code_sha256 of the running workload's
-    kernels; the summaries carry the hash of the kernels they profiled); otherwise null, with the reason."""
+    kernels; the summaries carry the hash of the kernels they profiled) AND over the same search (the same level budget and
+    the same depth: a per-launch average over ten geometrically growing levels says nothing about a run
+    of fourteen); otherwise null, with the reason."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*pmc_summary.json")), reverse=True)
     if not files:
@@ -135,6 +137,11 @@ def measured_traffic(code=None):
             seen.append(f"{os.path.basename(path)}: {str(e)[:40]}")
             continue
         if j.get("kernel_code_sha256") == code and j.get("hbm_bytes_per_launch"):
+            run = j.get("run", {})
+            if (run.get("level_budget") or None) != (level_budget or None) or (depth and run.get("depth") and run["depth"] != depth):
+                seen.append(f"{os.path.basename(path)}: same code, another search (level budget {run.get('level_budget')}, "
+                            f"depth {run.get('depth')}; this run {level_budget}, {depth})")
+                continue
             return j["hbm_bytes_per_launch"], (f"{os.path.relpath(path, ROOT)} (measured on this machine code: "
                                                f"kernel_code_sha256 {code[:16]})")
         seen.append(f"{os.path.basename(path)} {str(j.get('kernel_code_sha256'))[:12]}")
@@ -169,12 +176,25 @@ def workload_name(c):
             f"MaxLeaderEpoch={c['max_leader_epoch']} inv={'+'.join(c['invariants'])} deadlock=off")
 
 
+GOLDEN_TAG = {"Kip320": "kip320", "Kip279": "kip279", "Kip101": "kip101", "Kip320FirstTry": "kip320firsttry",
+              "KafkaTruncateToHighWatermark": "thw"}
+
+
 def expected_counts(c):
-    p = os.path.join(ROOT, "tests", "golden",
-                     f"oracle_kip320_{c['n_replicas']}_{c['log_size']}_{c['max_records']}_{c['max_leader_epoch']}.json")
-    if c["model"] == "Kip320" and os.path.exists(p):
-        g = json.load(open(p))
-        return dict(distinct=g["distinct"], generated=g["generated"], depth=g["depth"])
+    """(counts, file) of the committed oracle fixture for this binding [and level budget]: the exact C oracle's
+    (tests/golden/oracle_*.json) or Oracle-O's exact orbit search (orbit_*.json); None when there is none."""
+    tag = GOLDEN_TAG.get(c["model"])
+    if not tag:
+        return None
+    key = f"{tag}_{c['n_replicas']}_{c['log_size']}_{c['max_records']}_{c['max_leader_epoch']}"
+    if c.get("max_levels"):
+        key += f"_levels{c['max_levels']}"
+    for prefix in ("oracle_", "orbit_"):
+        p = os.path.join(ROOT, "tests", "golden", prefix + key + ".json")
+        if os.path.exists(p):
+            g = json.load(open(p))
+            return dict(distinct=g["distinct"], generated=g["generated"], depth=g["depth"], levels=g.get("levels"),
+                        file=os.path.relpath(p, ROOT))
     return None
 
 
@@ -234,12 +254,12 @@ def cpu_baseline(c, budget_states, total_states):
     return out
 
 
-def run_single(c, steps, warmup, symmetry=False):
+def run_single(c, steps, warmup, symmetry=False, table=None, frontier=None):
     import kafka_specification_amd as kmc
     # (under symmetry the seen-set and the frontiers hold one state per orbit: a quarter of the slots keeps the same load)
     cfg = kmc.CheckerConfig(**c, device=0, symmetry=symmetry,
-                            table_capacity=int(os.environ.get("KMC_BENCH_TABLE", (1 << 28) if symmetry else (1 << 30))),
-                            frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", (1 << 24) if symmetry else (1 << 26))),
+                            table_capacity=int(os.environ.get("KMC_BENCH_TABLE", table or ((1 << 28) if symmetry else (1 << 30)))),
+                            frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", frontier or ((1 << 24) if symmetry else (1 << 26)))),
                             wide_fingerprint=os.environ.get("KMC_BENCH_FP128", "0") == "1")   # tuning: 128-bit entries
     results = []
     with kmc.ModelChecker(cfg) as mc:
@@ -254,6 +274,65 @@ def run_single(c, steps, warmup, symmetry=False):
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     return results, dt
+
+
+def algorithmic_bytes_per_state(r):
+    """A = 2*S + 8*g + 8 per distinct state (frontier read + write, g seen-set probes of 8 B, one 8-B claim).
+    g is priced on generated - generated_repeats: TLC's "generated" counts a successor twice when two disjuncts of one binding
+    hold at once (Kip320.tla:82-83, Kip279.tla:47-51); such a pair is ONE successor and one probe."""
+    S = 8 * r.state_words
+    probes = r.generated - getattr(r, "generated_repeats", 0)
+    g = probes / max(r.distinct, 1)
+    return 2 * S + 8 * g + 8, S, g, probes
+
+
+# BASELINE.json configs[3] and configs[4] (SURVEY section 8d rows "config 4" and "config 5") on ONE GPU, in the driver's own run.
+# (The frontier-sharded forms of the same searches are `--gpus N --workload ...`; nothing here claims a multi-GPU number.)
+BASELINE_LEGS = {
+    # Kip279.tla:53-62 at five brokers: exhaustible, 112,549,196 states (tests/golden/oracle_kip279_5_2_2_1.json, exact)
+    "config4_kip279_5brokers": dict(
+        c=dict(model="Kip279", n_replicas=5, log_size=2, max_records=2, max_leader_epoch=1, invariants=("TypeOk",)),
+        table=1 << 30, frontier=1 << 26),
+    # Kip320.tla:150-159 at seven brokers, LogSize 8: nobody exhausts it (SURVEY section 7) — ten BFS levels, 197,561,008
+    # states (tests/golden/oracle_kip320_7_8_8_3_levels10.json, exact), reported with "exhausted": false
+    "config5_kip320_7brokers_levels10": dict(
+        c=dict(model="Kip320", n_replicas=7, log_size=8, max_records=8, max_leader_epoch=3,
+               invariants=("TypeOk", "WeakIsr", "StrongIsr"), max_levels=10),
+        table=1 << 31, frontier=1 << 29),
+}
+
+
+def baseline_leg(name, steps, warmup):
+    """One BASELINE config beside the headline: the same measurement (whole kmc_run steps, inputs resident, k_expand time from HIP
+    events on the engine's stream), its counts against the committed exact fixture, its own roofline block."""
+    spec = BASELINE_LEGS[name]
+    c = dict(spec["c"])
+    try:
+        results, dt = run_single(c, steps, warmup, table=spec["table"], frontier=spec["frontier"])
+    except Exception as e:   # a leg never takes the headline line down with it
+        return {"error": str(e)[:300]}
+    r = results[-1]
+    exp = expected_counts(c)
+    A, S, g, probes = algorithmic_bytes_per_state(r)
+    kernel_s = sum(x.seconds_expand for x in results) / len(results)
+    code = kernel_code_sha256_of({k: v for k, v in c.items() if k != "max_levels"})
+    traffic, traffic_source = measured_traffic(code, c.get("max_levels"), r.depth)
+    achieved = A * r.distinct / max(kernel_s, 1e-12)
+    return {
+        "workload": workload_name(c), "state_bytes": S, "level_budget": c.get("max_levels"),
+        "exhausted": r.verdict != "level_limit", "verdict": r.verdict,
+        "value": sum(x.distinct for x in results) / dt, "unit": "distinct states/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * dt / steps, "time_s": dt / steps,
+        "distinct_states": r.distinct, "states_generated": r.generated, "seen_set_probes": probes, "depth": r.depth,
+        "matches_oracle_golden": None if exp is None else (r.distinct == exp["distinct"] and r.generated == exp["generated"]
+                                                           and r.depth == exp["depth"]
+                                                           and (exp["levels"] is None or list(r.levels) == list(exp["levels"]))),
+        "oracle_golden": exp["file"] if exp else None,
+        "kernel_seconds_per_step": kernel_s, "launches_per_step": r.expand_launches,
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_BPS, "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_distinct_state": A, "kernel": "kmc_expand_*", "kernel_code_sha256": code},
+    }
 
 
 def self_launch(n):
@@ -289,6 +368,9 @@ def main():
                          "profiling that kernel; the default line times the plain search and reports orbit counting beside it")
     ap.add_argument("--no-orbit-counting", action="store_true", help="skip the orbit_counting leg of the default line")
     ap.add_argument("--no-cold-start", action="store_true", help="skip the cold_start leg (one fresh CLI process, exec to exit)")
+    ap.add_argument("--no-baseline-configs", action="store_true",
+                    help="skip the baseline_configs legs (BASELINE.json configs 4 and 5 on one GPU, beside the headline)")
+    ap.add_argument("--config-steps", type=int, default=3, help="timed steps of each baseline_configs leg (1 warmup before)")
     ap.add_argument("--backend", default=os.environ.get("KMC_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
                     help="process-group backend of the N>1 leg: nccl (= RCCL, the product) or gloo (CPU launch-path test)")
     a = ap.parse_args()
@@ -330,7 +412,8 @@ def main():
     distinct, generated = r.distinct, r.generated
     exp = expected_counts(c)
     counts_match = None if exp is None else (distinct == exp["distinct"] and generated == exp["generated"]
-                                             and r.depth == exp["depth"])
+                                             and r.depth == exp["depth"]
+                                             and (exp["levels"] is None or list(r.levels) == list(exp["levels"])))
     total_states = sum(x.distinct for x in results)
     value = total_states / dt
     S = 8 * r.state_words
@@ -346,9 +429,7 @@ def main():
     code_sha = kernel_code_sha256_of(c, symmetry=a.symmetry)
     if world == 1:   # (a level budget runs the same kernels over fewer launches; the summary's per-launch figure is then of
         #               the profiled run's own budget — the summaries name theirs in "run")
-        traffic, traffic_source = measured_traffic(code_sha)
-        if traffic and a.level_budget:
-            traffic_source += f"; per-launch average of the profiled run, this run's level budget is {a.level_budget}"
+        traffic, traffic_source = measured_traffic(code_sha, a.level_budget, r.depth)
     else:
         traffic, traffic_source = None, "PMC counters are collected for single-GPU searches only"
     # Secondary view — the seen-set's probes are uniformly random 8-byte accesses, which this memory system serves
@@ -441,7 +522,7 @@ def main():
                  r.generated_repeats))
         s_alg = alg_bytes_per_state * sr.orbit_representatives
         s_code = kernel_code_sha256_of(c, symmetry=True)
-        s_traffic, s_traffic_source = measured_traffic(s_code)
+        s_traffic, s_traffic_source = measured_traffic(s_code, None, sr.depth)
         out["orbit_counting"] = {
             "value": sum(x.distinct for x in sres) / sdt, "unit": "distinct states/s", "ms_per_step": 1e3 * sdt / a.steps,
             "time_to_exhaustive_s": sdt / a.steps, "speedup_over_plain": (dt / a.steps) / (sdt / a.steps),
@@ -456,6 +537,9 @@ def main():
                          "note": "algorithmic bytes of the STORED states (the same per-state figure) over this search's "
                                  "k_expand time; the kernel is instruction-bound here (the representative of every successor "
                                  "is the smallest of its images under the permutations: profiles/r03_symmetry.txt)"}}
+    if (world == 1 and not a.symmetry and not a.level_budget and not a.no_baseline_configs and not a.workload and not a.small):
+        # SURVEY section 8d rows "config 4" and "config 5": driver-timed here, never part of `value`
+        out["baseline_configs"] = {name: baseline_leg(name, a.config_steps, 1) for name in BASELINE_LEGS}
     if world == 1 and not a.symmetry and not a.level_budget and not a.no_cold_start:
         cs = cold_start(c)
         if cs:

@@ -96,12 +96,12 @@ def precompile_variants():
     tests run against (KMC_FAULT_DROP) — so that the GPU box spends none of its minutes in hiprtc."""
     small = dict(model="Kip320", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1)
     wide = dict(model="Kip279", n_replicas=5, log_size=1, max_records=1, max_leader_epoch=1)
-    fault = {"KMC_JIT_DEFINES": "-DKMC_FAULT_DROP=1"}
+    fault = {"KMC_JIT_DEFINES": "-DKMC_TUNING=1 -DKMC_FAULT_DROP=1"}
     golden = dict(model="Kip320", n_replicas=3, log_size=5, max_records=5, max_leader_epoch=2)
     return [(small, {"KMC_VERIFY": "1"}), (wide, {"KMC_VERIFY": "1"}), (golden, {"KMC_VERIFY": "1"}), (small, fault),
             (small, dict(fault, KMC_VERIFY="1")),
             (dict(model="AsyncIsr", n_replicas=3, log_size=2, max_leader_epoch=2), fault),
-            (small, {"KMC_JIT_DEFINES": "-DKMC_TEST_FP_BITS=10"})] + layout_variants() + symmetry_variants()   # (collisions on demand for the wide-fingerprint test)
+            (small, {"KMC_JIT_DEFINES": "-DKMC_TUNING=1 -DKMC_TEST_FP_BITS=10"})] + layout_variants() + symmetry_variants()   # (collisions on demand for the wide-fingerprint test)
 
 
 # The arrangements of the Kafka state vector (csrc/kmc_layout.h) and the two walks of k_expand's pass 2 that go with them:

@@ -24,7 +24,7 @@
 
 #include "../../include/kmc.h"
 #include "kmc_device.h"   // host-visible parts: KmcArgs, KmcLevelCtl, layout, fingerprint
-#include "kmc_sources.inc"  // generated: KMC_SRC_LAYOUT, KMC_SRC_DEVICE (the same two headers as text)
+#include "kmc_sources.inc"  // generated: KMC_SRC_DEVICE (kmc_layout.h and the parts of kmc_device.h, as text)
 
 // Levels kmc_run queues back to back before it waits (no progress callback): see run_levels.
 #define KMC_CHAIN 32
@@ -152,7 +152,7 @@ bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::strin
 }
 
 std::string strip_for_concat(const char* src) {
-    // drop '#pragma once' and the local include so the two headers can be fed to hiprtc as one file; drop `//` comments
+    // drop '#pragma once' and the local includes so the parts can be fed to hiprtc as one file; drop `//` comments
     // (line structure kept) so that the text — and with it the key of the code-object cache — only changes with the code
     std::string out, line;
     for (const char* p = src;; ++p) {
@@ -166,7 +166,7 @@ std::string strip_for_concat(const char* src) {
                     break;
                 }
             }
-            if (line.rfind("#pragma once", 0) != 0 && line.rfind("#include \"kmc_layout.h\"", 0) != 0) {
+            if (line.rfind("#pragma once", 0) != 0 && line.rfind("#include \"kmc_", 0) != 0) {
                 out += line;
             }
             out += '\n';
@@ -258,7 +258,7 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
             }
         }
     }
-    std::string src = strip_for_concat(KMC_SRC_LAYOUT) + strip_for_concat(KMC_SRC_DEVICE) + "\nKMC_INSTANTIATE(" +
+    std::string src = strip_for_concat(KMC_SRC_DEVICE) + "\nKMC_INSTANTIATE(" +
                       name + ", " + inst + ")\n";
     // ONE code object per (source, architecture, defines), whoever compiled it.  The PyTorch wheel bundles its own
     // hiprtc / comgr next to the system ROCm's (same hiprtcVersion, different LLVM builds: from round 4's source on they emit
@@ -431,15 +431,13 @@ struct kmc_handle {
 
 namespace {
 
-int qcap_wide();
-
 int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid, hipStream_t stream = nullptr) {
     KmcArgs args = a;
     unsigned lds = 0;
     if (f == h->f_expand || f == h->f_expand_verify) {  // k_expand carves its rings out of dynamic LDS
         const bool meta = (args.flags & KMC_FLAG_TRACE) || args.mode == KMC_MODE_ENUM;
         if (meta) args.flags |= KMC_FLAG_META;
-        lds = kmc_expand_lds_bytes(h->W, meta, h->cfg.symmetry != 0, qcap_wide());
+        lds = kmc_expand_lds_bytes(h->W, meta, h->cfg.symmetry != 0);
     }
     size_t size = sizeof(args);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -480,14 +478,6 @@ uint64_t max_fanout(const kmc_handle* h) {
         return N + N + E1 * N + N * N + NP + N + N + NP * E1 + NP + (h->cfg.model == KMC_KIP320_FIRST_TRY ? NP : 0);
     }
     }
-}
-
-// The stager's capacity for wide states is a JIT define of the code object (KMC_QCAP_WIDE, kmc_device.h): the host sizes the
-// dynamic LDS of a launch with the value the kernels were specialised with.
-int qcap_wide() {
-    if (const char* d = getenv("KMC_JIT_DEFINES"))
-        if (const char* p = strstr(d, "-DKMC_QCAP_WIDE=")) return atoi(p + 16);
-    return KMC_QCAP_WIDE;
 }
 
 unsigned expand_grid(kmc_handle* h, uint64_t n) {
@@ -938,11 +928,11 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     }
     int occ = 0;
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->f_expand, KMC_BLOCK,
-                                                           kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0, cfg->symmetry != 0, qcap_wide())) == hipSuccess && occ > 0)
+                                                           kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0, cfg->symmetry != 0)) == hipSuccess && occ > 0)
         h->blocks_per_cu = occ > 8 ? 8 : occ;
     {   // the occupancy query may admit a block more than really fits when LDS is the limit
         // (5 x 32 KiB = all 160 KiB was reported resident, ran as 4 + a queued 5th: 69 ms vs 55 ms)
-        const unsigned lds = kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0, cfg->symmetry != 0, qcap_wide());
+        const unsigned lds = kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0, cfg->symmetry != 0);
         const int by_lds = (int)((160u * 1024u - 1024u) / (lds ? lds : 1u));
         if (by_lds >= 1 && h->blocks_per_cu > by_lds) h->blocks_per_cu = by_lds;
     }

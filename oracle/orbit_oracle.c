@@ -16,6 +16,11 @@
  *   gcc -O2 -pthread -std=gnu11 -o oracle/orbit_oracle oracle/orbit_oracle.c
  *   oracle/orbit_oracle --model Kip320 --N 7 --L 8 --R 8 --E 3 --levels 14 --threads 8 [--last-level-fp] [--table-log2 28]
  * prints one JSON object: levels (weighted = the plain search's), stored per level, distinct, generated, action_generated.
+ *
+ * --compact (round 5): the same EXACT search with the arena bit-packed — every canonical byte in just the bits its range
+ * needs (22 bytes per stored state instead of 48 at Kip320 3/6/6/3) and a table of 32-bit indices — so that the 1.08 G orbit
+ * representatives of Kip320 3/6/6/3 (6.45 G states) fit this container's 62 GB: 23.7 GB of states + 8.6 GB of table.  Still
+ * full states compared bit for bit: no fingerprint anywhere.
  */
 #include "kmc_oracle.c"
 
@@ -36,6 +41,10 @@ typedef struct {
     _Atomic uint64_t cursor;
     uint64_t lo, hi;
     int overflow;
+    /* --compact */
+    int compact, crs;          /* crs = bytes of a packed record (state fields + the stabiliser's order) */
+    uint8_t width[KMO_MAXSB + 2];  /* bits of canonical byte i (sb: stab low byte, sb + 1: unused = 0) */
+    _Atomic uint32_t *table32; /* 0 empty, 1 busy, else index + 2 */
 } OE;
 
 typedef struct {
@@ -125,8 +134,83 @@ static int o_canon(const P *p, const uint8_t *s, uint8_t *c) {
 
 static inline uint64_t o_hash(const uint8_t *b, int n) { return hash_bytes_strong(b, n); }
 
+/* ---- --compact: canonical bytes <-> packed bits (every field in the bits its range needs) ---- */
+static int o_bits(unsigned maxv) { int b = 0; while (maxv >> b) b++; return b; }
+static void o_make_widths(OE *e) {
+    const P *p = &e->p;
+    const int N = p->N, L = p->L, E = p->E, R = p->R;
+    int at = 0, total = 0;
+    for (int r = 0; r < N; r++) {
+        e->width[at++] = (uint8_t)o_bits((unsigned)L);           /* endOffset 0..L */
+        e->width[at++] = (uint8_t)o_bits((unsigned)L);           /* hw */
+        e->width[at++] = (uint8_t)o_bits((unsigned)E + 1);       /* leaderEpoch + 1: 0..E+1 */
+        e->width[at++] = (uint8_t)o_bits((unsigned)N);           /* leader + 1: 0..N */
+        e->width[at++] = (uint8_t)N;                             /* isr mask */
+        for (int o = 0; o < L; o++) e->width[at++] = (uint8_t)o_bits((unsigned)(R * (E + 1)));  /* 0 = Nil, 1 + id * (E+1) + epoch */
+    }
+    e->width[at++] = (uint8_t)o_bits((unsigned)R);               /* nextRecordId 0..R */
+    e->width[at++] = (uint8_t)o_bits((unsigned)E + 1);           /* nextLeaderEpoch 0..E+1 */
+    e->width[at++] = (uint8_t)o_bits((unsigned)E + 1);           /* quorum.leaderEpoch + 1 */
+    e->width[at++] = (uint8_t)o_bits((unsigned)N);               /* quorum.leader + 1 */
+    e->width[at++] = (uint8_t)N;                                 /* quorum.isr */
+    for (int q = 0; q < p->EP1; q++) { e->width[at++] = (uint8_t)o_bits((unsigned)N); e->width[at++] = (uint8_t)N; }
+    if (at != e->sb) { fprintf(stderr, "orbit_oracle: width table does not cover the state (%d of %d bytes)\n", at, e->sb); exit(2); }
+    e->width[at++] = (uint8_t)o_bits((unsigned)e->nf);           /* |Stab| <= N! */
+    for (int i = 0; i < at; i++) total += e->width[i];
+    e->crs = (total + 7) / 8;
+}
+/* returns 0 when a byte does not fit its width (a TypeOk violation would: the search stops there, loudly) */
+static int o_pack(const OE *e, const uint8_t *st, int stab, uint8_t *out) {
+    memset(out, 0, (size_t)e->crs);
+    int bit = 0;
+    for (int i = 0; i <= e->sb; i++) {
+        const unsigned v = i < e->sb ? st[i] : (unsigned)stab;
+        const int w = e->width[i];
+        if (v >> w) return 0;
+        for (int b = 0; b < w; b++, bit++)
+            if (v >> b & 1u) out[bit >> 3] |= (uint8_t)(1u << (bit & 7));
+    }
+    return 1;
+}
+static int o_unpack(const OE *e, const uint8_t *in, uint8_t *st) {
+    int bit = 0, stab = 0;
+    for (int i = 0; i <= e->sb; i++) {
+        unsigned v = 0;
+        const int w = e->width[i];
+        for (int b = 0; b < w; b++, bit++) v |= (unsigned)(in[bit >> 3] >> (bit & 7) & 1u) << b;
+        if (i < e->sb) st[i] = (uint8_t)v; else stab = (int)v;
+    }
+    return stab;
+}
+/* --compact: returns 1 when st (a representative) is new.  The stabiliser's order is a function of the state, so the packed
+ * record (state bits, then |Stab|) of an equal state is equal in every bit: one memcmp decides. */
+static int o_insert_compact(OE *e, const uint8_t *st, int stab) {
+    uint8_t rec[KMO_MAXSB + 8];
+    if (!o_pack(e, st, stab, rec)) { fprintf(stderr, "orbit_oracle: a field exceeds its range (TypeOk broken?)\n"); e->overflow = 1; return 0; }
+    const uint64_t h = o_hash(st, e->sb);
+    uint64_t i = h & (e->tcap - 1);
+    for (uint64_t probes = 0;; ) {
+        if (probes > e->tcap) { e->overflow = 1; return 0; }
+        uint32_t v = atomic_load_explicit(&e->table32[i], memory_order_acquire);
+        if (v == 0) {
+            uint32_t exp = 0;
+            if (!atomic_compare_exchange_strong(&e->table32[i], &exp, 1u)) continue;
+            const uint64_t idx = atomic_fetch_add(&e->nstates, 1);
+            if (idx >= e->cap_states || idx + 2 > 0xFFFFFFFFull) { e->overflow = 1; atomic_store(&e->table32[i], 0u); return 0; }
+            memcpy(e->arena + idx * (uint64_t)e->crs, rec, (size_t)e->crs);
+            atomic_store_explicit(&e->table32[i], (uint32_t)(idx + 2), memory_order_release);
+            return 1;
+        }
+        if (v == 1) continue;
+        if (memcmp(e->arena + (uint64_t)(v - 2) * (uint64_t)e->crs, rec, (size_t)e->crs) == 0) return 0;
+        probes++;
+        i = (i + 1) & (e->tcap - 1);
+    }
+}
+
 /* returns 1 when st (a representative) is new; records it with its stabiliser's order */
 static int o_insert(OE *e, const uint8_t *st, int stab) {
+    if (e->compact) return o_insert_compact(e, st, stab);
     const int sb = e->sb;
     const uint64_t h = o_hash(st, sb);
     uint64_t i = h & (e->tcap - 1);
@@ -188,8 +272,11 @@ static void *o_worker(void *a) {
         if (lo >= e->hi) break;
         const uint64_t hi = lo + 256 < e->hi ? lo + 256 : e->hi;
         for (uint64_t idx = lo; idx < hi; idx++) {
-            const uint8_t *r = e->arena + idx * (uint64_t)e->rs;
-            const int stab = r[e->sb] | (r[e->sb + 1] << 8);
+            uint8_t ub[KMO_MAXSB];
+            const uint8_t *r;
+            int stab;
+            if (e->compact) { stab = o_unpack(e, e->arena + idx * (uint64_t)e->crs, ub); r = ub; }
+            else { r = e->arena + idx * (uint64_t)e->rs; stab = r[e->sb] | (r[e->sb + 1] << 8); }
             w->w = e->nf / (uint64_t)stab;
             w->nsucc = 0;
             for (int inv = 0; inv < 4; inv++)
@@ -208,7 +295,7 @@ static void *o_map(uint64_t bytes) {
 
 int main(int argc, char **argv) {
     kmo_config c = {.model = M_KIP320, .N = 3, .L = 2, .R = 2, .E = 1, .K = 2, .MaxId = 10, .inv_mask = 0, .threads = 4};
-    int levels = 0, last_fp = 0, tlog = 26, flog = 0;
+    int levels = 0, last_fp = 0, tlog = 26, flog = 0, compact = 0;
     uint32_t inv_mask = 0;
     uint64_t cap_states = 0;
     static const char *names[] = {"IdSequence", "FiniteReplicatedLog", "KafkaTruncateToHighWatermark", "Kip101", "Kip279", "Kip320", "Kip320FirstTry"};
@@ -224,6 +311,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--fp-table-log2")) flog = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--max-stored")) cap_states = strtoull(argv[++i], NULL, 0);
         else if (!strcmp(argv[i], "--last-level-fp")) last_fp = 1;
+        else if (!strcmp(argv[i], "--compact")) compact = 1;
         else if (!strcmp(argv[i], "--inv")) inv_mask = (uint32_t)strtoul(argv[++i], NULL, 0);
         else { fprintf(stderr, "unknown arg %s\n", argv[i]); return 2; }
     }
@@ -236,8 +324,16 @@ int main(int argc, char **argv) {
     for (int i = 2; i <= c.N; i++) e->nf *= (uint64_t)i;
     e->tcap = 1ull << tlog;
     e->cap_states = cap_states ? cap_states : e->tcap / 2;
-    e->arena = o_map(e->cap_states * (uint64_t)e->rs);
-    e->table = o_map(e->tcap * 8);
+    if (compact && last_fp) { fprintf(stderr, "--compact is the exact search: no --last-level-fp\n"); return 2; }
+    e->compact = compact;
+    if (compact) {
+        o_make_widths(e);
+        e->arena = o_map(e->cap_states * (uint64_t)e->crs);
+        e->table32 = o_map(e->tcap * 4);
+    } else {
+        e->arena = o_map(e->cap_states * (uint64_t)e->rs);
+        e->table = o_map(e->tcap * 8);
+    }
     if (last_fp) { e->fcap = 1ull << (flog ? flog : tlog + 2); e->fpt = o_map(e->fcap * 8); }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -280,9 +376,9 @@ int main(int argc, char **argv) {
         if (e->fp_mode) break;
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
-    printf("{\"model\": \"%s\", \"N\": %d, \"L\": %d, \"R\": %d, \"E\": %d, \"orbit_counting\": true, \"exhausted\": %s, \"last_level_fingerprints_only\": %s, "
+    printf("{\"model\": \"%s\", \"N\": %d, \"L\": %d, \"R\": %d, \"E\": %d, \"orbit_counting\": true, \"exhausted\": %s, \"last_level_fingerprints_only\": %s, \"compact_exact\": %s, \"stored_record_bytes\": %d, "
            "\"distinct\": %llu, \"generated\": %llu, \"depth\": %d, \"stored\": %llu, \"deadlock_states\": %llu, \"levels\": [",
-           names[c.model], c.N, c.L, c.R, c.E, exhausted ? "true" : "false", last_fp ? "true" : "false", (unsigned long long)distinct,
+           names[c.model], c.N, c.L, c.R, c.E, exhausted ? "true" : "false", last_fp ? "true" : "false", compact ? "true" : "false", compact ? e->crs : e->rs, (unsigned long long)distinct,
            (unsigned long long)generated, nl, (unsigned long long)stored, (unsigned long long)deadlocks);
     for (int i = 0; i < nl; i++) printf("%s%llu", i ? ", " : "", (unsigned long long)lv_w[i]);
     printf("], \"stored_per_level\": [");

@@ -78,41 +78,8 @@ template <class M> bool kind_major_check(const u64* s, int* checked, int* bad) {
     }
 }
 
-// Guard groups (KmcKafka::group_pre, pass 1 of the wide configurations): on one state, every ENABLED instance's group
-// condition must hold (a group whose condition fails in all 64 lanes is skipped by the kernel: a false negative would lose
-// successors).  -> instances checked / enabled instances whose group condition is false; -1 = the model has no groups.
-template <class M> int group_check(const u64* s, int* enabled, int* bad) {
-    *enabled = *bad = 0;
-    if constexpr (!M::KIND_MAJOR) {
-        return -1;
-    } else {
-        static_assert(M::groups_partition_the_instances(), "guard groups must list every action instance exactly once");
-        typename M::Pre pre = M::extract(s);
-        int checked = 0;
-        kmc_static_for<0, M::NGROUPS>([&](auto GG) {
-            constexpr int g = decltype(GG)::value;
-            const u32 c = M::template group_pre<g>(pre);
-            kmc_static_for<0, M::group_size(g)>([&](auto JJ) {
-                constexpr int i = M::group_inst(g, decltype(JJ)::value);
-                static_assert(M::group_of(i) == g, "group_of / group_inst disagree");
-                u64 t[M::W];
-                int kind = 0;
-                u32 extra = 0;
-                const u32 en = M::template inst<i>(pre, s, t, kind, extra);
-                ++checked;
-                if (en) {
-                    ++*enabled;
-                    if (!c) ++*bad;
-                }
-            });
-        });
-        return checked;
-    }
-}
-
 template <class M> struct Ops {
     static int kmcheck(const u64* s, int* checked, int* bad) { return kind_major_check<M>(s, checked, bad) ? 1 : 0; }
-    static int grpcheck(const u64* s, int* enabled, int* bad) { return group_check<M>(s, enabled, bad); }
     static int succ(const u64* s, u64* out, int cap) { return successors<M>(s, out, cap); }
     static u32 violated(const u64* s, u32 mask) { return M::violated(s, mask); }
     static void init(u64* w) { M::init(w); }
@@ -144,25 +111,23 @@ struct Entry {
     int (*words)();
     int (*kmcheck)(const u64*, int*, int*);
     int (*canon)(const u64*, u64*);
-    int (*grpcheck)(const u64*, int*, int*);
 };
 
 #define KAFKA_LM(MODEL, N, L, R, E, LM) \
     {MODEL, N, L, R, E, 0, LM, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::succ, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::violated, \
      Ops<KmcKafka<MODEL, N, L, R, E, LM>>::init, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::in_model, \
      Ops<KmcKafka<MODEL, N, L, R, E, LM>>::words, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::kmcheck, \
-     Ops<KmcKafka<MODEL, N, L, R, E, LM>>::canon, Ops<KmcKafka<MODEL, N, L, R, E, LM>>::grpcheck}
+     Ops<KmcKafka<MODEL, N, L, R, E, LM>>::canon}
 #define KAFKA(MODEL, N, L, R, E) KAFKA_LM(MODEL, N, L, R, E, KMC_LAYOUT_AUTO)
 #define ASYNC(N, MO, V) \
     {KMC_MODEL_ASYNC_ISR, N, MO, 0, V, 0, 0, Ops<KmcAsyncIsr<N, MO, V>>::succ, Ops<KmcAsyncIsr<N, MO, V>>::violated, \
      Ops<KmcAsyncIsr<N, MO, V>>::init, Ops<KmcAsyncIsr<N, MO, V>>::in_model, Ops<KmcAsyncIsr<N, MO, V>>::words, \
-     Ops<KmcAsyncIsr<N, MO, V>>::kmcheck, Ops<KmcAsyncIsr<N, MO, V>>::canon, Ops<KmcAsyncIsr<N, MO, V>>::grpcheck}
+     Ops<KmcAsyncIsr<N, MO, V>>::kmcheck, Ops<KmcAsyncIsr<N, MO, V>>::canon}
 #define FRL(N, L, K) \
     {KMC_MODEL_FINITE_REPLICATED_LOG, N, L, 0, 0, K, 0, Ops<KmcFiniteReplicatedLog<N, L, K>>::succ, \
      Ops<KmcFiniteReplicatedLog<N, L, K>>::violated, Ops<KmcFiniteReplicatedLog<N, L, K>>::init, \
      Ops<KmcFiniteReplicatedLog<N, L, K>>::in_model, Ops<KmcFiniteReplicatedLog<N, L, K>>::words, \
-     Ops<KmcFiniteReplicatedLog<N, L, K>>::kmcheck, Ops<KmcFiniteReplicatedLog<N, L, K>>::canon, \
-     Ops<KmcFiniteReplicatedLog<N, L, K>>::grpcheck}
+     Ops<KmcFiniteReplicatedLog<N, L, K>>::kmcheck, Ops<KmcFiniteReplicatedLog<N, L, K>>::canon}
 
 const Entry TABLE[] = {
     KAFKA(KMC_MODEL_TRUNCATE_TO_HW, 3, 2, 2, 2), KAFKA(KMC_MODEL_KIP101, 3, 2, 2, 2), KAFKA(KMC_MODEL_KIP279, 3, 2, 2, 2),
@@ -274,11 +239,6 @@ int emu_configs(int i, int* out7) {
         out7[0] = e.model; out7[1] = e.N; out7[2] = e.L; out7[3] = e.R; out7[4] = e.E; out7[5] = e.K; out7[6] = e.lm;
     }
     return n;
-}
-// guard groups on one state: returns the instances checked (-1: no groups / unknown config), *enabled / *bad as group_check
-int emu_group_check(int model, int N, int L, int R, int E, int K, const u64* state, int* enabled, int* bad) {
-    const Entry* e = find(model, N, L, R, E, K);
-    return e ? e->grpcheck(state, enabled, bad) : -1;
 }
 // selects which compiled arrangement (KMC_LAYOUT_*) of a Kafka configuration the calls below mean
 void emu_layout(int lm) { g_lm = lm; }

@@ -7,8 +7,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "host_emu.cpp")
 LIB = os.path.join(HERE, "_host_emu.so")
-DEPS = [SRC, os.path.join(HERE, "..", "kafka_specification_amd", "csrc", "kmc_device.h"),
-        os.path.join(HERE, "..", "kafka_specification_amd", "csrc", "kmc_layout.h")]
+CSRC = os.path.join(HERE, "..", "kafka_specification_amd", "csrc")
+DEPS = [SRC] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.startswith("kmc_") and f.endswith(".h")]
 _lib = None
 
 
@@ -37,7 +37,6 @@ def lib():
         l.emu_canon.argtypes = six + [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         l.emu_canon_generic.argtypes = six + [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         l.emu_kind_major_check.argtypes = six + [C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        l.emu_group_check.argtypes = six + [C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = l
     return _lib
 
@@ -110,15 +109,6 @@ def kind_major_check(cfg6, words):
     rc = lib().emu_kind_major_check(*cfg6[:6], (C.c_uint64 * W)(*words), C.byref(checked), C.byref(bad))
     assert rc >= 0
     return bool(rc), checked.value, bad.value
-
-
-def group_check(cfg6, words):
-    """(instances checked or -1, enabled instances, enabled instances whose group's necessary condition is FALSE): the guard
-    groups of the wide configurations' pass 1 (KmcKafka::group_pre) on one state."""
-    W = lib().emu_words(*cfg6[:6])
-    enabled, bad = C.c_int(0), C.c_int(0)
-    n = lib().emu_group_check(*cfg6[:6], (C.c_uint64 * W)(*words), C.byref(enabled), C.byref(bad))
-    return n, enabled.value, bad.value
 
 
 def kafka_reference(cfg6, words, mask):

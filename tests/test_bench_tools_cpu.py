@@ -40,8 +40,13 @@ def test_traffic_is_quoted_only_for_the_machine_code_it_was_measured_on(bench):
     for f, j in stamped:   # newest round first wins for a given code
         first.setdefault(j["kernel_code_sha256"], (f, j))
     for code, (f, j) in first.items():
-        t, src = bench.measured_traffic(code)
+        run = j.get("run", {})
+        t, src = bench.measured_traffic(code, run.get("level_budget"), run.get("depth"))
         assert t == j["hbm_bytes_per_launch"] and os.path.relpath(f, ROOT) in src and code[:16] in src
+        # ... and only for the SEARCH it was measured over (a per-launch average over ten geometrically growing
+        # levels is not the per-launch traffic of a run with another budget)
+        t_other, why_other = bench.measured_traffic(code, (run.get("level_budget") or 0) + 3, None)
+        assert t_other is None and "another search" in why_other
         if "FETCH_SIZE_bytes_as_reported" in j and "atomic_bytes" in j:
             # the DRAM-unit counters, not FETCH_SIZE: reads are twice what FETCH_SIZE reports on gfx950
             assert abs(j["read_bytes"] / j["FETCH_SIZE_bytes_as_reported"] - 2.0) < 0.02

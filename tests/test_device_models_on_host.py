@@ -79,9 +79,6 @@ def test_device_model_matches_oracle_along_random_walks(cfg6):
                 want = sorted(kmo.successors(ocfg, s, sb))
                 got = sorted((k, mc.unpack(t)) for (k, t) in host_emu.successors(cfg6, w))
                 assert got == want
-                if name != "AsyncIsr":   # the guard groups of the wide configurations' pass 1 never hide an enabled instance
-                    n_checked, _enabled, hidden = host_emu.group_check(cfg6, w)
-                    assert hidden == 0 and (n_checked > 0 or n_checked == -1)
                 for inv in range(n_inv):
                     assert bool(host_emu.violated(cfg6, w, 1 << inv)) == (not kmo.check_invariant(ocfg, inv, s))
                 nxt = [t for (_a, t) in want

@@ -33,7 +33,7 @@ def test_conservation_holds_on_every_level_of_a_healthy_run():
 
 
 def test_a_lost_successor_trips_the_conservation_check(monkeypatch):
-    monkeypatch.setenv("KMC_JIT_DEFINES", "-DKMC_FAULT_DROP=1")
+    monkeypatch.setenv("KMC_JIT_DEFINES", "-DKMC_TUNING=1 -DKMC_FAULT_DROP=1")
     with pytest.raises(KmcError, match="conservation violated.*lost or invented successors"):
         run(SMALL)
     with pytest.raises(KmcError, match="conservation violated"):   # the progress-callback path checks level by level too
@@ -42,7 +42,7 @@ def test_a_lost_successor_trips_the_conservation_check(monkeypatch):
 
 
 def test_a_lost_successor_trips_the_verify_checksum_but_not_the_old_counts(monkeypatch):
-    monkeypatch.setenv("KMC_JIT_DEFINES", "-DKMC_FAULT_DROP=1")
+    monkeypatch.setenv("KMC_JIT_DEFINES", "-DKMC_TUNING=1 -DKMC_FAULT_DROP=1")
     monkeypatch.setenv("KMC_VERIFY", "1")
     # the second build runs in DRY mode, where the fault is not injected: its successors are complete, the first build's
     # are one short — "generated / deadlock / violation counts" (all the round-2 check compared) still agree
@@ -52,7 +52,7 @@ def test_a_lost_successor_trips_the_verify_checksum_but_not_the_old_counts(monke
 
 def test_a_lost_successor_is_caught_in_the_sharded_step_interface_too(monkeypatch):
     from kafka_specification_amd.sharded import check_loopback
-    monkeypatch.setenv("KMC_JIT_DEFINES", "-DKMC_FAULT_DROP=1")
+    monkeypatch.setenv("KMC_JIT_DEFINES", "-DKMC_TUNING=1 -DKMC_FAULT_DROP=1")
     cfg = CheckerConfig(model="AsyncIsr", n_replicas=3, log_size=2, max_leader_epoch=2, invariants=("ValidHighWatermark",),
                         table_capacity=1 << 20, frontier_capacity=1 << 18)
     with pytest.raises(KmcError, match="conservation violated"):
@@ -121,7 +121,7 @@ def test_wide_table_tells_colliding_fingerprints_apart():
     one compares the untouched 64-bit check word, walks past every collision and finds all of them."""
     import os
     o = kmo.Run(kmo.make_config("Kip320", N=3, L=2, R=2, E=1, invariants=("TypeOk",)))
-    os.environ["KMC_JIT_DEFINES"] = "-DKMC_TEST_FP_BITS=10"
+    os.environ["KMC_JIT_DEFINES"] = "-DKMC_TUNING=1 -DKMC_TEST_FP_BITS=10"
     try:
         narrow = run(SMALL)
         wide = run(SMALL, wide_fingerprint=True)
@@ -142,7 +142,7 @@ def test_wide_table_across_shards_loses_no_colliding_state_to_the_sender_side_fi
     from dataclasses import replace
     from kafka_specification_amd import sharded
     o = kmo.Run(kmo.make_config("Kip320", N=3, L=2, R=2, E=1, invariants=("TypeOk",)))
-    os.environ["KMC_JIT_DEFINES"] = "-DKMC_TEST_FP_BITS=10"
+    os.environ["KMC_JIT_DEFINES"] = "-DKMC_TUNING=1 -DKMC_TEST_FP_BITS=10"
     try:
         cfg = replace(CheckerConfig(**SMALL), wide_fingerprint=True, table_capacity=1 << 18, frontier_capacity=1 << 16,
                       send_capacity=1 << 14)

@@ -78,26 +78,6 @@ def test_device_model_templates_equal_the_executed_reference_state_by_state(entr
             ors.compare(m, fx, i, recs, host_emu.violated(cfg6, w, mask), "device templates on the host")
 
 
-@pytest.mark.parametrize("entry", KAFKA_ENTRIES, ids=ors.ids)
-def test_guard_groups_never_hide_an_enabled_instance(entry):
-    """Pass 1 of the wide configurations evaluates the guards group by group and SKIPS a group whose necessary condition
-    (KmcKafka::group_pre: the request of that epoch names that leader / that replica presumes leadership) fails in every lane
-    of the tile.  On every state of the fixtures — the bindings the bench runs, deep states — every enabled instance's group
-    condition holds, and the number of enabled instances is the reference's number of successors (less the twice-generated)."""
-    fn, m = entry
-    fx = ors.load(fn)
-    cfg6 = (kmo.MODELS[m["module"]], m["N"], m["L"], m["R"], m["E"], 0)
-    consts = dict(n_replicas=m["N"], log_size=m["L"], max_records=m["R"], max_leader_epoch=m["E"])
-    total = 0
-    with ModelChecker(CheckerConfig(model=m["module"], device=-1, **consts)) as mc:
-        for i in range(0, len(fx["states"]), 2):
-            n, enabled, bad = host_emu.group_check(cfg6, mc.pack(bytes(fx["states"][i])))
-            assert n > 0 and bad == 0, f"state {bytes(fx['states'][i]).hex()}: {bad} enabled instances sit in a group whose condition is false"
-            assert enabled <= int(fx["nsucc"][i])
-            total += enabled
-    assert total > 0
-
-
 # ---- the invariants on ARBITRARY states (tests/golden/oracle_r_mutants_*.npz, make_oracle_r_mutants.py) -------------------------
 MUTANTS = ors.mutant_entries()
 

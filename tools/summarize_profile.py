@@ -11,7 +11,7 @@ d = sys.argv[1]
 out = {}
 _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _h = hashlib.sha256()
-for _f in ("kmc_layout.h", "kmc_device.h"):
+for _f in ("kmc_layout.h", "kmc_common.h", "kmc_models_small.h", "kmc_kafka.h", "kmc_symm.h", "kmc_sink.h", "kmc_kernels.h"):
     _h.update(open(os.path.join(_root, "kafka_specification_amd", "csrc", _f), "rb").read())
 out["device_source_sha256"] = _h.hexdigest()
 # ... and the identity of the machine code of the kernels the profiled run executed (.text + descriptors + metadata of the
