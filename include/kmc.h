@@ -175,14 +175,31 @@ typedef struct kmc_handle kmc_handle;
 /* Compile (or load from cache) the kernels specialised for cfg's constants, allocate the
  * table and frontiers on cfg->device.  On failure *out is NULL and kmc_last_error() explains. */
 int kmc_open(const kmc_config* cfg, kmc_handle** out);
-/* Compile-and-cache only; needs no GPU (used by the build step).  arch NULL = "gfx950". */
+/* Compile-and-cache only; needs no GPU (used by the build step).  arch NULL = "gfx950".
+ * The kernels of one configuration live in three cached code objects — the search's own (k_expand for one GPU with the small
+ * kernels around it: kmc_run needs nothing else), k_expand for the level-step interface (owner bucketing: kmc_step_*) and
+ * k_expand as an enumerator (kmc_successors, trace replay) — the last two joining a handle when first asked for.
+ * kmc_precompile builds all three; kmc_precompile_mode one of them (mode 0 / 1 / 2 in that order, -1 = all), so that a build
+ * script can spread them over its workers. */
 int kmc_precompile(const kmc_config* cfg, const char* arch);
+int kmc_precompile_mode(const kmc_config* cfg, const char* arch, int32_t mode);
 /* Path of the cached code object cfg's kernels are loaded from (specialised first if absent; no GPU needed).  A profile
  * records a hash of its kernels' machine code, so that a number is quoted only for the code it was measured on. */
 int kmc_code_object_path(const kmc_config* cfg, const char* arch, char* out, uint64_t cap);
 /* Whole breadth-first search on the device; cb (may be NULL) is called once per level. */
 int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user);
 int kmc_result_get(kmc_handle* h, kmc_result* out);
+/* Where the wall time of a handle went BESIDES the search (what a front end's user waits for on top of kmc_result.seconds_total;
+ * SURVEY 8d "wall time-to-exhaustive"): filled by kmc_open and the first kmc_run. */
+typedef struct kmc_timing {
+    double hip_init_s;      /* first HIP call of the process: runtime + device initialisation (0 when another handle paid it) */
+    double code_object_s;   /* reading (or, cache cold, specialising) the code object and loading it into the device */
+    double alloc_s;         /* hipMalloc / hipHostMalloc of the seen-set, frontiers, control blocks */
+    double first_clear_s;   /* the first run's clear of the seen-set [+ predecessor table]: first touch of freshly mapped HBM */
+    double open_s;          /* kmc_open, whole */
+    uint64_t device_bytes;  /* allocated on the device by kmc_open */
+} kmc_timing;
+int kmc_timing_get(kmc_handle* h, kmc_timing* out);
 /* TLC -checkpoint / -recover analogues [TLC-recall].  Save after a run stopped early (max_levels):
  * the fingerprint table, the current frontier and all counters go to `path`.  Load into a handle
  * opened with the same constants, hash seed and capacities, then kmc_resume continues the

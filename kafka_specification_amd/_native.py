@@ -63,6 +63,11 @@ class KmcLevelInfo(C.Structure):
                 ("error_flags", C.c_uint32), ("pad_", C.c_uint32)]
 
 
+class KmcTiming(C.Structure):
+    _fields_ = [("hip_init_s", C.c_double), ("code_object_s", C.c_double), ("alloc_s", C.c_double), ("first_clear_s", C.c_double),
+                ("open_s", C.c_double), ("device_bytes", C.c_uint64)]
+
+
 class KmcResult(C.Structure):
     _fields_ = [
         ("generated", C.c_uint64), ("distinct", C.c_uint64), ("depth", C.c_uint64), ("queue_left", C.c_uint64),
@@ -83,9 +88,11 @@ _H = C.c_void_p
 SYMBOLS = [
     ("kmc_open", C.c_int, [C.POINTER(KmcConfig), C.POINTER(_H)]),
     ("kmc_precompile", C.c_int, [C.POINTER(KmcConfig), C.c_char_p]),
+    ("kmc_precompile_mode", C.c_int, [C.POINTER(KmcConfig), C.c_char_p, C.c_int32]),
     ("kmc_code_object_path", C.c_int, [C.POINTER(KmcConfig), C.c_char_p, C.c_char_p, C.c_uint64]),
     ("kmc_run", C.c_int, [_H, PROGRESS_CB, C.c_void_p]),
     ("kmc_result_get", C.c_int, [_H, C.POINTER(KmcResult)]),
+    ("kmc_timing_get", C.c_int, [_H, C.POINTER(KmcTiming)]),
     ("kmc_checkpoint_save", C.c_int, [_H, C.c_char_p]),
     ("kmc_checkpoint_load", C.c_int, [_H, C.c_char_p]),
     ("kmc_resume", C.c_int, [_H, PROGRESS_CB, C.c_void_p]),

@@ -43,7 +43,7 @@ class CheckerConfig:
     symmetry: bool = False                  # orbit counting: store / expand one state per orbit of the permutations of Replicas,
                                             # weigh every count by the orbit's size — the plain search's numbers (TLC without a
                                             # SYMMETRY set) from ~1/|Replicas|! of the probes.  Kafka family and
-                                            # FiniteReplicatedLog, at most 7 replicas (KMC_SYMMETRY_MAX_REPLICAS), one GPU
+                                            # FiniteReplicatedLog, at most 7 replicas (KMC_SYMMETRY_MAX_REPLICAS); one GPU or frontier-sharded (sharded.py)
 
     def to_native(self) -> nat.KmcConfig:
         if self.model not in nat.MODELS:
@@ -93,10 +93,11 @@ class CheckResult:
     orbit_representatives: int = 0   # CheckerConfig.symmetry: the states actually stored and expanded (else = distinct)
 
 
-def precompile(cfg: CheckerConfig, arch: str = "gfx950") -> None:
-    """Specialise + cache the kernels for cfg; needs the HIP compiler but no GPU."""
+def precompile(cfg: CheckerConfig, arch: str = "gfx950", mode: int = -1) -> None:
+    """Specialise + cache the kernels for cfg; needs the HIP compiler but no GPU.  mode: -1 all three code objects of the
+    configuration, 0 the search's own, 1 k_expand for the level-step interface, 2 k_expand as an enumerator (include/kmc.h)."""
     c = cfg.to_native()
-    nat.check(nat.lib().kmc_precompile(C.byref(c), arch.encode()))
+    nat.check(nat.lib().kmc_precompile_mode(C.byref(c), arch.encode(), mode))
 
 
 def code_object_path(cfg: CheckerConfig, arch: str = "gfx950") -> str:
@@ -155,6 +156,12 @@ class ModelChecker:
         if self._h:
             self._lib.kmc_close(self._h)
             self._h = C.c_void_p()
+
+    def timing(self) -> dict:
+        """Where the wall time outside the search went (kmc_timing: HIP initialisation, code object, allocation, first clear)."""
+        t = nat.KmcTiming()
+        nat.check(self._lib.kmc_timing_get(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in nat.KmcTiming._fields_}
 
     def __enter__(self):
         return self

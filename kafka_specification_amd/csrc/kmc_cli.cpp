@@ -2,7 +2,7 @@
 // kafka_specification_amd/tlc.py, for hosts without Python/torch.
 //
 //   tlc [-config X.cfg] [-deadlock] [-continue] [-workers N] [-fp SEED] [-fp128] [-symmetry] [-fpcheck] [-verify] [-force] [-table SLOTS]
-//       [-frontier STATES] [-device D] [-notrace] Spec.tla
+//       [-frontier STATES] [-device D] [-notrace] [-v] Spec.tla
 //
 // [TLC-recall] flag names and output lines follow tlc2.TLC; TLC itself is not part of the
 // reference repository.  The module name selects one of the lowered models; constants
@@ -22,6 +22,12 @@
 #include <vector>
 
 #include "../../include/kmc.h"
+
+static double wall_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 namespace {
 
@@ -422,7 +428,8 @@ int main(int argc, char** argv) {
     memset(&c, 0, sizeof c);
     c.n_shards = 1;
     c.keep_trace = 1;
-    bool no_deadlock = false, fpcheck = false, force = false;
+    bool no_deadlock = false, fpcheck = false, force = false, verbose = false;
+    const double t_main0 = wall_s();
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&](const char* what) -> const char* {
@@ -442,6 +449,7 @@ int main(int argc, char** argv) {
         else if (a == "-fp128") c.wide_fingerprint = 1;  // 128-bit seen-set entries: fingerprint + independent check word
         else if (a == "-symmetry") c.symmetry = 1;  // orbit counting: one stored state per orbit of the permutations of Replicas
         else if (a == "-force") force = true;
+        else if (a == "-v") verbose = true;   // where the wall time went: start-up (HIP, code object, allocation, first touch), search, teardown
         else if (a == "-verify") setenv("KMC_VERIFY", "1", 1);  // every level is regenerated by a second build of the kernels
         else if (const char* why = tlc_ignored_flag(a)) fprintf(stderr, "Note: %s is accepted for compatibility and ignored (%s)\n", a.c_str(), why);
         else if (const char* why = tlc_ignored_with_value(a)) {
@@ -557,10 +565,16 @@ int main(int argc, char** argv) {
     printf("Running breadth-first search Model-Checking with fp seed %llu on GPU %d.\n", (unsigned long long)c.hash_seed, c.device);
     printf("Computing initial states...\n");
     kmc_handle* h = nullptr;
+    const double t_open0 = wall_s();
     if (kmc_open(&c, &h) != KMC_OK) { fprintf(stderr, "Error: %s\n", kmc_last_error()); return 3; }
+    const double t_run0 = wall_s();
     if (kmc_run(h, on_level, nullptr) != KMC_OK) { fprintf(stderr, "Error: %s\n", kmc_last_error()); kmc_close(h); return 3; }
+    const double t_run1 = wall_s();
     kmc_result r;
     kmc_result_get(h, &r);
+    kmc_timing tm;
+    memset(&tm, 0, sizeof tm);
+    kmc_timing_get(h, &tm);
     int rc = 0;
     if (r.verdict == KMC_V_OK) {
         printf("Model checking completed. No error has been found.\n");
@@ -623,7 +637,11 @@ int main(int argc, char** argv) {
                "because two distinct states had the same fingerprint:\n");
         printf("  calculated (optimistic):  val = %.2E\n",
                (double)col_distinct * (double)(col_generated > col_distinct ? col_generated - col_distinct : 0) / std::pow(2.0, 64));
-        printf("  birthday bound on the stored fingerprints:  val = %.2E\n", (double)col_distinct * (double)col_distinct / std::pow(2.0, 65));
+        const double birthday = (double)col_distinct * (double)col_distinct / std::pow(2.0, 65);
+        printf("  birthday bound on the stored fingerprints:  val = %.2E\n", birthday);
+        if (birthday > 0.1)   // (Kip320 3/6/6/3: 6,452,700,520 states, bound 1.1 — the 64-bit search returns one state fewer)
+            printf("  Recommendation: that bound is above 0.1: counts of this size are only bit-exact with 128-bit entries - re-run with "
+                   "-fp128 (or, on the Kafka modules, -symmetry: a sixth of the stored fingerprints at three brokers).\n");
     }
     if (fpcheck) {  // a collision moves with the seed: equal counts under two seeds make a silent loss very unlikely
         kmc_close(h);
@@ -647,6 +665,17 @@ int main(int argc, char** argv) {
     }
     printf("Finished in %.3fs (%.0f distinct states/s; %.3fs in the expand kernel) at (%s)\n", r.seconds_total,
            r.distinct / (r.seconds_total > 1e-9 ? r.seconds_total : 1e-9), r.seconds_expand, now().c_str());
+    const double t_close0 = wall_s();
     kmc_close(h);
+    if (verbose) {
+        // (printed after the teardown it accounts for; kmc_timing: include/kmc.h)
+        const double t_end = wall_s();
+        printf("Wall time: %.3fs in this process = %.3fs before kmc_open (arguments, .cfg, spec revision) + %.3fs kmc_open "
+               "(HIP initialisation %.3fs, code object %.3fs, allocation of %.1f GiB %.3fs) + %.3fs kmc_run (first clear of the "
+               "seen-set %.3fs, search %.3fs) + %.3fs verdict / trace + %.3fs teardown\n",
+               t_end - t_main0, t_open0 - t_main0, t_run0 - t_open0, tm.hip_init_s, tm.code_object_s,
+               (double)tm.device_bytes / (double)(1ull << 30), tm.alloc_s, t_run1 - t_run0, tm.first_clear_s, r.seconds_total,
+               t_close0 - t_run1, t_end - t_close0);
+    }
     return rc;
 }

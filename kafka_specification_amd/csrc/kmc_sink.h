@@ -49,7 +49,7 @@ template <int W> struct KmcStager {
 #endif
     }
 
-    KMC_DEV void drain(const KmcArgs& a, u32 n) {  // the n <= 64 staged states -> next frontier
+    KMC_DEV void drain(const KmcArgsLocal& a, u32 n) {  // the n <= 64 staged states -> next frontier
         const u32 lane = kmc_lane();
         const u32 seg = blockIdx.x % KMC_SEGS;
         u64 base = 0;
@@ -68,7 +68,7 @@ template <int W> struct KmcStager {
     }
     // Stage the new states of a batch.  When they do not all fit, the first `room` of them complete the stager, it is
     // drained (always exactly 64: one atomicAdd, W coalesced 512-byte plane stores), and the rest start the next batch.
-    KMC_DEV void push(const KmcArgs& a, bool isnew, const u64* t, u32 tag = 0) {
+    KMC_DEV void push(const KmcArgsLocal& a, bool isnew, const u64* t, u32 tag = 0) {
         const u64 m = __ballot(isnew);
         if (m == 0) return;
         const u32 n = __popcll(m);
@@ -92,9 +92,9 @@ template <int W> struct KmcStager {
         }
         count = n - room;
     }
-    KMC_DEV void finish(const KmcArgs& a, bool publish_counters = true) {
+    KMC_DEV void finish(const KmcArgsLocal& a, bool publish_counters = true) {
         if (count) drain(a, count);
-        if (filtered && kmc_lane() == 0) atomicAdd(&a.ctl->send_filtered, (u64)filtered);
+        if (filtered && kmc_lane() == 0) atomicAdd(&a.ctl->send_filtered, (u64)filtered);   // (SHARDED only: 0 elsewhere)
         filtered = 0;
         if (!publish_counters) return;   // k_expand folds them into its per-block tail (kmc_expand_body)
 #if KMC_SYMM
@@ -136,7 +136,7 @@ template <class M> struct KmcSink {
     static constexpr int W = M::W;
 
     // probe/insert fp; returns true when this lane claimed the slot (the state is new)
-    static KMC_DEV bool claim(const KmcArgs& a, u64 fp, u64 meta) { return claim_from(a, fp, fp & a.table_mask, meta); }
+    static KMC_DEV bool claim(const KmcArgsLocal& a, u64 fp, u64 meta) { return claim_from(a, fp, fp & a.table_mask, meta); }
 
     // The same with 16-byte slots (KMC_FLAG_FP128): word 0 is the fingerprint and is claimed exactly as above; word 1 is a
     // second, independent 64-bit hash of the state, published by the claimer right after its CAS.  Both words sit in the same
@@ -146,7 +146,7 @@ template <class M> struct KmcSink {
     // (the claimer has not published yet, or this XCD's L2 holds the line from before it did) is re-read at the memory side
     // (an atomic, like the claim itself) until it appears; the claimer's store precedes every wait in program order, so two
     // lanes of one wave cannot wait on each other.
-    static KMC_DEV bool claim_wide(const KmcArgs& a, u64 fp, u64 chk, u64 meta) {
+    static KMC_DEV bool claim_wide(const KmcArgsLocal& a, u64 fp, u64 chk, u64 meta) {
         u64 i = fp & a.table_mask;
         const u64 max_probes = a.table_mask < (1ull << 10) ? a.table_mask : (1ull << 10);
         for (u64 probes = 0; probes <= max_probes; ++probes) {
@@ -180,7 +180,7 @@ template <class M> struct KmcSink {
         atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
         return false;
     }
-    static KMC_DEV bool claim_from(const KmcArgs& a, u64 fp, u64 i, u64 meta) {
+    static KMC_DEV bool claim_from(const KmcArgsLocal& a, u64 fp, u64 i, u64 meta) {
         // open addressing, linear probing.  Slots only ever change 0 -> fp, so a plain
         // (possibly stale) load can only mis-report "empty", which the CAS then corrects.
         // The probe chain is bounded: a table filled beyond ~95 % makes linear probing walk millions
@@ -190,10 +190,12 @@ template <class M> struct KmcSink {
         for (u64 probes = 0; probes <= max_probes; ++probes) {
             u64 v = a.table[i];
             if (v == 0) {
+#if KMC_TUNING
                 if (a.flags & KMC_FLAG_X_PLAINSTORE) {
                     a.table[i] = fp;
                     return true;
                 }
+#endif
                 v = atomicCAS(&a.table[i], 0ull, fp);
                 if (v == 0) {
                     if (a.pred) a.pred[i] = meta;
@@ -209,7 +211,7 @@ template <class M> struct KmcSink {
 
     // the narrow or the wide table, as the handle was opened (a wave-uniform branch); the check word is the same
     // fingerprint function under another seed
-    static KMC_DEV bool claim_any(const KmcArgs& a, const u64* t, u64 fp, u64 meta) {
+    static KMC_DEV bool claim_any(const KmcArgsLocal& a, const u64* t, u64 fp, u64 meta) {
         if (a.flags & KMC_FLAG_FP128) return claim_wide(a, fp, kmc_fingerprint<W>(t, a.seed ^ 0x6a09e667f3bcc908ull), meta);
         return claim(a, fp, meta);
     }
@@ -235,7 +237,7 @@ template <class M> struct KmcSink {
     // claimed: every distinct state is expanded exactly once, its fields are already extracted
     // there, and all 64 lanes hold a state to check.  (Checking winners inside the flush ran the
     // evaluation ~3x per tile with a third of the lanes useful and re-extracted every field.)
-    static KMC_DEV void report_violation(const KmcArgs& a, u32 bad, u64 fp, u32 deficit = 0) {
+    static KMC_DEV void report_violation(const KmcArgsLocal& a, u32 bad, u64 fp, u32 deficit = 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (bad >> k & 1u) {
@@ -248,7 +250,7 @@ template <class M> struct KmcSink {
     // A violating successor outside the state constraint (models with HAS_CONSTRAINT): it enters no
     // table and no frontier, so it is counted per generation and identified by its fingerprint; the
     // host fetches the state (and a parent) with an ENUM_MATCH pass over the expanded level.
-    static KMC_DEV void report_outside_violation(const KmcArgs& a, u32 bad, u64 fp) {
+    static KMC_DEV void report_outside_violation(const KmcArgsLocal& a, u32 bad, u64 fp) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (bad >> k & 1u) {
@@ -257,13 +259,15 @@ template <class M> struct KmcSink {
             }
     }
 
-    // Executed by the whole wave; lanes with valid=false only take part in the ballots.
+    // Executed by the whole wave; lanes with valid=false only take part in the ballots.  MODE is a compile-time constant: a
+    // kernel holds the code of its own mode only (and takes that mode's argument block, KmcArgsOf<MODE>).
     // KMC_SYMM: t is the orbit representative of the successor `raw` (what is fingerprinted, claimed, staged and shipped);
     // ENUM lists the successor itself with the representative's fingerprint, so that a trace replayed through kmc_successors
     // is a real behaviour whose states are FOUND by the fingerprints of their representatives.  stab = the order of t's
     // stabiliser: it travels with a new state (KmcStager) and gives the orbit's deficit.
-    static KMC_DEV void process(const KmcArgs& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta, const u64* raw = nullptr,
-                                u32 stab = 1) {
+    template <u32 MODE>
+    static KMC_DEV void process(const typename KmcArgsOf<MODE>::type& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta,
+                                const u64* raw = nullptr, u32 stab = 1) {
 #ifdef KMC_TEST_FP_BITS   // tests only: a fingerprint of that many bits, i.e. collisions on demand (the wide table's check
                           // word keeps its 64 bits) — tests/test_gpu_selfcheck_and_fp128.py
         const u64 fp = kmc_mix64((kmc_fingerprint<W>(t, a.seed) & ((1ull << (KMC_TEST_FP_BITS)) - 1)) + 0x9E3779B97F4A7C15ull) | 1ull;
@@ -271,7 +275,7 @@ template <class M> struct KmcSink {
         const u64 fp = kmc_fingerprint<W>(t, a.seed);
 #endif
         out.account(valid, fp);
-        if (a.mode == KMC_MODE_DRY) {
+        if constexpr (MODE == KMC_MODE_DRY) {
             u64 acc = fp;
             if (valid && (a.flags & KMC_FLAG_DRY_RAND)) {  // ONE load from an unrelated random slot per successor
                 acc ^= a.table[kmc_mix64(fp ^ 0xABCDEF12345ull) & a.table_mask];
@@ -289,9 +293,7 @@ template <class M> struct KmcSink {
                 if ((a.flags & KMC_FLAG_DRY_ATOM) && (fp & 0xFF) < 90) acc ^= atomicCAS(&a.table[i], fp, fp);
             }
             if (valid && acc == 0x1234567) atomicOr(&a.ctl->err, KMC_ERR_ENUM_FULL);  // keeps the work alive
-            return;
-        }
-        if (a.mode == KMC_MODE_LOCAL) {
+        } else if constexpr (MODE == KMC_MODE_LOCAL) {
             // once any wave has found the table full the level is lost anyway: stop probing so the
             // launch ends promptly instead of walking full chains: k_expand reads the flag once per tile (issued with the
             // frontier loads: -0.7 ms on the headline against a dependent L2 round trip in front of every probe batch) and
@@ -306,8 +308,11 @@ template <class M> struct KmcSink {
 #if KMC_SYMM
             out.corr_won += isnew ? KmcSymm<M>::deficit(stab) : 0u;
 #endif
-            if (!(a.flags & KMC_FLAG_X_NOSTAGE)) out.push(a, isnew, t, stab);
-        } else if (a.mode == KMC_MODE_SHARDED) {
+#if KMC_TUNING
+            if (a.flags & KMC_FLAG_X_NOSTAGE) return;
+#endif
+            out.push(a, isnew, t, stab);
+        } else if constexpr (MODE == KMC_MODE_SHARDED) {
             // successors this shard owns take the local path at once (probe, claim, stage): only
             // the (P-1)/P that belong elsewhere travel
             const u32 dst = valid ? kmc_owner(fp, a.nshards) : ~0u;
@@ -347,6 +352,7 @@ template <class M> struct KmcSink {
                 }
             }
         } else {  // KMC_MODE_ENUM
+            static_assert(MODE == KMC_MODE_ENUM, "unknown mode");
             if (valid && (!(a.flags & KMC_FLAG_ENUM_MATCH) || fp == a.match_fp)) {
                 const u64 pos = atomicAdd(&a.ctl->enum_count, 1ull);
                 if (pos < a.send_cap) {

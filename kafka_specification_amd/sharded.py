@@ -23,6 +23,7 @@ GPUs:
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import time
 from dataclasses import replace
@@ -562,7 +563,10 @@ def run_sharded(engines: Sequence, exchange, cfg: CheckerConfig, action_names: L
             # fused under the ABI: one host wait (or, for a very wide level, a pipeline of parts: RcclExchange).  `new` is the
             # global size of the last level RECORDED (the one before the level being expanded, whose statistics are still in
             # `pending`): the same on every rank, one level behind.
-            st, deliver = exchange.expand_and_exchange(engines, pending, level_states=new)
+            # (under orbit counting `new` is the WEIGHTED count, |Replicas|! times what the shards store, expand and ship: the
+            # choice between one shot and pipeline is about records on the wire, so it sees the stored representatives)
+            stored = new // math.factorial(cfg.n_replicas) if cfg.symmetry else new
+            st, deliver = exchange.expand_and_exchange(engines, pending, level_states=stored)
         elif can_expand and pipelined:
             sends = [e.expand() for e in engines]
             st, deliver = exchange.exchange(sends, pending)

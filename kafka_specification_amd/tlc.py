@@ -42,10 +42,18 @@ def collision_report(distinct: int, generated: int, wide: bool = False):
                 f"  birthday bound on the stored entries:  val = {distinct * distinct / 2.0 ** 129:.2E}"]
     opt = distinct * max(generated - distinct, 0) / 2.0 ** 64
     birthday = distinct * distinct / 2.0 ** 65
-    return ["The seen-set stores 64-bit fingerprints; estimates of the probability that not all reachable states were "
-            "checked because two distinct states had the same fingerprint:",
-            f"  calculated (optimistic):  val = {opt:.2E}",
-            f"  birthday bound on the stored fingerprints:  val = {birthday:.2E}"]
+    out = ["The seen-set stores 64-bit fingerprints; estimates of the probability that not all reachable states were "
+           "checked because two distinct states had the same fingerprint:",
+           f"  calculated (optimistic):  val = {opt:.2E}",
+           f"  birthday bound on the stored fingerprints:  val = {birthday:.2E}"]
+    if birthday > FP128_ADVICE_ABOVE:
+        # (Kip320 3/6/6/3: 6,452,700,520 states, birthday bound 1.1 — the 64-bit search returns one state fewer)
+        out.append(f"  Recommendation: that bound is above {FP128_ADVICE_ABOVE}: counts of this size are only bit-exact with 128-bit "
+                   "entries - re-run with -fp128 (or, on the Kafka modules, -symmetry: a sixth of the stored fingerprints at three brokers).")
+    return out
+
+
+FP128_ADVICE_ABOVE = 0.1
 
 
 TLC_IGNORED_FLAGS = {
@@ -105,6 +113,9 @@ def main(argv=None) -> int:
                     help="differential self-check: a second, differently compiled build of the kernels regenerates every "
                          "level and the per-action / deadlock / violation counts must agree (for constants no oracle reaches)")
     ap.add_argument("-force", action="store_true", help="check the built-in lowering although the spec text differs from it")
+    ap.add_argument("-v", action="store_true", dest="verbose",
+                    help="one more closing line: where the wall time outside the search went (HIP start-up, code object, allocation, "
+                         "first touch of the seen-set: kmc_timing)")
     # Stock TLC's other command-line switches [TLC-recall]: the ones that do not change what is checked are accepted and
     # ignored with a note (a wrapper script written for `java tlc2.TLC` keeps working); the ones that ask for another mode
     # of operation are refused — silently dropping them would answer a different question than the one asked.
@@ -204,6 +215,7 @@ def main(argv=None) -> int:
             return res, res.trace   # walked owner by owner through the shards' predecessor tables
         with ModelChecker(conf) as mc:
             res = mc.run(progress)
+            timing.update(mc.timing())
             trace = []
             if res.verdict in ("invariant",) and conf.keep_trace:
                 trace = mc.trace()
@@ -212,6 +224,7 @@ def main(argv=None) -> int:
             return res, trace
 
     second = None
+    timing = {}
     try:
         res, trace = search(cc, progress)
         if a.fpcheck:
@@ -267,6 +280,10 @@ def main(argv=None) -> int:
             rc = 13
     print(f"Finished in {res.seconds_total:.3f}s ({res.distinct / max(res.seconds_total, 1e-9):,.0f} distinct states/s; "
           f"{res.seconds_expand:.3f}s in the expand kernel) at ({_now()})")
+    if a.verbose and timing:
+        print(f"Wall time outside the search: kmc_open {timing['open_s']:.3f}s (HIP initialisation {timing['hip_init_s']:.3f}s, code "
+              f"object {timing['code_object_s']:.3f}s, allocation of {timing['device_bytes'] / 2 ** 30:.1f} GiB {timing['alloc_s']:.3f}s), "
+              f"first clear of the seen-set {timing['first_clear_s']:.3f}s")
     return rc
 
 

@@ -53,10 +53,16 @@ def test_names():
 def test_specialises_for_gfx950_without_a_gpu(tmp_path):
     cfg = CheckerConfig(model="Kip101", n_replicas=2, log_size=3, max_records=2, max_leader_epoch=1,
                         cache_dir=str(tmp_path))
-    precompile(cfg, "gfx950")
+    precompile(cfg, "gfx950", 0)       # the search's own code object ...
     files = os.listdir(tmp_path)
     assert len(files) == 1 and files[0].startswith("Kip101_N2_L3_R2_E1-gfx950-") and files[0].endswith(".hsaco")
     assert open(os.path.join(tmp_path, files[0]), "rb").read(4) == b"\x7fELF"
+    precompile(cfg, "gfx950")          # ... and all three: k_expand for the level-step interface and as an enumerator beside it
+    files = sorted(os.listdir(tmp_path), key=len)
+    assert len(files) == 3 and files[1].endswith("-enum.hsaco") and files[2].endswith("-sharded.hsaco")
+    assert all(f.startswith("Kip101_N2_L3_R2_E1-gfx950-") for f in files)
+    with pytest.raises(KmcError):
+        precompile(cfg, "gfx950", 3)
 
 
 @pytest.mark.parametrize("kw", [dict(model="Kip320", n_replicas=9), dict(model="Kip320", n_replicas=1),
@@ -259,10 +265,46 @@ def test_no_cached_expand_kernel_spills_vector_registers():
     for f in files:
         notes = subprocess.run([readelf, "--notes", f], capture_output=True, text=True).stdout
         blocks = notes.split(".name:")[1:]
+        # one k_expand per code object (round 5: a mode each — the search's, `-sharded`, `-enum`); a tuning / verify build
+        # of the search's object also carries the dry kernel
         expand = [b for b in blocks if b.strip().startswith("kmc_expand_")]
-        assert len(expand) == 1, f
-        spills = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", expand[0]).group(1))
-        vgprs = int(re.search(r"\.vgpr_count:\s*(\d+)", expand[0]).group(1))
-        assert spills <= 8, f"{os.path.basename(f)}: k_expand spills {spills} VGPRs at {vgprs}"
-        seen_wide = seen_wide or vgprs > 128
+        assert 1 <= len(expand) <= 2 and (len(expand) == 1 or any(b.strip().startswith("kmc_expand_dry_") for b in expand)), f
+        tag = "_sh_" if f.endswith("-sharded.hsaco") else "_en_" if f.endswith("-enum.hsaco") else None
+        assert all(b.strip().startswith("kmc_expand" + tag) for b in expand) if tag else \
+            not any(b.strip().startswith(("kmc_expand_sh_", "kmc_expand_en_")) for b in expand), f
+        for blk in expand:
+            spills = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", blk).group(1))
+            vgprs = int(re.search(r"\.vgpr_count:\s*(\d+)", blk).group(1))
+            if not blk.strip().startswith("kmc_expand_dry_"):   # (the rule is applied to the kernel a search runs)
+                assert spills <= 8, f"{os.path.basename(f)}: k_expand spills {spills} VGPRs at {vgprs}"
+            seen_wide = seen_wide or vgprs > 128
     assert seen_wide   # the wide-replica kernels did get the larger budget
+
+
+def test_the_search_kernel_takes_its_own_argument_block_and_holds_no_other_mode():
+    """Round 5: k_expand is one kernel per mode.  The search's own kernel receives KmcArgsLocal — 168 bytes
+    where the four-mode kernel of round 4 took 248 — and its scalar-register spills are what is left of one mode's code:
+    the headline's object reported 286 spilled SGPRs / 770 v_readlane in round 4 (profiles/r05_mode_split.txt)."""
+    import shutil
+    import subprocess
+    readelf = shutil.which("llvm-readelf") or "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(readelf) and os.path.exists(objdump)):
+        pytest.skip("llvm-readelf / llvm-objdump not available")
+    from kafka_specification_amd import code_object_path
+    cfg = CheckerConfig(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=2)
+    path = code_object_path(cfg)
+    notes = subprocess.run([readelf, "--notes", path], capture_output=True, text=True).stdout
+    blk = [b for b in notes.split(".name:")[1:] if b.strip().startswith("kmc_expand_Kip320")]
+    assert len(blk) == 1
+    # the metadata lists a kernel's keys alphabetically: .kernarg_segment_size precedes .name
+    head = notes.split(".name:")[0:1 + [b.strip().startswith("kmc_expand_Kip320") for b in notes.split(".name:")[1:]].index(True)][-1]
+    kernarg = int(re.findall(r"\.kernarg_segment_size:\s*(\d+)", head)[-1])
+    assert kernarg == 168 + 256, kernarg            # KmcArgsLocal + the hidden arguments
+    assert int(re.search(r"\.sgpr_spill_count:\s*(\d+)", blk[0]).group(1)) <= 160
+    text = subprocess.run([objdump, "-d", path], capture_output=True, text=True, check=True).stdout
+    body = text.split("<kmc_expand_Kip320_N3_L6_R6_E2>:")[1].split(">:")[0]
+    assert body.count("v_readlane_b32") <= 200
+    names = re.findall(r"<(kmc_\w+)>:", text)
+    assert not any(n.startswith(("kmc_expand_sh_", "kmc_expand_en_", "kmc_expand_dry_")) for n in names)
+    assert any(n.startswith("kmc_inv_") for n in names)

@@ -128,3 +128,17 @@ def test_invariant_counts_of_the_orbit_search_equal_the_plain_oracles(model):
     for k, n in enumerate(("TypeOk", "WeakIsr", "StrongIsr")):
         assert o.viol_count[n] == (r["violating_at_first_depth"][k] if r["first_violation_depth"][k] == first else 0)
     assert r["violating_states"][0] == 0 and all(r["violating_states"][k] >= r["violating_at_first_depth"][k] for k in (1, 2))
+
+
+@pytest.mark.parametrize("model,N,L,R,E", [("Kip320", 3, 3, 3, 1), ("Kip279", 3, 2, 2, 2), ("KafkaTruncateToHighWatermark", 4, 1, 1, 1),
+                                           ("Kip101", 5, 1, 1, 0), ("Kip320FirstTry", 3, 2, 3, 2)])
+def test_the_bit_packed_arena_is_the_same_exact_search(model, N, L, R, E):
+    """--compact (round 5: the mode that fits the 1.08 G orbit representatives of Kip320 3/6/6/3 into this container's memory:
+    tests/golden/orbit_kip320_3_6_6_3.json) stores every canonical byte in just the bits its range needs and indexes the arena
+    through a 32-bit table; states are still compared in full.  Every number it prints — levels, stored per level, per-disjunct
+    generated, deadlocks, the invariants' violation counts — equals the byte arena's."""
+    a = orbit_oracle(model, N, L, R, E, "--inv", "15")
+    b = orbit_oracle(model, N, L, R, E, "--inv", "15", "--compact")
+    assert b["compact_exact"] and not a["compact_exact"] and b["stored_record_bytes"] < a["stored_record_bytes"]
+    skip = {"compact_exact", "stored_record_bytes", "seconds", "states_per_second"}
+    assert {k: v for k, v in a.items() if k not in skip} == {k: v for k, v in b.items() if k not in skip}
