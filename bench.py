@@ -209,23 +209,37 @@ def cold_start(c):
     spec = os.path.join(ROOT, "models", c["model"] + ".tla")
     if c != headline_config() or not os.path.exists(exe):
         return None
-    out = {"command": "kafka_specification_amd/tlc models/%s.tla -table %d -frontier %d [-notrace]" % (c["model"], 1 << 30, 1 << 26)}
+    out = {"command": "kafka_specification_amd/tlc models/%s.tla -table %d -frontier %d -v [-notrace]" % (c["model"], 1 << 30, 1 << 26)}
+    # -v: the front end's own account of its wall time (kmc_timing, include/kmc.h) — what is HIP's start-up, what the code
+    # object, the allocation, the first touch of the seen-set, the search, the teardown
+    pat = re.compile(r"Wall time: ([\d.]+)s in this process = ([\d.]+)s before kmc_open .* \+ ([\d.]+)s kmc_open \(HIP initialisation "
+                     r"([\d.]+)s, code object ([\d.]+)s, allocation of ([\d.]+) GiB ([\d.]+)s\) \+ ([\d.]+)s kmc_run \(first clear of the "
+                     r"seen-set ([\d.]+)s, search ([\d.]+)s\) \+ ([\d.]+)s verdict / trace \+ ([\d.]+)s teardown")
     for key, extra in (("wall_s", []), ("wall_s_notrace", ["-notrace"])):
-        best, found = None, None
+        best, found, parts = None, None, None
         for _attempt in range(2):   # a fresh process each time; the smaller of two (the first also pages the binaries in)
             t0 = time.perf_counter()
             try:
-                p = subprocess.run([exe, spec, "-table", str(1 << 30), "-frontier", str(1 << 26)] + extra, capture_output=True,
+                p = subprocess.run([exe, spec, "-table", str(1 << 30), "-frontier", str(1 << 26), "-v"] + extra, capture_output=True,
                                    text=True, timeout=300)
             except Exception as e:   # the bench line does not depend on it
                 out["error"] = str(e)[:120]
                 break
             dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
             m = re.findall(r"(\d+) states generated, (\d+) distinct states found, (\d+) states left on queue", p.stdout)
             found = int(m[-1][1]) if m else None      # the closing line, not a progress line
             out["exit_code"] = p.returncode
+            if best is None or dt < best:
+                best = dt
+                b = pat.search(p.stdout)
+                if b:
+                    v = [float(x) for x in b.groups()]
+                    parts = {"in_process_s": v[0], "exec_and_load_s": max(dt - v[0], 0.0),   # fork/exec, the dynamic loader (libamdhip64), exit
+                             "before_open_s": v[1], "open_s": v[2], "hip_init_s": v[3], "code_object_s": v[4],
+                             "device_GiB": v[5], "alloc_s": v[6], "run_s": v[7], "first_clear_s": v[8], "search_s": v[9],
+                             "verdict_s": v[10], "teardown_s": v[11]}
         out[key] = best
+        out["breakdown" if key == "wall_s" else "breakdown_notrace"] = parts
         out["distinct_states" if key == "wall_s" else "distinct_states_notrace"] = found
     return out
 

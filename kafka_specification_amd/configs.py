@@ -101,7 +101,7 @@ def precompile_variants():
     return [(small, {"KMC_VERIFY": "1"}), (wide, {"KMC_VERIFY": "1"}), (golden, {"KMC_VERIFY": "1"}), (small, fault),
             (small, dict(fault, KMC_VERIFY="1")),
             (dict(model="AsyncIsr", n_replicas=3, log_size=2, max_leader_epoch=2), fault),
-            (small, {"KMC_JIT_DEFINES": "-DKMC_TUNING=1 -DKMC_TEST_FP_BITS=10"})] + layout_variants() + symmetry_variants()   # (collisions on demand for the wide-fingerprint test)
+            (small, {"KMC_JIT_DEFINES": "-DKMC_TUNING=1 -DKMC_TEST_FP_BITS=10"})] + layout_variants() + symmetry_variants() + full_leaves_variants()   # (collisions on demand for the wide-fingerprint test)
 
 
 # The arrangements of the Kafka state vector (csrc/kmc_layout.h) and the two walks of k_expand's pass 2 that go with them:
@@ -115,6 +115,26 @@ INSTANCE_MAJOR_SMALL = [(m, 3, 2, 2, 1) for m in KAFKA] + [("Kip320", 4, 2, 2, 1
                                                               ("Kip279", 3, 2, 2, 2)]
 INSTANCE_MAJOR_LARGE = [("Kip320", 3, 5, 5, 2), ("Kip279", 3, 5, 5, 2)]
 GROUPED_LARGE = [("Kip320", 3, 5, 5, 2)]
+
+
+# FULL leaves (k_expand's pass 2 under orbit counting at seven brokers: csrc/kmc_kafka.h, FULL_LEAVES) forced onto small
+# configurations: tests/test_gpu_full_leaves.py
+FULL_LEAVES_DEFINES = "-DKMC_FULL_LEAVES_MIN_INSTANCES=0 -DKMC_FULL_LEAVES_PLAIN=1"
+FULL_LEAVES_SMALL = [(m, 3, 2, 2, 1) for m in KAFKA] + [("Kip320", 4, 2, 2, 1), ("Kip279", 5, 1, 1, 1), ("Kip320", 3, 2, 2, 2),
+                                                         ("Kip320FirstTry", 2, 3, 3, 2)]
+FULL_LEAVES_SYMMETRY = [(m, 3, 2, 2, 1) for m in KAFKA] + [("Kip320", 4, 2, 2, 1), ("Kip279", 5, 1, 1, 1), ("Kip320", 3, 2, 2, 2),
+                                                            ("Kip279", 3, 2, 2, 2)]
+FULL_LEAVES_TRACES = [("Kip279", 3, 2, 2, 2), ("Kip101", 3, 2, 2, 2)]
+
+
+def full_leaves_variants():
+    env = {"KMC_JIT_DEFINES": FULL_LEAVES_DEFINES}
+
+    def c(t, **kw):
+        return dict(model=t[0], n_replicas=t[1], log_size=t[2], max_records=t[3], max_leader_epoch=t[4], **kw)
+    out = [(c(t), env) for t in sorted(set(FULL_LEAVES_SMALL + FULL_LEAVES_TRACES))]
+    out += [(c(t, symmetry=True), env) for t in sorted(set(FULL_LEAVES_SYMMETRY + FULL_LEAVES_TRACES))]
+    return out
 
 
 # Symmetry reduction with orbit counting (CheckerConfig.symmetry; tests/test_gpu_symmetry.py, bench.py's orbit_counting leg)

@@ -90,8 +90,11 @@ typedef unsigned int u32;
                                           // guards are then a second, independent lowering (kmc_engine.cpp)
 #endif
 #ifndef KMC_FULL_LEAVES_MIN_INSTANCES
-#define KMC_FULL_LEAVES_MIN_INSTANCES 200     // Kafka configurations with at least this many action instances (six brokers and
-                                              // more) run pass 2 with FULL leaves (KmcKafka::FULL_LEAVES, kmc_expand_body)
+#define KMC_FULL_LEAVES_MIN_INSTANCES 200     // orbit counting on Kafka configurations with at least this many action instances
+                                              // (seven brokers and more) runs pass 2 with FULL leaves (KmcKafka::FULL_LEAVES)
+#endif
+#ifndef KMC_FULL_LEAVES_PLAIN
+#define KMC_FULL_LEAVES_PLAIN 0               // 1: ... and so does the plain search (measured: a 2 % loss on BASELINE config 5)
 #endif
 #ifndef KMC_SYMM
 #define KMC_SYMM 0        // 1 (kmc_config.symmetry): symmetry reduction with orbit counting — every successor is replaced by the

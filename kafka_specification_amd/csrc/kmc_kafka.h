@@ -451,11 +451,15 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         constexpr u64 mask = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
         return (KindBits)(v & mask);
     }
-    // Pass 2 with FULL leaves (kmc_expand_body): from this many action instances on, a tile's (lane, binding) pairs of a kind are
-    // dealt out 64 to a leaf, every lane applying one pair to the state of the pair's source lane.  Seven brokers: ~13 leaves
-    // per tile instead of 30 at a third of the lanes; at three brokers the walk already runs 12 leaves for 9 kinds and the
-    // headline's kernel waits for memory, not for its effects (KMC_FULL_LEAVES_MIN_INSTANCES moves the threshold: A/B runs).
-    static constexpr bool FULL_LEAVES = KIND_MAJOR && NINST >= KMC_FULL_LEAVES_MIN_INSTANCES;
+    // Pass 2 with FULL leaves (kmc_expand_body): a tile's (lane, binding) pairs of a kind are dealt out 64 to a leaf, every lane
+    // applying one pair to the state of the pair's source lane, instead of one leaf per "next binding of every lane".  On under
+    // orbit counting from KMC_FULL_LEAVES_MIN_INSTANCES action instances on (seven brokers), where the kernel is bound by its
+    // vector instructions and by the length of a wave's chain of leaves (profiles/r05_full_leaves.txt, one box):
+    //   BASELINE config 5 under orbit counting, 14 levels   164.9 ms -> 96.3 ms        Kip320 7/1/1/0 (1,011 stored states) 24.7 -> 1.2 ms
+    //   the same without orbit counting, 10 levels            27.4 -> 27.9 ms (the memory system bounds it: off by default there)
+    //   headline / config 4, plain and orbit counting         +0.9 % / -2.5 %, -0.7 % / -3.5 %: nothing to gain at 12 leaves for 9 kinds
+    // (-DKMC_FULL_LEAVES_MIN_INSTANCES=0 -DKMC_FULL_LEAVES_PLAIN=1 force it everywhere: tests/test_gpu_full_leaves.py.)
+    static constexpr bool FULL_LEAVES = KIND_MAJOR && NINST >= KMC_FULL_LEAVES_MIN_INSTANCES && (KMC_SYMM || KMC_FULL_LEAVES_PLAIN);
 #ifndef KMC_HOST_EMU
     // what an effect reads of the state's shared sub-predicates besides its words, pulled from ANOTHER lane (src4 / 4) for an
     // effect applied on that lane's behalf: apply<4> of Kip320 reads fm (both disjuncts of Kip320.tla:82-83).  The others are

@@ -866,7 +866,14 @@ def bench_sharded(c: dict, steps: int, warmup: int, backend: str = "nccl", symme
             per_rank = mine
     finally:
         eng.close()
+    # what the first curve on real GPUs will be read against: did the exchange under the C ABI come up on every rank (the
+    # self-test in make_engine_and_exchange ran before anything was timed: an all-gather and a send / receive ring over RCCL,
+    # verified; a failure anywhere makes ALL ranks fall back to DistExchange), and how many levels took the within-level pipeline
     extra = {"shards": world, "exchange": type(ex).__name__,
+             "rccl_ranks": world if isinstance(ex, RcclExchange) else 0,
+             "pipelined_levels": int(getattr(ex, "pipelined_levels", 0)),
+             "pipeline_min_states": int(getattr(type(ex), "PIPELINE_MIN_STATES", 0)),
+             "pipeline_parts": int(getattr(type(ex), "PIPELINE_PARTS", 0)),
              "per_rank": [dict(rank=i, expand_kernel_seconds_last_step=float(per_rank[i][0]), states_owned=int(per_rank[i][1]),
                                received_bytes_last_step=int(per_rank[i][2]), levels_with_traffic=int(per_rank[i][3]))
                           for i in range(world)]}

@@ -36,6 +36,10 @@ def test_bench_gpus2_self_launches_and_prints_one_line():
     assert r["config"]["distinct_states"] == o.distinct and r["config"]["states_generated"] == o.generated
     assert r["config"]["depth"] == o.depth and r["config"]["verdict"] == "ok"
     assert r["config"]["shards"] == 2
+    # what the first curve on real GPUs is read against (round 5): which exchange ran, on how many ranks RCCL's self-test
+    # passed (none here: gloo, a stand-in engine), how many levels took the within-level pipeline and from which size on
+    assert r["config"]["exchange"] == "DistExchange" and r["config"]["rccl_ranks"] == 0
+    assert r["config"]["pipelined_levels"] == 0 and "pipeline_min_states" in r["config"] and "pipeline_parts" in r["config"]
     assert r["value"] > 0 and r["ms_per_step"] > 0
     assert "cpu_baseline" not in r                         # N>1 lines carry no CPU leg
 
