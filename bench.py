@@ -385,6 +385,10 @@ def main():
     ap.add_argument("--no-baseline-configs", action="store_true",
                     help="skip the baseline_configs legs (BASELINE.json configs 4 and 5 on one GPU, beside the headline)")
     ap.add_argument("--config-steps", type=int, default=3, help="timed steps of each baseline_configs leg (1 warmup before)")
+    ap.add_argument("--stretch", nargs="?", const="Kip320,3,6,6,3", default=None, metavar="MODEL,N,L,R,E",
+                    help="N > 1 only: one more leg beside the strong-scaling headline — the workload the frontier sharding is "
+                         "designed for (default Kip320 3/6/6/3: 6,452,700,520 states, 128-bit entries, seconds on one GPU; "
+                         "DESIGN.md section 6 holds the projection its curve is read against), one step, never part of `value`")
     ap.add_argument("--backend", default=os.environ.get("KMC_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
                     help="process-group backend of the N>1 leg: nccl (= RCCL, the product) or gloo (CPU launch-path test)")
     a = ap.parse_args()
@@ -419,6 +423,27 @@ def main():
         results, dt = run_single(c, a.steps, a.warmup, symmetry=a.symmetry)
         extra = {}
         scaling, parallelism = "strong", "1 GPU" + (", orbit counting over the permutations of Replicas" if a.symmetry else "")
+    stretch = None
+    if (a.gpus > 1 or world > 1) and a.stretch:
+        # every rank takes part (the exchange is collective); a failure is reported, it never takes the headline line down
+        m, n, l, rr, e = a.stretch.split(",")
+        sc = dict(model=m, n_replicas=int(n), log_size=int(l), max_records=int(rr), max_leader_epoch=int(e),
+                  invariants=("TypeOk", "WeakIsr", "StrongIsr") if m == "Kip320" else ("TypeOk",))
+        try:
+            sres, sdt, sextra = bench_sharded(sc, 1, 0, backend=a.backend, wide_fingerprint=True,
+                                              capacities=(1 << 33, (1 << 30) * 5 // 4, 1 << 28))
+            x = sres[-1]
+            kexp = expected_counts(sc)      # tests/golden/orbit_kip320_3_6_6_3.json: Oracle-O's exact search
+            known = (kexp["distinct"], kexp["generated"], kexp["depth"]) if kexp else None
+            stretch = {"workload": workload_name(sc), "entries": "128-bit (fingerprint + check word)", "steps": 1,
+                       "time_to_exhaustive_s": sdt, "value": x.distinct / sdt, "unit": "distinct states/s",
+                       "distinct_states": x.distinct, "states_generated": x.generated, "depth": x.depth, "verdict": x.verdict,
+                       "matches_the_exact_oracle": None if known is None else (x.distinct, x.generated, x.depth) == known,
+                       **{k: v for k, v in sextra.items() if k != "per_rank"},
+                       "expand_kernel_seconds_max_rank": max(pr["expand_kernel_seconds_last_step"] for pr in sextra["per_rank"]),
+                       "exchange_bytes": sum(pr["received_bytes_last_step"] for pr in sextra["per_rank"])}
+        except Exception as ex_:   # noqa: BLE001
+            stretch = {"workload": a.stretch, "error": f"{type(ex_).__name__}: {str(ex_)[:300]}"}
     if rank != 0:
         return
 
@@ -558,6 +583,8 @@ def main():
         cs = cold_start(c)
         if cs:
             out["cold_start"] = cs
+    if stretch is not None:
+        out["stretch"] = stretch
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(c, a.cpu_states or max(1_000_000, distinct // 4), distinct)
     print(json.dumps(out))

@@ -802,7 +802,8 @@ def _engine_factory():
     return getattr(importlib.import_module(mod), name)
 
 
-def bench_sharded(c: dict, steps: int, warmup: int, backend: str = "nccl", symmetry: bool = False):
+def bench_sharded(c: dict, steps: int, warmup: int, backend: str = "nccl", symmetry: bool = False, wide_fingerprint: bool = False,
+                  capacities=None):
     """bench.py's N>1 leg: strong scaling of the headline check over the ranks of this job.
     backend "nccl" (= RCCL over xGMI) is the product; "gloo" exists so that the launch / rendezvous /
     timing / rank-0-prints path can be exercised on a CPU box with a stand-in engine."""
@@ -830,9 +831,12 @@ def bench_sharded(c: dict, steps: int, warmup: int, backend: str = "nccl", symme
     # per rank: table for its 1/P of the states at load <= 0.5, frontier for its share of the widest
     # level (2.6e7 states) with 2x slack, send sub-buffers for its share of that level's successors
     # (symmetry: orbit counting on every rank — successors travel as representatives, each rank weighs its own counters)
-    cfg = CheckerConfig(**c, symmetry=symmetry, table_capacity=int(os.environ.get("KMC_BENCH_TABLE", max(1 << 27, (1 << 30) // per))),
-                        frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", max(1 << 23, (1 << 26) // per))),
-                        send_capacity=int(os.environ.get("KMC_BENCH_SEND", max(1 << 18, (1 << 25) // (per * per)))))
+    # (`capacities` = (table, frontier, send) for the whole job, divided here: bench.py's stretch leg brings its own)
+    tab, fro, snd = capacities or (1 << 30, 1 << 26, 1 << 25)
+    cfg = CheckerConfig(**c, symmetry=symmetry, wide_fingerprint=wide_fingerprint,
+                        table_capacity=int(os.environ.get("KMC_BENCH_TABLE", max(1 << 27, tab // per))),
+                        frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", max(1 << 23, fro // per))),
+                        send_capacity=int(os.environ.get("KMC_BENCH_SEND", max(1 << 18, snd // (per * per)))))
     eng, ex = make_engine_and_exchange(cfg, rank, world, local, device)
     names = eng.action_names()
     results = []

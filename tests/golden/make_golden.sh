@@ -32,6 +32,9 @@ for m in KafkaTruncateToHighWatermark:thw Kip101:kip101 Kip279:kip279 Kip320Firs
 done
 # ... and one step beyond the headline: Kip320 3/7/7/2, 973,929,178 states from 162,341,877 stored ones (~6 minutes, ~17 GB)
 ./oracle/orbit_oracle --model Kip320 --N 3 --L 7 --R 7 --E 2 --threads 4 --inv 7 --table-log2 30 --max-stored 450000000 > tests/golden/orbit_kip320_3_7_7_2.json
+# ... and the stretch configuration, Kip320 3/6/6/3: 6,452,700,520 states from 1,075,491,542 stored ones — EXACT, with the arena
+# bit-packed (--compact: 22 bytes per stored state instead of 48, a table of 32-bit indices: 23.7 + 8.6 GB; 20 minutes on 6 threads)
+./oracle/orbit_oracle --model Kip320 --N 3 --L 6 --R 6 --E 3 --threads 6 --inv 7 --compact --table-log2 31 --max-stored 1100000000 > tests/golden/orbit_kip320_3_6_6_3.json
 # BASELINE config 5 (7 brokers, LogSize 8) cannot be exhausted: the exact oracle's PREFIX of ten levels (197,561,008 states,
 # 2.5 minutes, ~25 GB) — what the plain and the orbit-counting GPU searches are held to over a level budget of 10
 # (written through tests/kmo.py: kmo.Run(make_config("Kip320", N=7, L=8, R=8, E=3, threads=8, max_states=41002348)) -> levels, generated,

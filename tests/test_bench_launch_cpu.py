@@ -44,6 +44,24 @@ def test_bench_gpus2_self_launches_and_prints_one_line():
     assert "cpu_baseline" not in r                         # N>1 lines carry no CPU leg
 
 
+def test_bench_gpus2_stretch_leg_rides_beside_the_headline():
+    """`bench.py --gpus N --stretch [WORKLOAD]` (round 5): the workload the frontier sharding is for (default Kip320 3/6/6/3,
+    128-bit entries) as one more leg of the N > 1 line — here a small stand-in workload over gloo; never part of `value`."""
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo", "--no-cpu-baseline",
+              "--workload", "Kip320,2,2,2,2", "--stretch", "Kip320,3,2,2,1"], {"KMC_SHARD_ENGINE": "shard_standin:make_engine"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    o = kmo.Run(kmo.make_config("Kip320", N=3, L=2, R=2, E=1, invariants=("TypeOk", "WeakIsr", "StrongIsr")))
+    st = r["stretch"]
+    assert "error" not in st, st
+    assert (st["distinct_states"], st["states_generated"], st["depth"], st["verdict"]) == (o.distinct, o.generated, o.depth, "ok")
+    assert st["shards"] == 2 and st["matches_the_exact_oracle"] is None and st["time_to_exhaustive_s"] > 0
+    o2 = kmo.Run(kmo.make_config("Kip320", N=2, L=2, R=2, E=2, invariants=("TypeOk", "WeakIsr", "StrongIsr")))
+    assert r["config"]["distinct_states"] == o2.distinct      # the headline leg is untouched
+
+
 def test_bench_gpus2_with_orbit_counting_prints_the_plain_searchs_numbers():
     """`bench.py --gpus 2 --symmetry`: orbit counting on every rank (round 4: the level-step interface weighs its counters) —
     the line carries the PLAIN search's counts, the stored states beside them."""

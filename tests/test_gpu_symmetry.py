@@ -247,15 +247,23 @@ def test_headline_configuration_equals_the_golden_fixture():
     assert res.orbit_representatives < g["distinct"] / 5.9
 
 
-def test_six_billion_states_beyond_any_oracle():
-    """Kip320 3/6/6/3: no oracle reaches it.  Its count — 6,452,700,520 distinct / 20,756,484,505 generated / 54 levels — is what
-    three hash seeds of the PLAIN search with 128-bit seen-set entries agree on (profiles/r03_fp128.txt; 64-bit runs lose 0-9
-    states to collisions).  The orbit-counting search gets there from 1,075,491,542 stored states by a different route: other
-    states in the table, other fingerprints, every count a weighted sum."""
+def test_six_billion_states_against_the_exact_orbit_oracle():
+    """Kip320 3/6/6/3: 6,452,700,520 states.  Until round 5 the pin was what three hash seeds of the PLAIN search with 128-bit
+    entries agreed on — GPU against GPU.  tests/golden/orbit_kip320_3_6_6_3.json is Oracle-O's EXACT search (orbit_oracle
+    --compact: 1,075,491,542 full states, bit-packed to 22 bytes each, compared bit for bit — no fingerprint anywhere; 20 minutes
+    and 33 GB here, recipe in make_golden.sh): level sizes, per-disjunct generated counts, deadlocked states, the orbit
+    representatives per level.  The orbit-counting search must reproduce all of it (and stores exactly the representatives
+    the oracle stored, level by level)."""
+    g = json.load(open(os.path.join(GOLDEN, "orbit_kip320_3_6_6_3.json")))
+    assert g["compact_exact"] and g["exhausted"] and not g["last_level_fingerprints_only"] and not any(g["violating_states"])
     res = sym_run("Kip320", invariants=("TypeOk", "WeakIsr", "StrongIsr"), n_replicas=3, log_size=6, max_records=6,
                   max_leader_epoch=3, wide_fingerprint=True, table_capacity=1 << 31, frontier_capacity=1 << 28)
-    assert (res.verdict, res.distinct, res.generated, res.depth) == ("ok", 6452700520, 20756484505, 54)
-    assert res.orbit_representatives == 1075491542
+    assert (res.verdict, res.distinct, res.generated, res.depth) == ("ok", g["distinct"], g["generated"], g["depth"])
+    assert (g["distinct"], g["generated"], g["depth"]) == (6452700520, 20756484505, 54)
+    assert res.levels == g["levels"]
+    assert list(res.action_generated.values()) == g["action_generated"][:len(res.action_generated)]
+    assert res.deadlock_states == g["deadlock_states"]
+    assert res.orbit_representatives == g["stored"] == 1075491542
 
 
 @pytest.mark.parametrize("model,N,L,R,E", [("Kip279", 5, 1, 1, 1), ("Kip279", 5, 2, 2, 1), ("KafkaTruncateToHighWatermark", 6, 1, 1, 1)])
