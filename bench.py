@@ -60,6 +60,22 @@ def kernel_code_sha256_of(c, symmetry=False):
         return None
 
 
+def kernel_compiler_of(c, symmetry=False):
+    """Which compiler wrote the cached code object this run loads (COMPILERS.jsonl beside it: the cache is keyed by what is
+    compiled, not by who compiles — the two HIP runtimes a box holds emit different instructions for the same text)."""
+    try:
+        import kafka_specification_amd as kmc
+        path = kmc.code_object_path(kmc.CheckerConfig(**{k: v for k, v in c.items() if k != "max_levels"}, symmetry=symmetry))
+        last = None
+        for line in open(os.path.join(os.path.dirname(path), "COMPILERS.jsonl")):
+            j = json.loads(line)
+            if j.get("file") == os.path.basename(path):
+                last = j
+        return {k: v for k, v in last.items() if k != "file"} if last else None
+    except Exception:
+        return None
+
+
 def headline_kernel_code_sha256(symmetry=False):
     return kernel_code_sha256_of(headline_config(), symmetry)
 
@@ -129,7 +145,7 @@ def measured_traffic(code=None, level_budget=None, depth=None):
         return None, "no PMC summary under profiles/"
     if not code:
         return None, "kernel_code_sha256 of the running kernels unavailable: no PMC summary can be matched"
-    seen = []
+    seen, near = [], []     # near: the same machine code, measured over another search — said first
     for path in files:
         try:
             j = json.load(open(path))
@@ -139,13 +155,13 @@ def measured_traffic(code=None, level_budget=None, depth=None):
         if j.get("kernel_code_sha256") == code and j.get("hbm_bytes_per_launch"):
             run = j.get("run", {})
             if (run.get("level_budget") or None) != (level_budget or None) or (depth and run.get("depth") and run["depth"] != depth):
-                seen.append(f"{os.path.basename(path)}: same code, another search (level budget {run.get('level_budget')}, "
+                near.append(f"{os.path.basename(path)}: same code, another search (level budget {run.get('level_budget')}, "
                             f"depth {run.get('depth')}; this run {level_budget}, {depth})")
                 continue
             return j["hbm_bytes_per_launch"], (f"{os.path.relpath(path, ROOT)} (measured on this machine code: "
                                                f"kernel_code_sha256 {code[:16]})")
         seen.append(f"{os.path.basename(path)} {str(j.get('kernel_code_sha256'))[:12]}")
-    return None, f"no PMC summary was measured on this code ({code[:12]}...): " + ", ".join(seen[:6])
+    return None, f"no PMC summary was measured on this code ({code[:12]}...) over this search: " + ", ".join(near + seen[:6])
 
 
 def device_info():
@@ -349,6 +365,33 @@ def baseline_leg(name, steps, warmup):
     }
 
 
+def stretch_leg(a):
+    """`--gpus N --stretch [MODEL,N,L,R,E]`: the workload the frontier sharding is designed for, beside the strong-scaling headline
+    (default Kip320 3/6/6/3: 6,452,700,520 states, 128-bit entries; DESIGN.md section 6 holds the projection its curve is read
+    against).  Every rank takes part (the exchange is collective); a failure is reported, it never takes the headline line down."""
+    from kafka_specification_amd.sharded import bench_sharded
+    m, n, l, rr, e = a.stretch.split(",")
+    sc = dict(model=m, n_replicas=int(n), log_size=int(l), max_records=int(rr), max_leader_epoch=int(e),
+              invariants=("TypeOk", "WeakIsr", "StrongIsr") if m == "Kip320" else ("TypeOk",))
+    try:
+        # capacities of the whole job (tools/loopback_stretch.py ran these on 8 logical shards): 2^33 table slots, 1.25 x 2^30
+        # frontier states, 2^28 send records
+        sres, sdt, sextra = bench_sharded(sc, 1, 0, backend=a.backend, wide_fingerprint=True,
+                                          capacities=(1 << 33, (1 << 30) * 5 // 4, 1 << 28))
+        x = sres[-1]
+        kexp = expected_counts(sc)      # tests/golden/orbit_kip320_3_6_6_3.json: Oracle-O's exact search
+        known = (kexp["distinct"], kexp["generated"], kexp["depth"]) if kexp else None
+        return {"workload": workload_name(sc), "entries": "128-bit (fingerprint + check word)", "steps": 1,
+                "time_to_exhaustive_s": sdt, "value": x.distinct / sdt, "unit": "distinct states/s",
+                "distinct_states": x.distinct, "states_generated": x.generated, "depth": x.depth, "verdict": x.verdict,
+                "matches_the_exact_oracle": None if known is None else (x.distinct, x.generated, x.depth) == known,
+                **{k: v for k, v in sextra.items() if k != "per_rank"},
+                "expand_kernel_seconds_max_rank": max(pr["expand_kernel_seconds_last_step"] for pr in sextra["per_rank"]),
+                "exchange_bytes": sum(pr["received_bytes_last_step"] for pr in sextra["per_rank"])}
+    except Exception as ex_:   # noqa: BLE001
+        return {"workload": a.stretch, "error": f"{type(ex_).__name__}: {str(ex_)[:300]}"}
+
+
 def self_launch(n):
     import socket
     import subprocess
@@ -423,27 +466,7 @@ def main():
         results, dt = run_single(c, a.steps, a.warmup, symmetry=a.symmetry)
         extra = {}
         scaling, parallelism = "strong", "1 GPU" + (", orbit counting over the permutations of Replicas" if a.symmetry else "")
-    stretch = None
-    if (a.gpus > 1 or world > 1) and a.stretch:
-        # every rank takes part (the exchange is collective); a failure is reported, it never takes the headline line down
-        m, n, l, rr, e = a.stretch.split(",")
-        sc = dict(model=m, n_replicas=int(n), log_size=int(l), max_records=int(rr), max_leader_epoch=int(e),
-                  invariants=("TypeOk", "WeakIsr", "StrongIsr") if m == "Kip320" else ("TypeOk",))
-        try:
-            sres, sdt, sextra = bench_sharded(sc, 1, 0, backend=a.backend, wide_fingerprint=True,
-                                              capacities=(1 << 33, (1 << 30) * 5 // 4, 1 << 28))
-            x = sres[-1]
-            kexp = expected_counts(sc)      # tests/golden/orbit_kip320_3_6_6_3.json: Oracle-O's exact search
-            known = (kexp["distinct"], kexp["generated"], kexp["depth"]) if kexp else None
-            stretch = {"workload": workload_name(sc), "entries": "128-bit (fingerprint + check word)", "steps": 1,
-                       "time_to_exhaustive_s": sdt, "value": x.distinct / sdt, "unit": "distinct states/s",
-                       "distinct_states": x.distinct, "states_generated": x.generated, "depth": x.depth, "verdict": x.verdict,
-                       "matches_the_exact_oracle": None if known is None else (x.distinct, x.generated, x.depth) == known,
-                       **{k: v for k, v in sextra.items() if k != "per_rank"},
-                       "expand_kernel_seconds_max_rank": max(pr["expand_kernel_seconds_last_step"] for pr in sextra["per_rank"]),
-                       "exchange_bytes": sum(pr["received_bytes_last_step"] for pr in sextra["per_rank"])}
-        except Exception as ex_:   # noqa: BLE001
-            stretch = {"workload": a.stretch, "error": f"{type(ex_).__name__}: {str(ex_)[:300]}"}
+    stretch = stretch_leg(a) if (a.gpus > 1 or world > 1) and a.stretch else None
     if rank != 0:
         return
 
@@ -535,7 +558,7 @@ def main():
                      "useful_fraction_ceiling_of_a_probe": 8.0 / 128.0,
                      "traffic_source": traffic_source, "random_access": random_access, "per_rank": per_rank,
                      "device_source_sha256": device_source_sha256()[:16],
-                     "kernel_code_sha256": code_sha,
+                     "kernel_code_sha256": code_sha, "kernel_compiler": kernel_compiler_of(c, a.symmetry),
                      "note": "achieved = algorithmic bytes (2*S + 8*g + 8 per distinct state) over the summed durations "
                              "of the step's per-level k_expand launches (HIP events on the engine stream).  traffic = DRAM bytes "
                              "per launch from the gfx950 request-size counters: every random 8-B probe fills one 128-B line "

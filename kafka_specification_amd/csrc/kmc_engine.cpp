@@ -346,6 +346,22 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
         fclose(f);
         if (ok) rename(tmp.c_str(), path.c_str());
         else unlink(tmp.c_str());
+        // Who compiled it.  The key above holds hiprtc's major.minor only (so that the bench under torch's runtime and a
+        // rocprofv3 run under the system's load the SAME object), but the two bundled compilers emit different instructions for
+        // the same text: which of them filled this slot of the cache is recorded beside it — COMPILERS.jsonl, one appended line
+        // per object written (bench.py reports it next to kernel_code_sha256; an object from a compiler found to be bad can be
+        // told from its neighbours and deleted).
+        if (ok) {
+            int rt = 0;
+            (void)hipRuntimeGetVersion(&rt);
+            if (FILE* idx = fopen((dir + "/COMPILERS.jsonl").c_str(), "ab")) {
+                const size_t slash = path.find_last_of('/');
+                fprintf(idx, "{\"file\": \"%s\", \"hiprtc\": \"%d.%d\", \"hip_runtime_version\": %d, \"waves\": \"%s\"}\n",
+                        path.substr(slash == std::string::npos ? 0 : slash + 1).c_str(), rtc_major, rtc_minor, rt,
+                        waves_forced ? "as given" : "rule");
+                fclose(idx);
+            }
+        }
     }
     return KMC_OK;
 }

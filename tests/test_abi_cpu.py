@@ -3,6 +3,7 @@ include/kmc.h declares, the ctypes structs match the header, kernels specialise 
 without a GPU, bad constants are rejected, the library fails loudly without a device, and the
 host-side pack/unpack/fingerprint logic round-trips (no compute calls: there is no GPU here)."""
 import ctypes as C
+import json
 import os
 import random
 import re
@@ -54,11 +55,15 @@ def test_specialises_for_gfx950_without_a_gpu(tmp_path):
     cfg = CheckerConfig(model="Kip101", n_replicas=2, log_size=3, max_records=2, max_leader_epoch=1,
                         cache_dir=str(tmp_path))
     precompile(cfg, "gfx950", 0)       # the search's own code object ...
-    files = os.listdir(tmp_path)
-    assert len(files) == 1 and files[0].startswith("Kip101_N2_L3_R2_E1-gfx950-") and files[0].endswith(".hsaco")
+    objects = lambda: [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    files = objects()
+    assert len(files) == 1 and files[0].startswith("Kip101_N2_L3_R2_E1-gfx950-")
     assert open(os.path.join(tmp_path, files[0]), "rb").read(4) == b"\x7fELF"
+    # ... and who compiled it, beside it (the cache is keyed by what is compiled, not by who compiles)
+    rec = [json.loads(ln) for ln in open(os.path.join(tmp_path, "COMPILERS.jsonl"))]
+    assert [r["file"] for r in rec] == files and rec[0]["hip_runtime_version"] > 0 and "." in rec[0]["hiprtc"]
     precompile(cfg, "gfx950")          # ... and all three: k_expand for the level-step interface and as an enumerator beside it
-    files = sorted(os.listdir(tmp_path), key=len)
+    files = sorted(objects(), key=len)
     assert len(files) == 3 and files[1].endswith("-enum.hsaco") and files[2].endswith("-sharded.hsaco")
     assert all(f.startswith("Kip101_N2_L3_R2_E1-gfx950-") for f in files)
     with pytest.raises(KmcError):
