@@ -233,7 +233,8 @@ def cold_start(c):
                      r"seen-set ([\d.]+)s, search ([\d.]+)s\) \+ ([\d.]+)s verdict / trace \+ ([\d.]+)s teardown")
     for key, extra in (("wall_s", []), ("wall_s_notrace", ["-notrace"])):
         best, found, parts = None, None, None
-        for _attempt in range(2):   # a fresh process each time; the smaller of two (the first also pages the binaries in)
+        for _attempt in range(3):   # a fresh process each time; the smallest of three (the first pages the binaries in: the system
+            #                           ROCm's libamdhip64, which a box whose Python processes only loaded PyTorch's bundled one has never read)
             t0 = time.perf_counter()
             try:
                 p = subprocess.run([exe, spec, "-table", str(1 << 30), "-frontier", str(1 << 26), "-v"] + extra, capture_output=True,
