@@ -140,7 +140,7 @@ def full_leaves_variants():
 # Symmetry reduction with orbit counting (CheckerConfig.symmetry; tests/test_gpu_symmetry.py, bench.py's orbit_counting leg)
 SYMMETRY_KAFKA = [(m, N, L, R, E) for m in KAFKA
                   for (N, L, R, E) in [(2, 2, 2, 1), (3, 2, 2, 1), (3, 1, 1, 2), (2, 3, 3, 2), (3, 2, 2, 2), (4, 1, 1, 1)]] + [
-    ("Kip320", 4, 2, 2, 1), ("Kip101", 4, 2, 1, 2), ("Kip279", 3, 2, 3, 2), ("Kip320FirstTry", 3, 3, 3, 1),
+    ("Kip320", 4, 2, 2, 1), ("Kip101", 4, 2, 1, 2), ("Kip279", 3, 2, 3, 2), ("Kip320FirstTry", 3, 3, 3, 1), ("Kip320", 3, 3, 3, 1),
     ("KafkaTruncateToHighWatermark", 3, 3, 3, 1), ("Kip320", 3, 6, 6, 2), ("Kip320", 3, 5, 5, 2), ("Kip320", 3, 6, 6, 3), ("Kip320", 3, 7, 7, 2),
     # every Kafka model at the headline's constants (the exact Oracle-O pins and the per-state differential, round 4)
     ("KafkaTruncateToHighWatermark", 3, 6, 6, 2), ("Kip101", 3, 6, 6, 2), ("Kip279", 3, 6, 6, 2), ("Kip320FirstTry", 3, 6, 6, 2),

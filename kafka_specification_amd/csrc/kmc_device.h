@@ -7,7 +7,8 @@
 // hiprtc), so every bit offset, loop bound and action-instance index below is a compile-time
 // constant and a packed state lives in W 64-bit registers per lane.
 //
-// Kernel shape (k_expand): one wavefront lane per frontier state.
+// Kernel shape (k_expand): one wavefront lane per frontier state.  One kernel PER MODE (the search's own,
+// the level-step interface's owner bucketing, the enumerator: kmc_expand_body<M, MODE>, three code objects per configuration).
 //   * coalesced loads of the SoA frontier planes (plane k, state i at fin[k*stride+i]); every
 //     field is extracted once; the invariants of the state being expanded are checked here;
 //   * pass 1: the guards of all action instances of `Next` (every binding of the specs' \E over
@@ -18,6 +19,8 @@
 //     extract at a compile-time offset") until no lane has one left — 12 leaves per 64-state tile at the headline.
 //     INSTANCE-MAJOR (every other model and layout): a walk over the instances; a scalar binary dispatch jumps to the
 //     statically specialised effect of each instance some lane enabled (30 leaves per tile at the headline's constants).
+//     Under orbit counting at seven brokers the kind-major walk runs with FULL leaves: a tile's (lane, binding) pairs of a
+//     kind dealt out 64 to a leaf, every lane applying one pair to its source lane's state (kmc_pull).
 //     Either way lanes never diverge on *which* action they apply, and enabled successors are compacted with
 //     __ballot + mbcnt prefix ranks into a per-wave LDS ring (SoA, conflict-free): the write-combining stage;
 //   * a flush drains exactly 64 successors, one per lane, so the random HBM probes of the

@@ -391,6 +391,8 @@ struct kmc_handle {
     std::string arch;
     kmc_timing timing{};                    // where the wall time outside the search went (kmc_timing_get)
     bool first_clear_timed = false;
+    std::string cache_dir;                  // kmc_config.cache_dir, copied: the later code objects (ensure_mode) are looked up
+                                            // long after kmc_open returned and the caller's string may be gone
     std::string jit_defines;                // KMC_JIT_DEFINES as it stood when the handle was opened
     bool verify = false;                    // KMC_VERIFY likewise
     hipModule_t mod = nullptr;              // the search's code object: k_expand (LOCAL), k_inv, k_insert, k_init, k_find, k_packrow
@@ -965,6 +967,10 @@ void kmc_close(kmc_handle* h) {
 
 static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     h->cfg = *cfg;
+    if (cfg->cache_dir) {
+        h->cache_dir = cfg->cache_dir;
+        h->cfg.cache_dir = h->cache_dir.c_str();
+    }
     if (h->cfg.n_shards < 1) h->cfg.n_shards = 1;
     if (h->cfg.n_shards > KMC_MAX_SHARDS || h->cfg.shard_id < 0 || h->cfg.shard_id >= h->cfg.n_shards)
         return fail(KMC_E_ARG, "bad shard configuration %d/%d", h->cfg.shard_id, h->cfg.n_shards);

@@ -275,31 +275,112 @@ template <class M> struct KmcSymm {
         }
         return k;
     }
+    // t = s with replica r renamed rank[r] (a run-time permutation, per lane): every replica's log and small fields move to the
+    // position of its rank — destination-major select chains over compile-time offsets, never an indexed array — and every
+    // (leader, isr) pair is renamed through the ranks (the leader by a packed 3-bit lookup, the isr bit by bit).
+    static KMC_DEV void permute_by_rank(const u64* s, const u32* rank, u64* t) {
+        constexpr int LB = Y.BR * Y.L;
+        constexpr int GB = KAFKA ? 2 * Y.BO + Y.BE : Y.BO;          // end | hw | ep (FiniteReplicatedLog: end)
+        static_assert(GB + PB <= 32, "a replica's small fields do not fit one register");
+        kmc_static_for<0, W>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            t[k] = s[k] & keep_mask(k);
+        });
+        u64 lg[N];
+        u32 sm[N];   // end | hw | ep, then the replica's own (leader, isr) pair from bit GB
+        kmc_static_for<0, N>([&](auto RR) {
+            constexpr int r = decltype(RR)::value;
+            lg[r] = kmc_getbits(s, Y.log_off[r], LB);
+            sm[r] = (u32)kmc_getbits(s, Y.end_off[r], GB);
+            if constexpr (KAFKA) sm[r] |= (u32)kmc_getbits(s, Y.ldr_off[r], PB) << GB;   // (adjacent: static_assert in exchange)
+        });
+        u32 packed = 0, bit[N];   // rank of replica i at bits 3 i; 1 << rank[i]
+        kmc_static_for<0, N>([&](auto II) {
+            constexpr int i = decltype(II)::value;
+            packed |= rank[i] << (3 * i);
+            bit[i] = 1u << rank[i];
+        });
+        auto rename = [&](u32 pair) -> u32 {   // (leader | isr << BL) with every replica in it renamed by its rank
+            const u32 l = pair & ML, m = pair >> Y.BL;
+            const u32 nl = (l == 0u || l > (u32)N) ? l : ((packed >> (3u * (l - 1u))) & 7u) + 1u;
+            u32 nm = 0;
+            kmc_static_for<0, N>([&](auto II) {
+                constexpr int i = decltype(II)::value;
+                nm += ((m >> i) & 1u) * bit[i];
+            });
+            return nl | nm << Y.BL;
+        };
+        kmc_static_for<0, N>([&](auto DD) {
+            constexpr int d = decltype(DD)::value;
+            // (every step opaque: the plain chain is recognised as lg[the r with rank d] — the arrays go to scratch memory and
+            // every destination loads them back with a per-lane address, as KmcKafka::sel_word found in round 3)
+            u32 llo = (u32)lg[0], lhi = (u32)(lg[0] >> 32), v = sm[0];
+            kmc_static_for<1, N>([&](auto RR) {
+                constexpr int r = decltype(RR)::value;
+                const bool here = rank[r] == (u32)d;
+                llo = here ? (u32)lg[r] : llo;
+                if constexpr (LB > 32) lhi = here ? (u32)(lg[r] >> 32) : lhi;
+                v = here ? sm[r] : v;
+                KMC_OPAQUE_PURE(llo);
+                if constexpr (LB > 32) KMC_OPAQUE_PURE(lhi);
+                KMC_OPAQUE_PURE(v);
+            });
+            const u64 l = LB > 32 ? (((u64)lhi << 32) | llo) : (u64)llo;
+            kmc_orbits(t, Y.log_off[d], LB, l);
+            kmc_orbits(t, Y.end_off[d], GB, v & ((1u << GB) - 1u));
+            if constexpr (KAFKA) kmc_orbits(t, Y.ldr_off[d], PB, rename(v >> GB));
+        });
+        if constexpr (KAFKA) {
+            kmc_static_for<N, NPAIR>([&](auto FF) {
+                constexpr int f = decltype(FF)::value;
+                if constexpr (pair_adjacent(f)) {
+                    kmc_orbits(t, pair_ldr_off(f), PB, rename((u32)kmc_getbits(s, pair_ldr_off(f), PB)));
+                } else {
+                    const u32 pi = rename((u32)kmc_getbits(s, pair_ldr_off(f), Y.BL) | ((u32)kmc_getbits(s, pair_isr_off(f), Y.BI) << Y.BL));
+                    kmc_orbits(t, pair_ldr_off(f), Y.BL, pi & ML);
+                    kmc_orbits(t, pair_isr_off(f), Y.BI, pi >> Y.BL);
+                }
+            });
+        }
+    }
+
     static KMC_DEV void canon_sorted(const u64* s, const u32* tab, u64* c, u32& stab) {
         u64 t[W];
-#pragma unroll
-        for (int k = 0; k < W; ++k) t[k] = s[k];
         Key key[N];
-        kmc_static_for<0, N>([&](auto RR) { key[decltype(RR)::value] = key_at<decltype(RR)::value>(t); });
-        kmc_static_for<0, N>([&](auto II) {
-            kmc_static_for<0, (N - 1 - decltype(II)::value % 2 + 1) / 2>([&](auto JJ) {
-                constexpr int a = decltype(II)::value % 2 + 2 * decltype(JJ)::value;
-                if constexpr (a + 1 < N) {
-                    const bool sw = key[a + 1].a < key[a].a || (key[a + 1].a == key[a].a && key[a + 1].b < key[a].b);
-                    if (kmc_any_lane(sw)) {
-                        exchange<a>(t, tab, sw ? ~0ull : 0ull);
-                        const Key lo = key[a], hi = key[a + 1];
-                        key[a] = sw ? hi : lo;
-                        key[a + 1] = sw ? lo : hi;
-                    }
-                }
+        kmc_static_for<0, N>([&](auto RR) { key[decltype(RR)::value] = key_at<decltype(RR)::value>(s); });
+        // 1. a sorted image.  Round 5: the RANK of every replica among the keys (N (N - 1) / 2 comparisons; equal keys keep their
+        //    order) and ONE run-time permutation (permute_by_rank), instead of an odd-even transposition network of
+        //    N (N - 1) / 2 masked exchanges each renaming every pair through the table — at seven replicas ~750 vector
+        //    instructions where the network took ~2,100 (profiles/r05_orbit_counting.txt).  Any sorted image serves: where
+        //    tied neighbours are interchangeable all of them are the same state, and where they are not the walk below
+        //    goes through every arrangement of the tied runs whichever it starts from.
+        u32 rank[N], runs = 0;
+        kmc_static_for<0, N>([&](auto RR) { rank[decltype(RR)::value] = 0; });
+        u64 equal = 0;   // bit a * N + b: keys of a < b equal
+        kmc_static_for<0, N>([&](auto AA) {
+            kmc_static_for<decltype(AA)::value + 1, N>([&](auto BB) {
+                constexpr int a = decltype(AA)::value, b = decltype(BB)::value;
+                const bool eq = key[a].a == key[b].a && key[a].b == key[b].b;
+                const bool b_first = key[b].a < key[a].a || (key[b].a == key[a].a && key[b].b < key[a].b);
+                rank[a] += b_first ? 1u : 0u;
+                rank[b] += b_first ? 0u : 1u;
+                equal |= (u64)(eq ? 1u : 0u) << (a * N + b);
+            });
+        });
+        permute_by_rank(s, rank, t);
+        // 2. ties: equal keys stand next to each other — boundary rank[a] is tied when some b > a with the same key follows directly
+        kmc_static_for<0, N>([&](auto AA) {
+            kmc_static_for<decltype(AA)::value + 1, N>([&](auto BB) {
+                constexpr int a = decltype(AA)::value, b = decltype(BB)::value;
+                const bool eq = (equal >> (a * N + b)) & 1ull;
+                runs |= (eq && rank[b] == rank[a] + 1u) ? 1u << rank[a] : 0u;
             });
         });
         // tied neighbours: is trading them the identity on t?
-        u32 runs = 0, told_apart = 0;
+        u32 told_apart = 0;
         kmc_static_for<0, N - 1>([&](auto AA) {
             constexpr int a = decltype(AA)::value;
-            const bool tie = key[a].a == key[a + 1].a && key[a].b == key[a + 1].b;
+            const bool tie = (runs >> a) & 1u;
             if (kmc_any_lane(tie)) {
                 u64 u[W];
 #pragma unroll
@@ -308,7 +389,6 @@ template <class M> struct KmcSymm {
                 bool same = true;
 #pragma unroll
                 for (int k = 0; k < W; ++k) same = same && u[k] == t[k];
-                runs |= tie ? 1u << a : 0u;
                 told_apart |= (tie && !same) ? 1u : 0u;
             }
         });

@@ -239,6 +239,50 @@ def test_native_cli_matches_python_cli(capsys):
     assert r.returncode == 0 and "1190091 states generated, 116281 distinct states found, 0 states left on queue." in r.stdout
 
 
+def test_timing_of_a_handle_and_the_clis_account_of_their_wall_time(capsys):
+    """kmc_timing (round 5): where a handle's wall time went besides the search — filled by kmc_open and the first kmc_run —
+    and the closing line both front ends print under -v (bench.py's cold_start block parses the native one)."""
+    import re
+    import subprocess
+    from kafka_specification_amd import tlc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = CheckerConfig(model="Kip320", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1, invariants=("TypeOk",),
+                        table_capacity=1 << 22, frontier_capacity=1 << 20)
+    with ModelChecker(cfg) as mc:
+        t0 = mc.timing()
+        assert t0["open_s"] > 0 and t0["first_clear_s"] == 0.0          # nothing has run yet
+        assert t0["open_s"] >= t0["hip_init_s"] + t0["code_object_s"] + t0["alloc_s"] - 1e-6
+        assert t0["device_bytes"] >= (1 << 22) * 8 + 2 * (1 << 20) * 8 * mc.state_words
+        mc.run()
+        t1 = mc.timing()
+        assert t1["first_clear_s"] > 0 and t1["open_s"] == t0["open_s"]
+        mc.run()
+        assert mc.timing()["first_clear_s"] == t1["first_clear_s"]    # the FIRST clear: fresh memory is touched once
+    exe = os.path.join(root, "kafka_specification_amd", "tlc")
+    args = [os.path.join(root, "models", "FiniteReplicatedLog.tla"), "-table", "1048576", "-frontier", "262144", "-v"]
+    r = subprocess.run([exe] + args, capture_output=True, text=True)
+    assert r.returncode == 0
+    m = re.search(r"Wall time: ([\d.]+)s in this process = ([\d.]+)s before kmc_open .* \+ ([\d.]+)s kmc_open \(HIP initialisation "
+                  r"([\d.]+)s, code object ([\d.]+)s, allocation of ([\d.]+) GiB ([\d.]+)s\) \+ ([\d.]+)s kmc_run \(first clear of the "
+                  r"seen-set ([\d.]+)s, search ([\d.]+)s\) \+ ([\d.]+)s verdict / trace \+ ([\d.]+)s teardown", r.stdout)
+    assert m, r.stdout[-600:]
+    v = [float(x) for x in m.groups()]
+    assert abs(v[0] - (v[1] + v[2] + v[7] + v[10] + v[11])) < 0.01 and v[2] >= v[3] + v[4] + v[6] - 0.002
+    assert "Wall time" not in subprocess.run([exe] + args[:-1], capture_output=True, text=True).stdout   # only under -v
+    assert tlc.main(args) == 0
+    assert "Wall time outside the search: kmc_open" in capsys.readouterr().out
+
+
+def test_both_clis_recommend_wide_entries_when_the_birthday_bound_is_large(capsys):
+    """At 6.45 G states (Kip320 3/6/6/3) the 64-bit search returns one state fewer than the exact count (n^2 / 2^65 = 1.1):
+    from a bound of 0.1 on, the closing estimate comes with the advice to re-run with -fp128 (or -symmetry)."""
+    from kafka_specification_amd.tlc import FP128_ADVICE_ABOVE, collision_report
+    big = collision_report(6452700520, 20756484505)
+    assert any("Recommendation" in ln and "-fp128" in ln for ln in big) and FP128_ADVICE_ABOVE == 0.1
+    assert not any("Recommendation" in ln for ln in collision_report(279753922, 901914892))        # the headline: 2e-3
+    assert not any("Recommendation" in ln for ln in collision_report(6452700520, 20756484505, True))   # already wide
+
+
 def test_overfull_table_stops_quickly():
     """A table far too small must end in `table_full` fast (bounded probe chains), not crawl."""
     import time

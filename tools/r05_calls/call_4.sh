@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 5, call 4: the -m gpu suite once more on the last tree, with the code objects the box had to specialise itself listed
+# (build() should leave none), and the default bench line
+cd "${GRAFT_REPO_ROOT:-.}"
+O=gpurun_out/r05_4; mkdir -p $O
+ls kafka_specification_amd/kmc_cache | sort > $O/cache_before.txt
+( time timeout 1500 python -m pytest tests -x -q -m gpu ) > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
+ls kafka_specification_amd/kmc_cache | sort > $O/cache_after.txt
+echo "specialised on the box:"; comm -13 $O/cache_before.txt $O/cache_after.txt
+tail -5 kafka_specification_amd/kmc_cache/COMPILERS.jsonl
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-200 $O/bench.json
