@@ -260,6 +260,15 @@ KMC_DEV u64 kmc_pull64(int src4, u64 v) {
     const u32 lo = kmc_pull(src4, (u32)v), hi = kmc_pull(src4, (u32)(v >> 32));
     return ((u64)hi << 32) | lo;
 }
+// The sum of x over the wave, in every lane (a butterfly of ds_bpermute / DPP steps).  Its users read it in ONE lane
+// (`if (lane == 0) atomicAdd(..., sum)`): the result is made opaque here, ahead of that branch, for the reason above — a
+// butterfly step that only lane 0 executes adds up zeros.
+KMC_DEV u32 kmc_wave_sum(u32 x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    KMC_OPAQUE(x);
+    return x;
+}
 #endif
 KMC_DEV u32 kmc_min(u32 a, u32 b) { return a < b ? a : b; }
 // does any lane of the wave say so?  (the host emulation runs one state at a time: the lane itself)

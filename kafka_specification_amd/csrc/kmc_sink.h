@@ -99,9 +99,7 @@ template <int W> struct KmcStager {
         if (!publish_counters) return;   // k_expand folds them into its per-block tail (kmc_expand_body)
 #if KMC_SYMM
         {
-            u32 x = corr_won;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            const u32 x = kmc_wave_sum(corr_won);
             if (x && kmc_lane() == 0) atomicAdd(&a.ctl->corr_won, (u64)x);
             corr_won = 0;
         }
@@ -114,6 +112,8 @@ template <int W> struct KmcStager {
                 sm += ((u64)(u32)__shfl_xor((int)(u32)(sm >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)sm, off);
                 xr ^= ((u64)(u32)__shfl_xor((int)(u32)(xr >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)xr, off);
             }
+            kmc_launder(sm);   // (read by lane 0 only, below: kept ahead of that branch — kmc_wave_sum)
+            kmc_launder(xr);
             csum = 0; cxor = 0;
 #endif
             if (kmc_lane() == 0) {
@@ -338,10 +338,12 @@ template <class M> struct KmcSink {
             u64 base = 0;
             if (want) base = atomicAdd(&a.ctl->send_count[kmc_lane()][sub].v, (u64)want);   // lanes 0..P-1, all at once
             // every record lane fetches the base of its destination's run from lane `dst`
+            // (kmc_pull: the value is only USED by the lanes that ship, but lane `dst` need not be one of them — the pull must
+            // run for the whole wave)
             const u32 src = ship ? dst : 0u;
-            const u32 lo = (u32)__shfl((int)(u32)base, (int)src), hi = (u32)__shfl((int)(u32)(base >> 32), (int)src);
+            const u64 run_base = kmc_pull64((int)(src << 2), base);
             if (ship) {
-                const u64 pos = (((u64)hi << 32) | lo) + my_rank;
+                const u64 pos = run_base + my_rank;
                 if (pos < a.send_cap) {
                     u64* rec = a.send + (((u64)dst * KMC_SEGS + sub) * a.send_cap + pos) * (u64)a.rec_words;
 #pragma unroll

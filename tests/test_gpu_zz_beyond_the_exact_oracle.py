@@ -135,3 +135,22 @@ def test_one_step_beyond_the_headline_kip320_with_logsize_7_matches_the_exact_or
     assert r.deadlock_states == g["deadlock_states"]
     if symmetry:
         assert r.orbit_representatives == g["stored"]
+
+
+def test_the_stretch_kip320_with_three_epochs_plain_search_with_wide_entries_matches_the_exact_orbit_oracle():
+    """Kip320 3 / 6 / 6 / 3: 6,452,700,520 distinct states / 20,756,484,505 generated / depth 54 — the workload the frontier
+    sharding is designed for and the size at which a 64-bit fingerprint loses a state (n^2 / 2^65 = 1.1: the
+    default search returns ...519).  The PLAIN search with 128-bit entries (137 GB of seen-set, 1.7 s) against Oracle-O's exact
+    search over orbits (tests/golden/orbit_kip320_3_6_6_3.json, round 5: 1,075,491,542 full states, no fingerprint): every
+    level, every per-disjunct count, the deadlocked states.  (The orbit-counting search is held to the same file in
+    tests/test_gpu_symmetry.py; until round 5 the two GPU searches only had each other.)"""
+    g = json.load(open(os.path.join(GOLDEN, "orbit_kip320_3_6_6_3.json")))
+    cfg = CheckerConfig(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3,
+                        invariants=("TypeOk", "WeakIsr", "StrongIsr"), wide_fingerprint=True,
+                        table_capacity=1 << 33, frontier_capacity=1 << 30)
+    with ModelChecker(cfg) as mc:
+        r = mc.run()
+    assert r.verdict == "ok" and r.queue_left == 0 and sum(g["violating_states"]) == 0
+    assert (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
+    assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
+    assert r.deadlock_states == g["deadlock_states"]
