@@ -355,7 +355,7 @@ KMC_HD inline void kmc_permute_state(const KmcLayout& y, const int* img, const u
 // orbit counting up to this many replicas (7! - 1 = 5039 steps in the table of the walk through all images; 8! would be 40319)
 #define KMC_SYMM_MAX_REPLICAS 7
 #ifndef KMC_SYMM_UNROLLED_MAX   // (a JIT define moves the DEVICE's threshold only — timing runs; the host forms follow the default)
-#define KMC_SYMM_UNROLLED_MAX 4
+#define KMC_SYMM_UNROLLED_MAX 3
 #endif
 // The key of the replica at position r of t — everything about it that does not depend on how the replicas are named:
 // *a = its log; *b = end | hw << BO | ep << 2 BO, then (from bit 2 BO + BE) 1 bit each: names itself as leader, holds itself

@@ -344,6 +344,34 @@ template <class M> struct KmcSymm {
         }
     }
 
+    // Is exchanging the replicas at positions A and A + 1 of t the identity on t, GIVEN that their keys are equal (so their
+    // logs, end offsets, high watermarks and epochs are)?  Then what is left to agree is the naming: every (leader, isr) pair
+    // of the OTHER replicas, of quorumState and of the requests must be unchanged by the renaming A <-> A + 1, and replica A's
+    // own pair must be replica A + 1's renamed (the renaming is an involution: the converse follows).  One table read per pair,
+    // no image built (until round 5 the exchanged state was built and compared word by word: twice the instructions).
+    template <int A> static KMC_DEV bool trade_is_identity(const u64* t, const u32* tab) {
+        if constexpr (!KAFKA) {
+            return true;   // FiniteReplicatedLog: a replica is its log and end offset — the key
+        } else {
+            auto pair_of = [&](auto FF) -> u32 {
+                constexpr int f = decltype(FF)::value;
+                if constexpr (pair_adjacent(f)) return (u32)kmc_getbits(t, pair_ldr_off(f), PB);
+                else return (u32)kmc_getbits(t, pair_ldr_off(f), Y.BL) | ((u32)kmc_getbits(t, pair_isr_off(f), Y.BI) << Y.BL);
+            };
+            u32 changed = 0;
+            kmc_static_for<0, NPAIR>([&](auto FF) {
+                constexpr int f = decltype(FF)::value;
+                if constexpr (f != A && f != A + 1) {
+                    const u32 idx = pair_of(FF);
+                    changed |= idx ^ tab[(A << PB) | idx];
+                }
+            });
+            const u32 pa = pair_of(KmcIC<A>{}), pb = pair_of(KmcIC<A + 1>{});
+            changed |= pa ^ tab[(A << PB) | pb];
+            return changed == 0;
+        }
+    }
+
     static KMC_DEV void canon_sorted(const u64* s, const u32* tab, u64* c, u32& stab) {
         u64 t[W];
         Key key[N];
@@ -381,16 +409,7 @@ template <class M> struct KmcSymm {
         kmc_static_for<0, N - 1>([&](auto AA) {
             constexpr int a = decltype(AA)::value;
             const bool tie = (runs >> a) & 1u;
-            if (kmc_any_lane(tie)) {
-                u64 u[W];
-#pragma unroll
-                for (int k = 0; k < W; ++k) u[k] = t[k];
-                exchange<a>(u, tab, tie ? ~0ull : 0ull);
-                bool same = true;
-#pragma unroll
-                for (int k = 0; k < W; ++k) same = same && u[k] == t[k];
-                told_apart |= (tie && !same) ? 1u : 0u;
-            }
+            if (kmc_any_lane(tie)) told_apart |= (tie && !trade_is_identity<a>(t, tab)) ? 1u : 0u;
         });
         if (kmc_any_lane(told_apart != 0)) {   // (every lane takes the walk's answer: where nothing is told apart it is the same)
             stab = walk<true>(t, tab, c, runs);

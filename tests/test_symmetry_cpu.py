@@ -112,7 +112,7 @@ def constructed_state(rnd, model, N, L, R, E, told_apart_tie):
     return bytes(b)
 
 
-UNROLLED_MAX = 4   # KMC_SYMM_UNROLLED_MAX (kmc_layout.h)
+UNROLLED_MAX = 3   # KMC_SYMM_UNROLLED_MAX (kmc_layout.h)
 
 
 def _consts(cfg6):

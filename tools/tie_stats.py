@@ -1,5 +1,5 @@
 """How often do replicas with EQUAL KEYS turn out not to be interchangeable?  (KmcSymm::canon_sorted, kmc_device.h: the
-representative of an orbit at five and six replicas is chosen among the images whose replica keys ascend; where neighbours'
+representative of an orbit from four replicas on is chosen among the images whose replica keys ascend; where neighbours'
 keys tie, exchanging them is almost always the identity, and only otherwise does the wave walk through all the images.)
 CPU only: a prefix of the plain search through the host-compiled device templates (tests/host_emu), every successor's keys
 restated on its canonical bytes at three strengths:
