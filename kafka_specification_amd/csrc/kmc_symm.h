@@ -473,6 +473,20 @@ template <class M> struct KmcSymm {
             return n;
         }
     }
+    // The same number for k_insert's records (Init, and every record a shard receives).  Beyond KMC_SYMM_UNROLLED_MAX replicas
+    // stabiliser() walks through all N! images — 5,039 steps at seven replicas, for every 64 records: the sorted form gives the
+    // order of the stabiliser as the product of its tied runs' factorials for ~2 k instructions (canon_sorted; the walk only
+    // where tied replicas are told apart).  stabiliser() stays what the host emulation holds canon()'s count to.
+    static KMC_DEV u32 stabiliser_of_record(const u64* s, const u32* tab) {
+        if constexpr (!UNROLLED) {
+            u64 c[W];
+            u32 st;
+            canon_sorted(s, tab, c, st);
+            return st;
+        } else {
+            return stabiliser(s, tab);
+        }
+    }
     // what a state of stabiliser order `stab` lacks to a full orbit: N! - N!/stab (0 for almost every state)
     static KMC_DEV u32 deficit(u32 stab) { return stab == 1 ? 0u : (u32)NFACT - (u32)NFACT / stab; }
 };
