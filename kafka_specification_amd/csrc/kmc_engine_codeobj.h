@@ -1,0 +1,345 @@
+// kmc_engine_codeobj.h — part of kmc_engine.cpp (ONE translation unit: kmc_engine.cpp includes the parts in order): the code objects: validation of a configuration, the text handed to hiprtc, the on-disk cache, the register-budget rule.
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[2048];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(KMC_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+const char* const MODEL_NAMES[] = {"IdSequence", "FiniteReplicatedLog", "KafkaTruncateToHighWatermark",
+                                   "Kip101",     "Kip279",              "Kip320",
+                                   "Kip320FirstTry", "AsyncIsr"};
+const char* const INV_NAMES[] = {"TypeOk", "WeakIsr", "StrongIsr", "LeaderInIsr"};
+// AsyncIsr.tla:62,161; LeaderOffsetInRange is defined in models/MCAsyncIsr.tla (not in the reference)
+const char* const INV_NAMES_ASYNC[] = {"TypeOk", "ValidHighWatermark", "LeaderOffsetInRange", "?"};
+const char* const KINDS_ASYNC[] = {"ControllerShrinkIsr", "ControllerHandleRequest", "LeaderRequestShrinkIsr",
+                                   "LeaderRequestExpandIsr", "LeaderWrite", "LeaderHandleUpdate", "FollowerReplicate"};
+
+const char* const KINDS_BASE[] = {"ControllerElectLeader", "ControllerShrinkIsr", "BecomeLeader",
+                                  "LeaderExpandIsr",       "LeaderShrinkIsr",     "LeaderWrite",
+                                  "LeaderIncHighWatermark", nullptr,              "FollowerReplicate"};
+const char* const KINDS_KIP320[] = {"ControllerElectLeader",        "ControllerShrinkIsr",
+                                    "BecomeLeader",                 "FencedLeaderExpandIsr",
+                                    "FencedLeaderShrinkIsr",        "LeaderWrite",
+                                    "FencedLeaderIncHighWatermark", "FencedBecomeFollowerAndTruncate",
+                                    "FencedFollowerFetch"};
+const char* const KINDS_FIRST[] = {"ControllerElectLeader",
+                                   "ControllerShrinkIsr",
+                                   "BecomeLeader",
+                                   "LeaderExpandIsrBetterFencing",
+                                   "LeaderShrinkIsrBetterFencing",
+                                   "LeaderWrite",
+                                   "ImprovedLeaderIncHighWatermark",
+                                   "BecomeFollower",
+                                   "FollowerFetch",
+                                   "FollowerTruncate"};
+const char* const KINDS_FRL[] = {"Append", "TruncateTo", "ReplicateTo"};
+
+uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+    for (unsigned char c : s) {
+        h ^= c;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::string* inst) {
+    char buf[256];
+    switch (c.model) {
+    case KMC_IDSEQUENCE:
+        if (c.max_id < 0) return false;
+        *lay = kmc_make_layout(c.model, 0, 0, 0, 0, 0);
+        snprintf(buf, sizeof buf, "IdSequence_M%lld", (long long)c.max_id);
+        *name = buf;
+        snprintf(buf, sizeof buf, "KmcIdSequence<%lldLL>", (long long)c.max_id);
+        *inst = buf;
+        return true;
+    case KMC_FINITE_REPLICATED_LOG:
+        *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, 0, 0, c.n_log_records);
+        if (!lay->valid || c.n_replicas < 2) return false;
+        snprintf(buf, sizeof buf, "FiniteReplicatedLog_N%d_L%d_K%d%s", c.n_replicas, c.log_size, c.n_log_records,
+                 c.symmetry ? "_sym" : "");
+        *name = buf;
+        snprintf(buf, sizeof buf, "KmcFiniteReplicatedLog<%d,%d,%d>", c.n_replicas, c.log_size, c.n_log_records);
+        *inst = buf;
+        return true;
+    case KMC_ASYNC_ISR:  // log_size = MaxOffset, max_leader_epoch = MaxVersion (the constraint's bounds)
+        *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, 0, c.max_leader_epoch, 0);
+        if (!lay->valid || c.n_replicas < 1 || c.log_size < 1) return false;  // ASSUME MaxOffset > 0, AsyncIsr.tla:28
+        snprintf(buf, sizeof buf, "AsyncIsr_N%d_O%d_V%d", c.n_replicas, c.log_size, c.max_leader_epoch);
+        *name = buf;
+        snprintf(buf, sizeof buf, "KmcAsyncIsr<%d,%d,%d>", c.n_replicas, c.log_size, c.max_leader_epoch);
+        *inst = buf;
+        return true;
+    case KMC_TRUNCATE_TO_HW:
+    case KMC_KIP101:
+    case KMC_KIP279:
+    case KMC_KIP320:
+    case KMC_KIP320_FIRST_TRY: {
+        // KMC_LAYOUT=tight|rm (tests, A/B measurements) overrides the automatic choice between the two arrangements of
+        // the state vector (kmc_layout.h); host and device evaluate the same constexpr function with the same mode
+        const char* lenv = getenv("KMC_LAYOUT");
+        const int lm = !lenv || !*lenv || !strcmp(lenv, "auto") ? KMC_LAYOUT_AUTO
+                       : !strcmp(lenv, "tight") ? KMC_LAYOUT_TIGHT : !strcmp(lenv, "rm") ? KMC_LAYOUT_RM
+                       : !strcmp(lenv, "rmg") ? KMC_LAYOUT_RMG : -1;
+        if (lm < 0) return false;
+        *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, c.max_records, c.max_leader_epoch, 0, lm);
+        if (!lay->valid || c.n_replicas < 2) return false;
+        snprintf(buf, sizeof buf, "%s_N%d_L%d_R%d_E%d%s%s", MODEL_NAMES[c.model], c.n_replicas, c.log_size,
+                 c.max_records, c.max_leader_epoch,
+                 lm == KMC_LAYOUT_TIGHT ? "_tight" : lm == KMC_LAYOUT_RM ? "_rm" : lm == KMC_LAYOUT_RMG ? "_rmg" : "",
+                 c.symmetry ? "_sym" : "");
+        *name = buf;
+        snprintf(buf, sizeof buf, "KmcKafka<%d,%d,%d,%d,%d,%d>", c.model, c.n_replicas, c.log_size, c.max_records,
+                 c.max_leader_epoch, lm);
+        *inst = buf;
+        return true;
+    }
+    default: return false;
+    }
+}
+
+std::string strip_for_concat(const char* src) {
+    // drop '#pragma once' and the local includes so the parts can be fed to hiprtc as one file; drop `//` comments
+    // (line structure kept) so that the text — and with it the key of the code-object cache — only changes with the code
+    std::string out, line;
+    for (const char* p = src;; ++p) {
+        if (*p == '\n' || *p == 0) {
+            bool in_str = false;
+            for (size_t k = 0; k + 1 < line.size(); ++k) {
+                if (line[k] == '"' && (k == 0 || line[k - 1] != '\\')) in_str = !in_str;
+                if (!in_str && line[k] == '/' && line[k + 1] == '/') {
+                    line.erase(k);
+                    while (!line.empty() && (line.back() == ' ' || line.back() == '\t')) line.pop_back();
+                    break;
+                }
+            }
+            if (line.rfind("#pragma once", 0) != 0 && line.rfind("#include \"kmc_", 0) != 0) {
+                out += line;
+            }
+            out += '\n';
+            line.clear();
+            if (*p == 0) break;
+        } else {
+            line += *p;
+        }
+    }
+    return out;
+}
+
+std::string default_cache_dir() {
+    if (const char* e = getenv("KMC_CACHE_DIR")) return e;
+    Dl_info info;
+    if (dladdr((void*)&default_cache_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t k = p.find_last_of('/');
+        if (k != std::string::npos) return p.substr(0, k) + "/kmc_cache";
+    }
+    return "./kmc_cache";
+}
+
+bool read_file(const std::string& path, std::vector<char>* out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out->resize(n > 0 ? n : 0);
+    bool ok = n > 0 && fread(out->data(), 1, n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+// .vgpr_spill_count of one kernel, read from the code object's AMDGPU metadata note (msgpack: the
+// keys of a kernel's map are sorted, so the count follows the kernel's ".name" value).  -1 = not found.
+#define KMC_MAX_VGPR_SPILLS 8
+long expand_vgpr_spills(const std::vector<char>& code, const std::string& kernel) {
+    const std::string blob(code.begin(), code.end());
+    size_t at = blob.find(kernel);
+    while (at != std::string::npos) {  // the name also occurs in the symbol table: take the one inside the metadata
+        const size_t key = blob.find(".vgpr_spill_count", at);
+        const size_t next_name = blob.find(".name", at + kernel.size());
+        if (key != std::string::npos && (next_name == std::string::npos || key < next_name || key - at < 2048)) {
+            const unsigned char* q = (const unsigned char*)blob.data() + key + 17;
+            if (q[0] <= 0x7f) return q[0];
+            if (q[0] == 0xcc) return q[1];
+            if (q[0] == 0xcd) return (q[1] << 8) | q[2];
+            if (q[0] == 0xce) return ((long)q[1] << 24) | (q[2] << 16) | (q[3] << 8) | q[4];
+            return -1;
+        }
+        at = blob.find(kernel, at + 1);
+    }
+    return -1;
+}
+
+// Compile (or fetch from the cache) the code object specialised for cfg.
+// `mode` = which k_expand the object holds (kmc_kernels.h, KMC_ONLY_MODE): KMC_MODE_LOCAL — the search's own kernel with the
+// small kernels around it — KMC_MODE_SHARDED or KMC_MODE_ENUM; one cached file each, so that a front end which never steps or
+// enumerates never pays for those kernels, and the search's kernel is not recompiled (minutes at seven brokers) for them.
+const char* const MODE_SUFFIX[3] = {"", "_sh", "_en"};
+const char* const MODE_FILE_TAG[3] = {"", "-sharded", "-enum"};
+int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<char>* code, std::string* kname,
+                    const char* extra_options = nullptr, std::string* path_out = nullptr, unsigned mode = KMC_MODE_LOCAL,
+                    const std::string* jit_defines = nullptr) {
+    if (mode > KMC_MODE_ENUM) return fail(KMC_E_ARG, "no code object for mode %u", mode);
+    KmcLayout lay;
+    std::string name, inst;
+    if (!validate(cfg, &lay, &name, &inst))
+        return fail(KMC_E_ARG, "unsupported model/constants (model=%d N=%d L=%d R=%d E=%d K=%d): need 2<=N<=8, "
+                               "L*bits(record)<=64, E<=7 (AsyncIsr: N<=6, MaxVersion<=7)", cfg.model, cfg.n_replicas, cfg.log_size,
+                    cfg.max_records, cfg.max_leader_epoch, cfg.n_log_records);
+    *kname = name;
+    if (cfg.symmetry && (!kmc_model_symmetric(cfg.model) || cfg.n_replicas > KMC_SYMMETRY_MAX_REPLICAS))
+        return fail(KMC_E_ARG, "symmetry (orbit counting) is for the Kafka family and FiniteReplicatedLog with at most 7 replicas: "
+                               "%s singles out a replica, or N = %d > %d",
+                    MODEL_NAMES[cfg.model], cfg.n_replicas, KMC_SYMMETRY_MAX_REPLICAS);
+
+    // optional tuning overrides, e.g. KMC_JIT_DEFINES="-DKMC_MIN_WAVES=5 -DKMC_PROFILE=1"
+    std::vector<std::string> defines;
+    std::string defines_key;
+    // (a handle's later code objects — ensure_mode — are built with the defines its first one was opened under: jit_defines)
+    std::string all_defines = jit_defines ? *jit_defines : getenv("KMC_JIT_DEFINES") ? getenv("KMC_JIT_DEFINES") : "";
+    if (extra_options) all_defines += std::string(" ") + extra_options;
+    if (cfg.symmetry) all_defines += " -DKMC_SYMM=1";
+    if (mode != KMC_MODE_LOCAL) all_defines += " -DKMC_ONLY_MODE=" + std::to_string(mode);
+    if (!all_defines.empty()) {
+        const char* d = all_defines.c_str();
+        std::string tok;
+        for (const char* q = d;; ++q) {
+            if (*q == ' ' || *q == 0) {
+                if (!tok.empty()) { defines.push_back(tok); defines_key += tok + " "; }
+                tok.clear();
+                if (*q == 0) break;
+            } else {
+                tok += *q;
+            }
+        }
+    }
+    std::string src = strip_for_concat(KMC_SRC_DEVICE) + "\nKMC_INSTANTIATE(" +
+                      name + ", " + inst + ")\n";
+    // ONE code object per (source, architecture, defines), whoever compiled it.  The PyTorch wheel bundles its own
+    // hiprtc / comgr next to the system ROCm's (same hiprtcVersion, different LLVM builds: from round 4's source on they emit
+    // different instructions for the same text), and a process binds to one or the other (_native.py).  Rounds 1-3 keyed the
+    // cache by the HIP runtime's build number too, so the bench (torch's runtime) and a rocprofv3 run (system ROCm) each
+    // compiled and ran their own object — a profile then described other machine code than the line it is quoted beside.
+    // A gfx950 code object loads under either runtime: the cache is keyed by what is compiled, not by who asks.
+    int rtc_major = 0, rtc_minor = 0;
+    hiprtcVersion(&rtc_major, &rtc_minor);
+    char key[64];
+    snprintf(key, sizeof key, "%016llx",
+             (unsigned long long)fnv1a(src + "|" + arch + "|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
+                                       "|" + defines_key));
+    const std::string dir = cfg.cache_dir ? std::string(cfg.cache_dir) : default_cache_dir();
+    const std::string path = dir + "/" + name + "-" + arch + "-" + key + MODE_FILE_TAG[mode] + ".hsaco";
+    if (path_out) *path_out = path;
+    if (read_file(path, code)) return KMC_OK;
+    if (getenv("KMC_VERBOSE"))
+        fprintf(stderr, "[kmc] specialising kernels for %s (first use; wide configurations take minutes)\n", name.c_str());
+
+    // k_expand is compiled for 6 waves/SIMD (80 VGPRs).  Wide configurations (7-8 replicas: hundreds of
+    // action instances, several words of state) do not fit: at 184 spilled VGPRs on top of 466 spilled
+    // SGPRs, Kip320 with 7 replicas lost successors (six missing states at BFS level 3; the same code is
+    // right at -O1, at -O0 and with a larger register budget, and the model templates are right when
+    // compiled for the host — tests/test_device_models_on_host.py).  So the register budget follows the
+    // kernel: recompile with fewer waves per SIMD until k_expand spills (almost) no VGPRs.  An explicit
+    // -DKMC_MIN_WAVES in KMC_JIT_DEFINES is respected as given.
+    const bool waves_forced = defines_key.find("KMC_MIN_WAVES") != std::string::npos;
+    size_t n = 0;
+    for (int waves = 6; waves >= 1;) {
+        hiprtcProgram prog;
+        if (hiprtcCreateProgram(&prog, src.c_str(), "kmc_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+            return fail(KMC_E_COMPILE, "hiprtcCreateProgram failed");
+        const std::string archopt = "--offload-arch=" + arch;
+        const std::string wavesopt = "-DKMC_MIN_WAVES=" + std::to_string(waves);
+        std::vector<const char*> opts = {archopt.c_str(), "-O3", "-std=c++17"};
+        if (!waves_forced) opts.push_back(wavesopt.c_str());
+        for (const std::string& d : defines) opts.push_back(d.c_str());
+        hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+        if (r != HIPRTC_SUCCESS) {
+            size_t ln = 0;
+            hiprtcGetProgramLogSize(prog, &ln);
+            std::string log(ln, 0);
+            if (ln) hiprtcGetProgramLog(prog, &log[0]);
+            hiprtcDestroyProgram(&prog);
+            return fail(KMC_E_COMPILE, "hiprtc failed for %s: %s\n%.1500s", name.c_str(), hiprtcGetErrorString(r), log.c_str());
+        }
+        hiprtcGetCodeSize(prog, &n);
+        code->resize(n);
+        hiprtcGetCode(prog, code->data());
+        hiprtcDestroyProgram(&prog);
+        const long spills = expand_vgpr_spills(*code, std::string("kmc_expand") + MODE_SUFFIX[mode] + "_" + name);
+        if (waves_forced) break;  // an explicit -DKMC_MIN_WAVES (tuning, bug hunts) is taken as given and never cached as default
+        // The guard must not pass by accident: an unreadable spill count, or a kernel that still spills at
+        // one wave per SIMD, is a failed specialisation — not a kernel to run and cache.
+        if (spills < 0)
+            return fail(KMC_E_COMPILE, "cannot read .vgpr_spill_count of kmc_expand%s_%s from the code object's metadata: "
+                                       "the register-budget rule cannot be checked", MODE_SUFFIX[mode], name.c_str());
+        if (spills <= KMC_MAX_VGPR_SPILLS) break;
+        if (waves == 1)
+            return fail(KMC_E_COMPILE, "kmc_expand%s_%s spills %ld vector registers even at one wave per SIMD: constants too "
+                                       "wide for this kernel shape", MODE_SUFFIX[mode], name.c_str(), spills);
+        // (these kernels take up to minutes to compile: jump by the size of the overflow, do not crawl)
+        // (a near miss at 6 waves gets 5 — 96 registers: the kind-major headline kernel spills 9 at 80 and 2 at 96 and runs
+        // equally fast at either, profiles/r03_kind_major.txt)
+        // (the orbit-counting headline kernel spills 23 at 80: at 5 waves — 96 registers, 8 spilled — it runs 7.4 ms, at 4 waves
+        // — 108, none — 7.7 ms, profiles/r03_symmetry.txt: a miss of up to 24 tries 5 first and falls to 4 from there)
+        const int next = spills > 64 ? 2 : spills > 40 ? 3 : spills > 24 ? 4 : 5;
+        waves = next < waves ? next : waves - 1;
+    }
+    // best-effort cache write (atomic rename)
+    mkdir(dir.c_str(), 0755);
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    if (FILE* f = fopen(tmp.c_str(), "wb")) {
+        bool ok = fwrite(code->data(), 1, n, f) == n;
+        fclose(f);
+        if (ok) rename(tmp.c_str(), path.c_str());
+        else unlink(tmp.c_str());
+        // Who compiled it.  The key above holds hiprtc's major.minor only (so that the bench under torch's runtime and a
+        // rocprofv3 run under the system's load the SAME object), but the two bundled compilers emit different instructions for
+        // the same text: which of them filled this slot of the cache is recorded beside it — COMPILERS.jsonl, one appended line
+        // per object written (bench.py reports it next to kernel_code_sha256; an object from a compiler found to be bad can be
+        // told from its neighbours and deleted).
+        if (ok) {
+            int rt = 0;
+            (void)hipRuntimeGetVersion(&rt);
+            if (FILE* idx = fopen((dir + "/COMPILERS.jsonl").c_str(), "ab")) {
+                const size_t slash = path.find_last_of('/');
+                fprintf(idx, "{\"file\": \"%s\", \"hiprtc\": \"%d.%d\", \"hip_runtime_version\": %d, \"waves\": \"%s\"}\n",
+                        path.substr(slash == std::string::npos ? 0 : slash + 1).c_str(), rtc_major, rtc_minor, rt,
+                        waves_forced ? "as given" : "rule");
+                fclose(idx);
+            }
+        }
+    }
+    return KMC_OK;
+}
+
+uint64_t pow2_floor(uint64_t x) {
+    uint64_t p = 1;
+    while (p * 2 <= x) p *= 2;
+    return p;
+}
+uint64_t pow2_ceil(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p *= 2;
+    return p;
+}
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
