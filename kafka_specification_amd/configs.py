@@ -101,7 +101,7 @@ def precompile_variants():
     return [(small, {"KMC_VERIFY": "1"}), (wide, {"KMC_VERIFY": "1"}), (golden, {"KMC_VERIFY": "1"}), (small, fault),
             (small, dict(fault, KMC_VERIFY="1")),
             (dict(model="AsyncIsr", n_replicas=3, log_size=2, max_leader_epoch=2), fault),
-            (small, {"KMC_JIT_DEFINES": "-DKMC_TUNING=1 -DKMC_TEST_FP_BITS=10"})] + layout_variants() + symmetry_variants() + full_leaves_variants()   # (collisions on demand for the wide-fingerprint test)
+            (small, {"KMC_JIT_DEFINES": "-DKMC_TUNING=1 -DKMC_TEST_FP_BITS=10"})] + layout_variants() + symmetry_variants() + full_leaves_variants() + deferred_probe_variants()   # (collisions on demand for the wide-fingerprint test)
 
 
 # The arrangements of the Kafka state vector (csrc/kmc_layout.h) and the two walks of k_expand's pass 2 that go with them:
@@ -134,6 +134,24 @@ def full_leaves_variants():
         return dict(model=t[0], n_replicas=t[1], log_size=t[2], max_records=t[3], max_leader_epoch=t[4], **kw)
     out = [(c(t), env) for t in sorted(set(FULL_LEAVES_SMALL + FULL_LEAVES_TRACES))]
     out += [(c(t, symmetry=True), env) for t in sorted(set(FULL_LEAVES_SYMMETRY + FULL_LEAVES_TRACES))]
+    return out
+
+
+# The deferred probe (the search's flush on states of >= 8 words: csrc/kmc_kernels.h) forced onto small configurations:
+# tests/test_gpu_deferred_probe.py
+DEFERRED_PROBE_DEFINES = "-DKMC_DEFER_MIN_WORDS=1"
+DEFERRED_PROBE_SMALL = [(m, 3, 2, 2, 1) for m in KAFKA] + [("Kip320", 4, 2, 2, 1), ("Kip279", 5, 1, 1, 1), ("Kip320", 3, 2, 2, 2)]
+DEFERRED_PROBE_SYMMETRY = [("Kip320", 3, 2, 2, 1), ("Kip279", 3, 2, 2, 2), ("Kip101", 4, 2, 1, 1), ("Kip279", 5, 1, 1, 1)]
+DEFERRED_PROBE_TRACES = [("Kip279", 3, 2, 2, 2), ("Kip101", 3, 2, 2, 2)]
+
+
+def deferred_probe_variants():
+    env = {"KMC_JIT_DEFINES": DEFERRED_PROBE_DEFINES}
+
+    def c(t, **kw):
+        return dict(model=t[0], n_replicas=t[1], log_size=t[2], max_records=t[3], max_leader_epoch=t[4], **kw)
+    out = [(c(t), env) for t in sorted(set(DEFERRED_PROBE_SMALL + DEFERRED_PROBE_TRACES))]
+    out += [(c(t, symmetry=True), env) for t in sorted(set(DEFERRED_PROBE_SYMMETRY))]
     return out
 
 

@@ -96,6 +96,10 @@ typedef unsigned int u32;
 #ifndef KMC_FULL_LEAVES_PLAIN
 #define KMC_FULL_LEAVES_PLAIN 0               // 1: ... and so does the plain search (measured: a 2 % loss on BASELINE config 5)
 #endif
+#ifndef KMC_DEFER_MIN_WORDS
+#define KMC_DEFER_MIN_WORDS 8   // states of at least this many words (seven brokers with deep logs: 2 waves per SIMD by LDS) run
+                                // the search's flush with a DEFERRED probe: kmc_expand_body
+#endif
 #ifndef KMC_SYMM
 #define KMC_SYMM 0        // 1 (kmc_config.symmetry): symmetry reduction with orbit counting — every successor is replaced by the
                           // representative of its orbit under the permutations of Replicas before it is fingerprinted, and

@@ -209,6 +209,21 @@ template <class M> struct KmcSink {
         return false;
     }
 
+    // claim() for a successor whose FIRST probe was issued earlier (kmc_expand_body's deferred probe): v = what table[i] held
+    // then.  Slots only ever change 0 -> fp, so the old value is as good as a fresh one: a stale 0 is corrected by the CAS,
+    // anything else is still there.  Further steps of the chain, if any, probe as usual.
+    static KMC_DEV bool claim_loaded(const KmcArgsLocal& a, u64 fp, u64 i, u64 v, u64 meta) {
+        if (v == 0) {
+            v = atomicCAS(&a.table[i], 0ull, fp);
+            if (v == 0) {
+                if (a.pred) a.pred[i] = meta;
+                return true;
+            }
+        }
+        if (v == fp) return false;
+        return claim_from(a, fp, (i + 1) & a.table_mask, meta);
+    }
+
     // the narrow or the wide table, as the handle was opened (a wave-uniform branch); the check word is the same
     // fingerprint function under another seed
     static KMC_DEV bool claim_any(const KmcArgsLocal& a, const u64* t, u64 fp, u64 meta) {
@@ -265,15 +280,18 @@ template <class M> struct KmcSink {
     // ENUM lists the successor itself with the representative's fingerprint, so that a trace replayed through kmc_successors
     // is a real behaviour whose states are FOUND by the fingerprints of their representatives.  stab = the order of t's
     // stabiliser: it travels with a new state (KmcStager) and gives the orbit's deficit.
+    static KMC_DEV u64 fingerprint_of(const u64* t, u64 seed) {
+#ifdef KMC_TEST_FP_BITS   // tests only: a fingerprint of that many bits, i.e. collisions on demand (the wide table's check
+                          // word keeps its 64 bits) — tests/test_gpu_selfcheck_and_fp128.py
+        return kmc_mix64((kmc_fingerprint<W>(t, seed) & ((1ull << (KMC_TEST_FP_BITS)) - 1)) + 0x9E3779B97F4A7C15ull) | 1ull;
+#else
+        return kmc_fingerprint<W>(t, seed);
+#endif
+    }
     template <u32 MODE>
     static KMC_DEV void process(const typename KmcArgsOf<MODE>::type& a, KmcStager<W>& out, bool valid, const u64* t, u64 meta,
                                 const u64* raw = nullptr, u32 stab = 1) {
-#ifdef KMC_TEST_FP_BITS   // tests only: a fingerprint of that many bits, i.e. collisions on demand (the wide table's check
-                          // word keeps its 64 bits) — tests/test_gpu_selfcheck_and_fp128.py
-        const u64 fp = kmc_mix64((kmc_fingerprint<W>(t, a.seed) & ((1ull << (KMC_TEST_FP_BITS)) - 1)) + 0x9E3779B97F4A7C15ull) | 1ull;
-#else
-        const u64 fp = kmc_fingerprint<W>(t, a.seed);
-#endif
+        const u64 fp = fingerprint_of(t, a.seed);
         out.account(valid, fp);
         if constexpr (MODE == KMC_MODE_DRY) {
             u64 acc = fp;
