@@ -1,3 +1,5 @@
+#!/bin/bash
+# round 5, call 9b: Kip279 / Kip320 7/1/1/0 under orbit counting, four runs each, twice — the 1 ms / 23 ms searches (call_9c.sh: fixed)
 cd "${GRAFT_REPO_ROOT:-.}"
 export KMC_NO_TORCH=1
 for i in 1 2; do for w in "Kip279 7 1 1 0" "Kip320 7 1 1 0"; do
