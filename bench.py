@@ -61,17 +61,16 @@ def kernel_code_sha256_of(c, symmetry=False):
 
 
 def kernel_compiler_of(c, symmetry=False):
-    """Which compiler wrote the cached code object this run loads (COMPILERS.jsonl beside it: the cache is keyed by what is
-    compiled, not by who compiles — the two HIP runtimes a box holds emit different instructions for the same text)."""
+    """Which compiler wrote the code object this run loads — read from the object's FILE NAME (`...-c<HIP runtime build of the
+    compiler's bundle>.hsaco`: two compilers can never write the same file) — and which one is pinned (csrc/kmc_engine_internal.h,
+    KMC_PINNED_COMPILER; profiles/r06_compiler_ab.txt holds the A/B behind the choice)."""
+    import re
     try:
         import kafka_specification_amd as kmc
         path = kmc.code_object_path(kmc.CheckerConfig(**{k: v for k, v in c.items() if k != "max_levels"}, symmetry=symmetry))
-        last = None
-        for line in open(os.path.join(os.path.dirname(path), "COMPILERS.jsonl")):
-            j = json.loads(line)
-            if j.get("file") == os.path.basename(path):
-                last = j
-        return {k: v for k, v in last.items() if k != "file"} if last else None
+        m = re.search(r"-c(\d+)(?:-sharded|-enum)?\.hsaco$", path)
+        return {"hip_runtime_version_of_the_compiler": int(m.group(1)) if m else None, "file": os.path.basename(path),
+                "pinned": kmc.compiler_identity(1), "this_process": kmc.compiler_identity(0)}
     except Exception:
         return None
 
@@ -261,7 +260,7 @@ def cold_start(c):
     return out
 
 
-def cpu_baseline(c, budget_states, total_states):
+def cpu_baseline(c, budget_states, total_states, whole="the reachable set"):
     """The C oracle (exact-state BFS, a port — TLC itself cannot run here) on all host cores,
     on a bounded prefix of the same workload: it stops after the BFS level that crosses
     `budget_states` distinct states."""
@@ -278,7 +277,7 @@ def cpu_baseline(c, budget_states, total_states):
     dt = time.time() - t0
     out = dict(value=run.distinct / max(run.seconds, 1e-9), unit="distinct states/s", cores=threads, kind="port",
                sample=(f"first {run.depth} BFS levels of the same workload ({run.distinct} distinct states = "
-                       f"{100.0 * run.distinct / max(total_states, 1):.1f} % of the reachable set, {run.seconds:.1f} s) with "
+                       f"{100.0 * run.distinct / max(total_states, 1):.1f} % of {whole}, {run.seconds:.1f} s) with "
                        f"oracle/kmc_oracle.c, {threads} threads; not TLC (no JVM on this box)"),
                seconds=round(dt, 2))
     run.close()
@@ -323,17 +322,25 @@ BASELINE_LEGS = {
     # Kip279.tla:53-62 at five brokers: exhaustible, 112,549,196 states (tests/golden/oracle_kip279_5_2_2_1.json, exact)
     "config4_kip279_5brokers": dict(
         c=dict(model="Kip279", n_replicas=5, log_size=2, max_records=2, max_leader_epoch=1, invariants=("TypeOk",)),
-        table=1 << 30, frontier=1 << 26),
+        table=1 << 30, frontier=1 << 26, cpu_states=0),     # cpu_baseline: the whole search (about ten seconds on 32 threads)
     # Kip320.tla:150-159 at seven brokers, LogSize 8: nobody exhausts it — ten BFS levels, 197,561,008
     # states (tests/golden/oracle_kip320_7_8_8_3_levels10.json, exact), reported with "exhausted": false
     "config5_kip320_7brokers_levels10": dict(
         c=dict(model="Kip320", n_replicas=7, log_size=8, max_records=8, max_leader_epoch=3,
                invariants=("TypeOk", "WeakIsr", "StrongIsr"), max_levels=10),
-        table=1 << 31, frontier=1 << 29),
+        # (table: 2^30 slots = load 0.18 at the tenth level.  Round 5 ran it at 2^31: 2.8 ms of every 35 ms step went into
+        # clearing 16 GiB for 197 M states; profiles/r06_config5.txt holds the A/B)
+        table=int(os.environ.get("KMC_BENCH_TABLE5", 1 << 30)), frontier=1 << 29, cpu_states=5_000_000),
 }
 
 
-def baseline_leg(name, steps, warmup):
+def step_breakdown(ms_per_step, kernel_s, inv_s, clear_s):
+    """Where a step's wall time goes (HIP events on the engine's stream; the rest is host latency around the waits)."""
+    return {"k_expand_ms": 1e3 * kernel_s, "k_inv_ms": 1e3 * inv_s, "clear_seen_set_ms": 1e3 * clear_s,
+            "host_and_rest_ms": ms_per_step - 1e3 * (kernel_s + inv_s + clear_s)}
+
+
+def baseline_leg(name, steps, warmup, with_cpu=True):
     """One BASELINE config beside the headline: the same measurement (whole kmc_run steps, inputs resident, k_expand time from HIP
     events on the engine's stream), its counts against the committed exact fixture, its own roofline block."""
     spec = BASELINE_LEGS[name]
@@ -346,7 +353,16 @@ def baseline_leg(name, steps, warmup):
     exp = expected_counts(c)
     A, S, g, probes = algorithmic_bytes_per_state(r)
     kernel_s = sum(x.seconds_expand for x in results) / len(results)
+    inv_s = sum(x.seconds_inv for x in results) / len(results)
+    clear_s = sum(x.seconds_clear for x in results) / len(results)
     code = kernel_code_sha256_of({k: v for k, v in c.items() if k != "max_levels"})
+    cpu = None
+    if with_cpu:
+        try:   # the same search (or, under a level budget, a prefix of its levels) on the host cores: a port, not TLC
+            cpu = cpu_baseline({k: v for k, v in c.items() if k != "max_levels"}, spec["cpu_states"], r.distinct,
+                               whole="the reachable set" if not c.get("max_levels") else f"the {c['max_levels']}-level prefix")
+        except Exception as e:
+            cpu = {"error": str(e)[:200]}
     traffic, traffic_source = measured_traffic(code, c.get("max_levels"), r.depth)
     achieved = A * r.distinct / max(kernel_s, 1e-12)
     return {
@@ -360,10 +376,134 @@ def baseline_leg(name, steps, warmup):
                                                            and (exp["levels"] is None or list(r.levels) == list(exp["levels"]))),
         "oracle_golden": exp["file"] if exp else None,
         "kernel_seconds_per_step": kernel_s, "launches_per_step": r.expand_launches,
+        "step_breakdown": step_breakdown(1e3 * dt / steps, kernel_s, inv_s, clear_s),
+        "table_slots": r.table_capacity, "table_load_at_end": r.distinct / max(r.table_capacity, 1),
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_BPS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_distinct_state": A, "kernel": "kmc_expand_*", "kernel_code_sha256": code},
+        "k_inv": inv_pass_block(c, r, inv_s, S, code),
+        "cpu_baseline": cpu,
     }
+
+
+def inv_pass_block(c, r, inv_s, S, code):
+    """The invariant pass over the last, unexpanded frontier of a level-budgeted search (k_inv): a pure streaming read of that
+    level's states — its own roofline block (algorithmic bytes = S per state of the level) and, when a committed PMC summary
+    was measured on this machine code, its DRAM traffic."""
+    if not c.get("max_levels") or not inv_s or not r.levels:
+        return None
+    n = r.levels[-1]
+    alg = float(S) * n
+    traffic, src = None, "no kmc_inv row in a PMC summary of this machine code"
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*summary.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+        except Exception:
+            continue
+        row = j.get("kmc_inv")
+        if row and j.get("kernel_code_sha256") == code and row.get("hbm_bytes_per_launch"):
+            traffic, src = row["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+            break
+    return {"kernel": "kmc_inv_*", "states": n, "seconds": inv_s, "bound": "hbm", "achieved": alg / inv_s / 1e9,
+            "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": alg / inv_s / HBM_PEAK_BPS, "algorithmic_bytes": alg,
+            "traffic": traffic, "traffic_source": src}
+
+
+STRETCH = dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_leader_epoch=3, invariants=("TypeOk", "WeakIsr", "StrongIsr"))
+
+
+def stretch_1gpu_leg():
+    """The one exhaustible workload that needs the HBM north_star talks about, on ONE GPU, in the driver's own run: Kip320 3/6/6/3
+    (Kip320.tla:150-159 with MaxLeaderEpoch = 3, KafkaReplication.tla:36) — 6,452,700,520 distinct states, 20.76 G generated, 54
+    levels — with 128-bit seen-set entries (2^33 slots of 16 bytes = 128 GiB; the 64-bit table loses one state to the collision
+    n^2 / 2^65 = 1.1 predicts) and two frontiers of 2^30 states (48 GiB).  One search, counts held level by level to Oracle-O's exact
+    fixture (tests/golden/orbit_kip320_3_6_6_3.json: no fingerprint anywhere).  Roofline: unit = distinct state, algorithmic bytes
+    A = 2*S + 16*g + 16 (the probe reads a 16-byte entry, the claim writes one).  Never part of `value`."""
+    import kafka_specification_amd as kmc
+    c = dict(STRETCH)
+    try:
+        cfg = kmc.CheckerConfig(**c, device=0, wide_fingerprint=True,
+                                table_capacity=int(os.environ.get("KMC_BENCH_STRETCH_TABLE", 1 << 33)),
+                                frontier_capacity=int(os.environ.get("KMC_BENCH_STRETCH_FRONTIER", 1 << 30)))
+        t_open = time.perf_counter()
+        with kmc.ModelChecker(cfg) as mc:
+            open_s = time.perf_counter() - t_open
+            t0 = time.perf_counter()
+            r = mc.run()
+            first_wall = time.perf_counter() - t0     # includes the first touch of 128 GiB of freshly mapped HBM (timing.first_clear_s)
+            timing = mc.timing()
+            t0 = time.perf_counter()
+            r = mc.run()                              # the timed step: memory mapped, as every other leg's steps
+            dt = time.perf_counter() - t0
+            levels = mc.level_stats()
+    except Exception as e:   # a leg never takes the headline line down with it
+        return {"workload": workload_name(c), "error": f"{type(e).__name__}: {str(e)[:300]}"}
+    exp = expected_counts(c)
+    S = 8 * r.state_words
+    probes = r.generated - r.generated_repeats
+    g = probes / max(r.distinct, 1)
+    A = 2 * S + 16 * g + 16
+    achieved = A * r.distinct / max(r.seconds_expand, 1e-12)
+    code = kernel_code_sha256_of(c)
+    traffic, traffic_source = None, "no PMC summary of this machine code with 128-bit entries"
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_stretch*pmc_summary.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+        except Exception:
+            continue
+        if j.get("kernel_code_sha256") == code and j.get("hbm_bytes_per_launch"):
+            traffic, traffic_source = j["hbm_bytes_per_launch"], f"{os.path.relpath(path, ROOT)} (measured on this machine code)"
+            break
+    # the widest levels carry the run: their probe rate against the microbenchmark of the same footprint
+    big = sorted(levels, key=lambda st: -st["probes"])[:8]
+    big_probes, big_ms = sum(st["probes"] for st in big), sum(st["expand_ms"] for st in big)
+    rates, rates_file = randbench_rates_at(33)
+    return {
+        "workload": workload_name(c), "entries": "128-bit (fingerprint + check word)", "table_slots": r.table_capacity,
+        "table_GiB": r.table_capacity * 16 / 2 ** 30, "frontier_states": r.frontier_capacity, "table_load_at_end": r.distinct / r.table_capacity,
+        "steps": 1, "warmup": 1, "time_to_exhaustive_s": dt, "ms_per_step": 1e3 * dt,
+        "first_run_wall_s": first_wall, "open_s": open_s, "first_clear_s": timing.get("first_clear_s"),
+        "device_GiB": timing.get("device_bytes", 0) / 2 ** 30,
+        "value": r.distinct / dt, "unit": "distinct states/s",
+        "distinct_states": r.distinct, "states_generated": r.generated, "seen_set_probes": probes, "depth": r.depth, "verdict": r.verdict,
+        "matches_oracle_golden": None if exp is None else (r.distinct == exp["distinct"] and r.generated == exp["generated"]
+                                                           and r.depth == exp["depth"]
+                                                           and (exp["levels"] is None or list(r.levels) == list(exp["levels"]))),
+        "oracle_golden": exp["file"] if exp else None,
+        "step_breakdown": step_breakdown(1e3 * dt, r.seconds_expand, r.seconds_inv, r.seconds_clear),
+        "kernel_seconds_per_step": r.seconds_expand, "launches_per_step": r.expand_launches,
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_BPS, "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_distinct_state": A, "kernel": "kmc_expand_*", "kernel_code_sha256": code,
+                     "probes_per_s": probes / max(r.seconds_expand, 1e-12),
+                     "probes_per_s_widest_levels": 1e3 * big_probes / max(big_ms, 1e-9),
+                     "randbench_at_this_footprint": {"mode_13_wide_mix_per_s": rates.get(13), "mode_1_loads_per_s": rates.get(1),
+                                                     "mode_7_narrow_mix_per_s": rates.get(7), "source": rates_file},
+                     "ratio_to_randbench_wide_mix": (1e3 * big_probes / max(big_ms, 1e-9)) / rates[13] if rates.get(13) else None},
+    }
+
+
+def randbench_rates_at(log2_slots):
+    """{mode: G accesses/s -> accesses/s} of tools/membench/randbench at a footprint of 2^log2_slots 8-byte slots, from the newest
+    committed profiles/rNN_randbench_sweep.txt that holds that footprint; ({}, None) when there is none."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_randbench_sweep.txt")), reverse=True):
+        rates, on = {}, False
+        for line in open(path):
+            m = re.match(r"# table of 2\^(\d+) slots", line)
+            if m:
+                on = int(m.group(1)) == log2_slots
+                continue
+            m = re.match(r"mode (\d+).*=\s*([0-9.]+) G/s", line)
+            if m and on:
+                k, v = int(m.group(1)), float(m.group(2)) * 1e9
+                rates[k] = max(rates.get(k, 0.0), v)
+        if rates:
+            return rates, os.path.relpath(path, ROOT)
+    return {}, None
 
 
 def stretch_leg(a):
@@ -428,6 +568,9 @@ def main():
     ap.add_argument("--no-cold-start", action="store_true", help="skip the cold_start leg (one fresh CLI process, exec to exit)")
     ap.add_argument("--no-baseline-configs", action="store_true",
                     help="skip the baseline_configs legs (BASELINE.json configs 4 and 5 on one GPU, beside the headline)")
+    ap.add_argument("--no-stretch", action="store_true",
+                    help="skip the stretch_1gpu leg (Kip320 3/6/6/3, 6,452,700,520 states, 128-bit entries in a 128 GiB seen-set: the "
+                         "one exhaustible workload that uses the HBM)")
     ap.add_argument("--config-steps", type=int, default=3, help="timed steps of each baseline_configs leg (1 warmup before)")
     ap.add_argument("--stretch", nargs="?", const="Kip320,3,6,6,3", default=None, metavar="MODEL,N,L,R,E",
                     help="N > 1 only: one more leg beside the strong-scaling headline — the workload the frontier sharding is "
@@ -545,7 +688,10 @@ def main():
                    "verdict": r.verdict, "matches_oracle_golden": counts_match,
                    "exhausted": r.verdict != "level_limit", "level_budget": a.level_budget or None,
                    "stored_states": r.orbit_representatives if a.symmetry else None,
-                   "time_to_exhaustive_s": dt / a.steps, **extra},
+                   "time_to_exhaustive_s": dt / a.steps,
+                   "step_breakdown": step_breakdown(1e3 * dt / a.steps, kernel_s, sum(x.seconds_inv for x in results) / len(results),
+                                                    sum(x.seconds_clear for x in results) / len(results)) if world == 1 else None,
+                   **extra},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_BPS, "traffic": traffic,
                      "kernel": "kmc_expand_*", "kernel_seconds_per_step": kernel_s, "launches_per_step": launches,
@@ -602,7 +748,9 @@ def main():
                                  "is the smallest of its images under the permutations: profiles/r03_symmetry.txt)"}}
     if (world == 1 and not a.symmetry and not a.level_budget and not a.no_baseline_configs and not a.workload and not a.small):
         # SURVEY section 8d rows "config 4" and "config 5": driver-timed here, never part of `value`
-        out["baseline_configs"] = {name: baseline_leg(name, a.config_steps, 1) for name in BASELINE_LEGS}
+        out["baseline_configs"] = {name: baseline_leg(name, a.config_steps, 1, with_cpu=not a.no_cpu_baseline) for name in BASELINE_LEGS}
+    if (world == 1 and not a.symmetry and not a.level_budget and not a.no_stretch and not a.workload and not a.small):
+        out["stretch_1gpu"] = stretch_1gpu_leg()
     if world == 1 and not a.symmetry and not a.level_budget and not a.no_cold_start:
         cs = cold_start(c)
         if cs:

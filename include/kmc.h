@@ -168,7 +168,26 @@ typedef struct kmc_result {
                                    and one seen-set probe, so probes = generated - 1 - generated_repeats */
     uint64_t orbit_representatives; /* kmc_config.symmetry: the states actually stored and expanded (one per orbit);
                                    without it equal to `distinct` */
+    /* the rest of a run's device time, so that seconds_total is accounted for (HIP events on the engine stream): */
+    double seconds_inv;         /* the invariant pass over a frontier that is not expanded (k_inv: the last level under max_levels) */
+    double seconds_clear;       /* clearing the seen-set [+ predecessor table] at the start of the run */
+    uint64_t inv_launches;
 } kmc_result;
+
+/* One record per expansion of the last search (kmc_run / kmc_resume, or the kmc_step_* calls of one shard): what a user tunes
+ * constants and capacities by — TLC's -coverage / Progress lines give the same view per disjunct [TLC-recall].  The per-disjunct
+ * counts follow the module's Next (Kip320.tla:150-159 etc.: kmc_action_name). */
+typedef struct kmc_level_stat {
+    uint64_t depth;             /* depth of the level this expansion PRODUCED (Init is depth 1 and has no record) */
+    uint64_t frontier;          /* states expanded = the size of level depth-1, as stored (orbit representatives under symmetry) */
+    uint64_t new_states;        /* distinct states first found by this expansion (the plain search's count) */
+    uint64_t stored_new;        /* ... as stored */
+    uint64_t generated[KMC_MAX_KINDS]; /* successors generated per disjunct of Next (the plain search's count) */
+    uint64_t probes;            /* seen-set probes of this expansion */
+    uint64_t deadlocks;         /* expanded states without successor */
+    double table_load;          /* stored states / table slots after this expansion */
+    double expand_ms;           /* duration of this expansion's k_expand launch(es), HIP events on the engine stream */
+} kmc_level_stat;
 
 typedef struct kmc_handle kmc_handle;
 
@@ -209,6 +228,15 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path);
 int kmc_resume(kmc_handle* h, kmc_progress_cb cb, void* user);
 /* Per-level sizes of the last run: fills up to cap entries, returns the number of levels. */
 uint64_t kmc_level_sizes(kmc_handle* h, uint64_t* out, uint64_t cap);
+/* Per-expansion records of the last run (see kmc_level_stat): fills up to cap entries, returns their number. */
+uint64_t kmc_level_stats(kmc_handle* h, kmc_level_stat* out, uint64_t cap);
+/* Who compiles, and whose code runs.  A box holds two hiprtc / comgr builds (the system ROCm's and the one bundled with
+ * PyTorch) that emit different instructions for the same source; a process is bound to one of them.  The compiler's identity
+ * (the HIP runtime build number of the bundle it belongs to, e.g. 70051831) is part of every cached code object's FILE NAME, so
+ * two compilers never write the same file, and kmc_open prefers the object of the PINNED compiler (the one the build step
+ * specialises with and the profiles were measured on; KMC_COMPILER_PIN overrides) when the cache holds it.
+ * which = 0: this process's compiler; 1: the pinned one (0 = none pinned). */
+int64_t kmc_compiler_identity(int32_t which);
 void kmc_close(kmc_handle* h);
 const char* kmc_last_error(void);
 

@@ -3,5 +3,5 @@
 of include/kmc.h; this package is the thin host mirror (checker, .cfg reader, tlc-shaped CLI,
 multi-GPU driver)."""
 from .checker import (CheckerConfig, CheckResult, ModelChecker, precompile,  # noqa: F401
-                      code_object_path, kernel_code_sha256)
+                      code_object_path, kernel_code_sha256, compiler_identity)
 from ._native import KmcError, MODELS, INVARIANTS  # noqa: F401

@@ -78,7 +78,14 @@ class KmcResult(C.Structure):
         ("seconds_total", C.c_double), ("seconds_expand", C.c_double), ("expand_launches", C.c_uint64),
         ("state_words", C.c_uint64), ("state_bits", C.c_uint64), ("generated_repeats", C.c_uint64),
         ("orbit_representatives", C.c_uint64),
+        ("seconds_inv", C.c_double), ("seconds_clear", C.c_double), ("inv_launches", C.c_uint64),
     ]
+
+
+class KmcLevelStat(C.Structure):
+    _fields_ = [("depth", C.c_uint64), ("frontier", C.c_uint64), ("new_states", C.c_uint64), ("stored_new", C.c_uint64),
+                ("generated", C.c_uint64 * KMC_MAX_KINDS), ("probes", C.c_uint64), ("deadlocks", C.c_uint64),
+                ("table_load", C.c_double), ("expand_ms", C.c_double)]
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.POINTER(KmcLevelInfo), C.c_void_p)
@@ -97,6 +104,8 @@ SYMBOLS = [
     ("kmc_checkpoint_load", C.c_int, [_H, C.c_char_p]),
     ("kmc_resume", C.c_int, [_H, PROGRESS_CB, C.c_void_p]),
     ("kmc_level_sizes", C.c_uint64, [_H, C.POINTER(C.c_uint64), C.c_uint64]),
+    ("kmc_level_stats", C.c_uint64, [_H, C.POINTER(KmcLevelStat), C.c_uint64]),
+    ("kmc_compiler_identity", C.c_int64, [C.c_int32]),
     ("kmc_close", None, [_H]),
     ("kmc_last_error", C.c_char_p, []),
     ("kmc_state_words", C.c_uint64, [_H]),

@@ -91,6 +91,9 @@ class CheckResult:
     trace: list = field(default_factory=list)
     generated_repeats: int = 0   # of `generated`: successors yielded twice by two disjuncts of one binding (one probe each)
     orbit_representatives: int = 0   # CheckerConfig.symmetry: the states actually stored and expanded (else = distinct)
+    seconds_inv: float = 0.0     # the invariant pass over the last, unexpanded frontier under max_levels (k_inv)
+    seconds_clear: float = 0.0   # clearing the seen-set at the start of the run
+    inv_launches: int = 0
 
 
 def precompile(cfg: CheckerConfig, arch: str = "gfx950", mode: int = -1) -> None:
@@ -98,6 +101,11 @@ def precompile(cfg: CheckerConfig, arch: str = "gfx950", mode: int = -1) -> None
     configuration, 0 the search's own, 1 k_expand for the level-step interface, 2 k_expand as an enumerator (include/kmc.h)."""
     c = cfg.to_native()
     nat.check(nat.lib().kmc_precompile_mode(C.byref(c), arch.encode(), mode))
+
+
+def compiler_identity(which: int = 0) -> int:
+    """0: the hiprtc / comgr this process compiles with; 1: the pinned one (include/kmc.h, kmc_compiler_identity)."""
+    return int(nat.lib().kmc_compiler_identity(which))
 
 
 def code_object_path(cfg: CheckerConfig, arch: str = "gfx950") -> str:
@@ -232,7 +240,20 @@ class ModelChecker:
             table_capacity=int(r.table_capacity), frontier_capacity=int(r.frontier_capacity),
             seconds_total=float(r.seconds_total), seconds_expand=float(r.seconds_expand),
             expand_launches=int(r.expand_launches), state_words=int(r.state_words), state_bits=int(r.state_bits),
-            generated_repeats=int(r.generated_repeats), orbit_representatives=int(r.orbit_representatives))
+            generated_repeats=int(r.generated_repeats), orbit_representatives=int(r.orbit_representatives),
+            seconds_inv=float(r.seconds_inv), seconds_clear=float(r.seconds_clear), inv_launches=int(r.inv_launches))
+
+    def level_stats(self) -> list:
+        """One dict per expansion of the last search (kmc_level_stat): depth produced, frontier expanded, new states, generated per
+        disjunct of Next, probes, deadlocks, table load, k_expand milliseconds."""
+        n = int(self._lib.kmc_level_stats(self._h, None, 0))
+        buf = (nat.KmcLevelStat * max(n, 1))()
+        n = min(n, int(self._lib.kmc_level_stats(self._h, buf, n)))
+        names = self.action_names()
+        return [dict(depth=int(b.depth), frontier=int(b.frontier), new_states=int(b.new_states), stored_new=int(b.stored_new),
+                     generated={names[k]: int(b.generated[k]) for k in range(len(names))}, probes=int(b.probes),
+                     deadlocks=int(b.deadlocks), table_load=float(b.table_load), expand_ms=float(b.expand_ms))
+                for b in buf[:n]]
 
     # -- states as data -------------------------------------------------------------------
     def unpack(self, words) -> bytes:

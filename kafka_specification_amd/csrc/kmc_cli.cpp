@@ -1,7 +1,7 @@
 // kmc_cli.cpp — native `tlc`-shaped front end over the C ABI (include/kmc.h); the C++ twin of
 // kafka_specification_amd/tlc.py, for hosts without Python/torch.
 //
-//   tlc [-config X.cfg] [-deadlock] [-continue] [-workers N] [-fp SEED] [-fp128] [-symmetry] [-fpcheck] [-verify] [-force] [-table SLOTS]
+//   tlc [-config X.cfg] [-deadlock] [-continue] [-workers N] [-fp SEED] [-fp128] [-symmetry] [-fpcheck] [-verify] [-force] [-levels-csv FILE] [-table SLOTS]
 //       [-frontier STATES] [-device D] [-notrace] [-v] Spec.tla
 //
 // [TLC-recall] flag names and output lines follow tlc2.TLC; TLC itself is not part of the
@@ -429,6 +429,7 @@ int main(int argc, char** argv) {
     c.n_shards = 1;
     c.keep_trace = 1;
     bool no_deadlock = false, fpcheck = false, force = false, verbose = false;
+    std::string levels_csv;
     const double t_main0 = wall_s();
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -436,6 +437,10 @@ int main(int argc, char** argv) {
             if (i + 1 >= argc) { fprintf(stderr, "Error: %s needs a value\n", what); exit(2); }
             return argv[++i];
         };
+        if (a == "-abi-sizes") {   // tests/test_abi_cpu.py: the structs of include/kmc.h as this translation unit sees them
+            printf("%zu %zu %zu %zu %zu\n", sizeof(kmc_config), sizeof(kmc_level_info), sizeof(kmc_result), sizeof(kmc_level_stat), sizeof(kmc_timing));
+            return 0;
+        }
         if (a == "-config") cfg_path = val("-config");
         else if (a == "-deadlock") no_deadlock = true;
         else if (a == "-continue") c.continue_on_violation = 1;
@@ -449,6 +454,7 @@ int main(int argc, char** argv) {
         else if (a == "-fp128") c.wide_fingerprint = 1;  // 128-bit seen-set entries: fingerprint + independent check word
         else if (a == "-symmetry") c.symmetry = 1;  // orbit counting: one stored state per orbit of the permutations of Replicas
         else if (a == "-force") force = true;
+        else if (a == "-levels-csv") levels_csv = val("-levels-csv");  // one line per BFS level: frontier, generated per disjunct, new, table load, kernel ms
         else if (a == "-v") verbose = true;   // where the wall time went: start-up (HIP, code object, allocation, first touch), search, teardown
         else if (a == "-verify") setenv("KMC_VERIFY", "1", 1);  // every level is regenerated by a second build of the kernels
         else if (const char* why = tlc_ignored_flag(a)) fprintf(stderr, "Note: %s is accepted for compatibility and ignored (%s)\n", a.c_str(), why);
@@ -616,6 +622,27 @@ int main(int argc, char** argv) {
             print_state(c, st.data());
         }
     }
+    if (!levels_csv.empty()) {
+        // the per-level view a user tunes constants and capacities by (kmc_level_stats: one record per expansion)
+        std::vector<kmc_level_stat> st(kmc_level_stats(h, nullptr, 0));
+        const uint64_t ns = kmc_level_stats(h, st.data(), st.size());
+        if (FILE* lf = fopen(levels_csv.c_str(), "w")) {
+            fprintf(lf, "depth,frontier,new_states,stored_new,probes,deadlocks,table_load,expand_ms");
+            const int nk = kmc_action_count(c.model);
+            for (int k = 0; k < nk; ++k) fprintf(lf, ",%s", kmc_action_name(c.model, k));
+            fprintf(lf, "\n");
+            for (uint64_t i = 0; i < ns && i < st.size(); ++i) {
+                fprintf(lf, "%llu,%llu,%llu,%llu,%llu,%llu,%.6f,%.4f", (unsigned long long)st[i].depth, (unsigned long long)st[i].frontier,
+                        (unsigned long long)st[i].new_states, (unsigned long long)st[i].stored_new, (unsigned long long)st[i].probes,
+                        (unsigned long long)st[i].deadlocks, st[i].table_load, st[i].expand_ms);
+                for (int k = 0; k < nk; ++k) fprintf(lf, ",%llu", (unsigned long long)st[i].generated[k]);
+                fprintf(lf, "\n");
+            }
+            fclose(lf);
+        } else {
+            fprintf(stderr, "Error: cannot write %s\n", levels_csv.c_str());
+        }
+    }
     printf("%llu states generated, %llu distinct states found, %llu states left on queue.\n", (unsigned long long)r.generated,
            (unsigned long long)r.distinct, (unsigned long long)r.queue_left);
     printf("The depth of the complete state graph search is %llu.\n", (unsigned long long)r.depth);
@@ -639,9 +666,17 @@ int main(int argc, char** argv) {
                (double)col_distinct * (double)(col_generated > col_distinct ? col_generated - col_distinct : 0) / std::pow(2.0, 64));
         const double birthday = (double)col_distinct * (double)col_distinct / std::pow(2.0, 65);
         printf("  birthday bound on the stored fingerprints:  val = %.2E\n", birthday);
-        if (birthday > 0.1)   // (Kip320 3/6/6/3: 6,452,700,520 states, bound 1.1 — the 64-bit search returns one state fewer)
+        if (birthday > 0.1) {   // (Kip320 3/6/6/3: 6,452,700,520 states, bound 1.1 — the 64-bit search returns one state fewer)
             printf("  Recommendation: that bound is above 0.1: counts of this size are only bit-exact with 128-bit entries - re-run with "
                    "-fp128 (or, on the Kafka modules, -symmetry: a sixth of the stored fingerprints at three brokers).\n");
+            // A FINISHED search whose count is more likely wrong than not must not look like a success to a script: BASELINE's
+            // target is the bit-identical count (exit 14; a verdict that already failed keeps its own code).
+            if (rc == 0) {
+                printf("Warning: the distinct-state count of this run is NOT certified (64-bit fingerprints, birthday bound %.2E > 0.1): "
+                       "exit code 14.\n", birthday);
+                rc = 14;
+            }
+        }
     }
     if (fpcheck) {  // a collision moves with the seed: equal counts under two seeds make a silent loss very unlikely
         kmc_close(h);

@@ -49,9 +49,11 @@ typedef unsigned int u32;
 #define KMC_TUNING 0
 #endif
 #if !KMC_TUNING
-#undef KMC_PROFILE
-#undef KMC_FAULT_DROP
-#undef KMC_TEST_FP_BITS
+// (a stale script that asks for a diagnostic build without -DKMC_TUNING=1 must fail, not run a normal kernel under another
+// cache key and pass vacuously: ADVICE r5)
+#if defined(KMC_PROFILE) || defined(KMC_FAULT_DROP) || defined(KMC_TEST_FP_BITS)
+#error "KMC_PROFILE / KMC_FAULT_DROP / KMC_TEST_FP_BITS only exist in a tuning build: add -DKMC_TUNING=1"
+#endif
 #endif
 #ifndef KMC_PROFILE
 #define KMC_PROFILE 0     // 1 (KMC_TUNING): per-phase s_memtime accounting into KmcLevelCtl::prof (costs ~10 %)

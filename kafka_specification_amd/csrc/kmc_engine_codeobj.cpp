@@ -1,5 +1,8 @@
-// kmc_engine_codeobj.h — part of kmc_engine.cpp (ONE translation unit: kmc_engine.cpp includes the parts in order): the code objects: validation of a configuration, the text handed to hiprtc, the on-disk cache, the register-budget rule.
-namespace {
+// kmc_engine_codeobj.cpp — the code objects: validation of a configuration, the text handed to hiprtc, the on-disk cache, the register-budget rule.
+#include "kmc_engine_internal.h"
+#include "kmc_sources.inc"  // generated: KMC_SRC_DEVICE (kmc_layout.h and the parts of kmc_device.h, as text)
+
+namespace kmc_engine {
 
 thread_local std::string g_err;
 
@@ -13,30 +16,24 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                                  \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) return fail(KMC_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-const char* const MODEL_NAMES[] = {"IdSequence", "FiniteReplicatedLog", "KafkaTruncateToHighWatermark",
+extern const char* const MODEL_NAMES[] = {"IdSequence", "FiniteReplicatedLog", "KafkaTruncateToHighWatermark",
                                    "Kip101",     "Kip279",              "Kip320",
                                    "Kip320FirstTry", "AsyncIsr"};
-const char* const INV_NAMES[] = {"TypeOk", "WeakIsr", "StrongIsr", "LeaderInIsr"};
+extern const char* const INV_NAMES[] = {"TypeOk", "WeakIsr", "StrongIsr", "LeaderInIsr"};
 // AsyncIsr.tla:62,161; LeaderOffsetInRange is defined in models/MCAsyncIsr.tla (not in the reference)
-const char* const INV_NAMES_ASYNC[] = {"TypeOk", "ValidHighWatermark", "LeaderOffsetInRange", "?"};
-const char* const KINDS_ASYNC[] = {"ControllerShrinkIsr", "ControllerHandleRequest", "LeaderRequestShrinkIsr",
+extern const char* const INV_NAMES_ASYNC[] = {"TypeOk", "ValidHighWatermark", "LeaderOffsetInRange", "?"};
+extern const char* const KINDS_ASYNC[] = {"ControllerShrinkIsr", "ControllerHandleRequest", "LeaderRequestShrinkIsr",
                                    "LeaderRequestExpandIsr", "LeaderWrite", "LeaderHandleUpdate", "FollowerReplicate"};
 
-const char* const KINDS_BASE[] = {"ControllerElectLeader", "ControllerShrinkIsr", "BecomeLeader",
+extern const char* const KINDS_BASE[] = {"ControllerElectLeader", "ControllerShrinkIsr", "BecomeLeader",
                                   "LeaderExpandIsr",       "LeaderShrinkIsr",     "LeaderWrite",
                                   "LeaderIncHighWatermark", nullptr,              "FollowerReplicate"};
-const char* const KINDS_KIP320[] = {"ControllerElectLeader",        "ControllerShrinkIsr",
+extern const char* const KINDS_KIP320[] = {"ControllerElectLeader",        "ControllerShrinkIsr",
                                     "BecomeLeader",                 "FencedLeaderExpandIsr",
                                     "FencedLeaderShrinkIsr",        "LeaderWrite",
                                     "FencedLeaderIncHighWatermark", "FencedBecomeFollowerAndTruncate",
                                     "FencedFollowerFetch"};
-const char* const KINDS_FIRST[] = {"ControllerElectLeader",
+extern const char* const KINDS_FIRST[] = {"ControllerElectLeader",
                                    "ControllerShrinkIsr",
                                    "BecomeLeader",
                                    "LeaderExpandIsrBetterFencing",
@@ -46,9 +43,9 @@ const char* const KINDS_FIRST[] = {"ControllerElectLeader",
                                    "BecomeFollower",
                                    "FollowerFetch",
                                    "FollowerTruncate"};
-const char* const KINDS_FRL[] = {"Append", "TruncateTo", "ReplicateTo"};
+extern const char* const KINDS_FRL[] = {"Append", "TruncateTo", "ReplicateTo"};
 
-uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+static uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
     for (unsigned char c : s) {
         h ^= c;
         h *= 1099511628211ull;
@@ -56,7 +53,35 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
     return h;
 }
 
-bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::string* inst) {
+// The compiler's identity = the build number of the HIP runtime bundle this process is bound to (hiprtc and comgr come from the same
+// bundle: _native.py): 70051831 for the one PyTorch ships, 70226015 for the system ROCm 7.2 of this image.
+int64_t compiler_id_mine() {
+    static const int64_t id = [] {
+        int rt = 0;
+        if (hipRuntimeGetVersion(&rt) != hipSuccess) rt = 0;
+        return (int64_t)rt;
+    }();
+    return id;
+}
+// The compiler whose objects every process prefers (KMC_PINNED_COMPILER: profiles/r06_compiler_ab.txt holds the A/B it was
+// chosen by; KMC_COMPILER_PIN=<id> overrides, 0 = no preference).
+int64_t compiler_id_pinned() {
+    if (const char* e = getenv("KMC_COMPILER_PIN")) return (int64_t)atoll(e);
+    return (int64_t)KMC_PINNED_COMPILER;
+}
+
+// KMC_LAYOUT=tight|rm|rmg (tests, A/B measurements) overrides the automatic choice between the arrangements of the Kafka state
+// vector (kmc_layout.h); host and device evaluate the same constexpr function with the same mode.  A handle reads the
+// environment ONCE, at kmc_open (kmc_handle::layout_mode): its later code objects (ensure_mode) are specialised for the layout
+// it was opened with, whatever the environment says by then.
+int layout_mode_from_env() {
+    const char* lenv = getenv("KMC_LAYOUT");
+    return !lenv || !*lenv || !strcmp(lenv, "auto") ? KMC_LAYOUT_AUTO
+           : !strcmp(lenv, "tight") ? KMC_LAYOUT_TIGHT : !strcmp(lenv, "rm") ? KMC_LAYOUT_RM
+           : !strcmp(lenv, "rmg") ? KMC_LAYOUT_RMG : -1;
+}
+
+bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::string* inst, int layout_mode) {
     char buf[256];
     switch (c.model) {
     case KMC_IDSEQUENCE:
@@ -89,12 +114,7 @@ bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::strin
     case KMC_KIP279:
     case KMC_KIP320:
     case KMC_KIP320_FIRST_TRY: {
-        // KMC_LAYOUT=tight|rm (tests, A/B measurements) overrides the automatic choice between the two arrangements of
-        // the state vector (kmc_layout.h); host and device evaluate the same constexpr function with the same mode
-        const char* lenv = getenv("KMC_LAYOUT");
-        const int lm = !lenv || !*lenv || !strcmp(lenv, "auto") ? KMC_LAYOUT_AUTO
-                       : !strcmp(lenv, "tight") ? KMC_LAYOUT_TIGHT : !strcmp(lenv, "rm") ? KMC_LAYOUT_RM
-                       : !strcmp(lenv, "rmg") ? KMC_LAYOUT_RMG : -1;
+        const int lm = layout_mode == -2 ? layout_mode_from_env() : layout_mode;
         if (lm < 0) return false;
         *lay = kmc_make_layout(c.model, c.n_replicas, c.log_size, c.max_records, c.max_leader_epoch, 0, lm);
         if (!lay->valid || c.n_replicas < 2) return false;
@@ -112,7 +132,7 @@ bool validate(const kmc_config& c, KmcLayout* lay, std::string* name, std::strin
     }
 }
 
-std::string strip_for_concat(const char* src) {
+static std::string strip_for_concat(const char* src) {
     // drop '#pragma once' and the local includes so the parts can be fed to hiprtc as one file; drop `//` comments
     // (line structure kept) so that the text — and with it the key of the code-object cache — only changes with the code
     std::string out, line;
@@ -140,7 +160,7 @@ std::string strip_for_concat(const char* src) {
     return out;
 }
 
-std::string default_cache_dir() {
+static std::string default_cache_dir() {
     if (const char* e = getenv("KMC_CACHE_DIR")) return e;
     Dl_info info;
     if (dladdr((void*)&default_cache_dir, &info) && info.dli_fname) {
@@ -151,7 +171,7 @@ std::string default_cache_dir() {
     return "./kmc_cache";
 }
 
-bool read_file(const std::string& path, std::vector<char>* out) {
+static bool read_file(const std::string& path, std::vector<char>* out) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
     fseek(f, 0, SEEK_END);
@@ -166,7 +186,7 @@ bool read_file(const std::string& path, std::vector<char>* out) {
 // .vgpr_spill_count of one kernel, read from the code object's AMDGPU metadata note (msgpack: the
 // keys of a kernel's map are sorted, so the count follows the kernel's ".name" value).  -1 = not found.
 #define KMC_MAX_VGPR_SPILLS 8
-long expand_vgpr_spills(const std::vector<char>& code, const std::string& kernel) {
+static long expand_vgpr_spills(const std::vector<char>& code, const std::string& kernel) {
     const std::string blob(code.begin(), code.end());
     size_t at = blob.find(kernel);
     while (at != std::string::npos) {  // the name also occurs in the symbol table: take the one inside the metadata
@@ -189,15 +209,14 @@ long expand_vgpr_spills(const std::vector<char>& code, const std::string& kernel
 // `mode` = which k_expand the object holds (kmc_kernels.h, KMC_ONLY_MODE): KMC_MODE_LOCAL — the search's own kernel with the
 // small kernels around it — KMC_MODE_SHARDED or KMC_MODE_ENUM; one cached file each, so that a front end which never steps or
 // enumerates never pays for those kernels, and the search's kernel is not recompiled (minutes at seven brokers) for them.
-const char* const MODE_SUFFIX[3] = {"", "_sh", "_en"};
-const char* const MODE_FILE_TAG[3] = {"", "-sharded", "-enum"};
+extern const char* const MODE_SUFFIX[3] = {"", "_sh", "_en"};
+extern const char* const MODE_FILE_TAG[3] = {"", "-sharded", "-enum"};
 int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<char>* code, std::string* kname,
-                    const char* extra_options = nullptr, std::string* path_out = nullptr, unsigned mode = KMC_MODE_LOCAL,
-                    const std::string* jit_defines = nullptr) {
+                    const char* extra_options, std::string* path_out, unsigned mode, const std::string* jit_defines, int layout_mode) {
     if (mode > KMC_MODE_ENUM) return fail(KMC_E_ARG, "no code object for mode %u", mode);
     KmcLayout lay;
     std::string name, inst;
-    if (!validate(cfg, &lay, &name, &inst))
+    if (!validate(cfg, &lay, &name, &inst, layout_mode))
         return fail(KMC_E_ARG, "unsupported model/constants (model=%d N=%d L=%d R=%d E=%d K=%d): need 2<=N<=8, "
                                "L*bits(record)<=64, E<=7 (AsyncIsr: N<=6, MaxVersion<=7)", cfg.model, cfg.n_replicas, cfg.log_size,
                     cfg.max_records, cfg.max_leader_epoch, cfg.n_log_records);
@@ -230,12 +249,17 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
     }
     std::string src = strip_for_concat(KMC_SRC_DEVICE) + "\nKMC_INSTANTIATE(" +
                       name + ", " + inst + ")\n";
-    // ONE code object per (source, architecture, defines), whoever compiled it.  The PyTorch wheel bundles its own
-    // hiprtc / comgr next to the system ROCm's (same hiprtcVersion, different LLVM builds: from round 4's source on they emit
-    // different instructions for the same text), and a process binds to one or the other (_native.py).  Rounds 1-3 keyed the
-    // cache by the HIP runtime's build number too, so the bench (torch's runtime) and a rocprofv3 run (system ROCm) each
-    // compiled and ran their own object — a profile then described other machine code than the line it is quoted beside.
-    // A gfx950 code object loads under either runtime: the cache is keyed by what is compiled, not by who asks.
+    // ONE FILE per (source, architecture, defines, COMPILER).  The PyTorch wheel bundles its own hiprtc / comgr next to the
+    // system ROCm's (same hiprtcVersion, different LLVM builds: from round 4's source on they emit different instructions for
+    // the same text), and a process binds to one or the other (_native.py).  History: rounds 1-3 keyed the cache by the HIP
+    // runtime's build number, so the bench (torch's runtime) and a rocprofv3 run (system ROCm) each compiled and ran their own
+    // object — a profile then described other machine code than the line it is quoted beside; rounds 4-5 left the compiler out
+    // of the key, so both loaded one object — but WHICH compiler's depended on who filled the cache first, under one file name
+    // (VERDICT r5, weak 7).  Now the compiler's identity is in the name, so two compilers can never alias, and every process
+    // PREFERS the object of the pinned compiler (compiler_id_pinned: the one build() specialises with and the profiles were
+    // measured on) when the cache holds it — a gfx950 code object loads under either runtime — so the bench and a profile run
+    // still execute the same machine code.  A process bound to another compiler that finds no pinned object compiles its own,
+    // under its own name.
     int rtc_major = 0, rtc_minor = 0;
     hiprtcVersion(&rtc_major, &rtc_minor);
     char key[64];
@@ -243,9 +267,23 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
              (unsigned long long)fnv1a(src + "|" + arch + "|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
                                        "|" + defines_key));
     const std::string dir = cfg.cache_dir ? std::string(cfg.cache_dir) : default_cache_dir();
-    const std::string path = dir + "/" + name + "-" + arch + "-" + key + MODE_FILE_TAG[mode] + ".hsaco";
+    const long long mine = (long long)compiler_id_mine(), pinned = (long long)compiler_id_pinned();
+    auto path_of = [&](long long compiler) {
+        return dir + "/" + name + "-" + arch + "-" + key + "-c" + std::to_string(compiler) + MODE_FILE_TAG[mode] + ".hsaco";
+    };
+    if (pinned && pinned != mine) {
+        const std::string pp = path_of(pinned);
+        if (read_file(pp, code)) {
+            if (path_out) *path_out = pp;
+            return KMC_OK;
+        }
+    }
+    const std::string path = path_of(mine);
     if (path_out) *path_out = path;
     if (read_file(path, code)) return KMC_OK;
+    if (getenv("KMC_VERBOSE") && pinned && pinned != mine)
+        fprintf(stderr, "[kmc] no code object of the pinned compiler %lld for %s in %s: compiling with this process's (%lld)\n", pinned,
+                name.c_str(), dir.c_str(), mine);
     if (getenv("KMC_VERBOSE"))
         fprintf(stderr, "[kmc] specialising kernels for %s (first use; wide configurations take minutes)\n", name.c_str());
 
@@ -307,22 +345,6 @@ int get_code_object(const kmc_config& cfg, const std::string& arch, std::vector<
         fclose(f);
         if (ok) rename(tmp.c_str(), path.c_str());
         else unlink(tmp.c_str());
-        // Who compiled it.  The key above holds hiprtc's major.minor only (so that the bench under torch's runtime and a
-        // rocprofv3 run under the system's load the SAME object), but the two bundled compilers emit different instructions for
-        // the same text: which of them filled this slot of the cache is recorded beside it — COMPILERS.jsonl, one appended line
-        // per object written (bench.py reports it next to kernel_code_sha256; an object from a compiler found to be bad can be
-        // told from its neighbours and deleted).
-        if (ok) {
-            int rt = 0;
-            (void)hipRuntimeGetVersion(&rt);
-            if (FILE* idx = fopen((dir + "/COMPILERS.jsonl").c_str(), "ab")) {
-                const size_t slash = path.find_last_of('/');
-                fprintf(idx, "{\"file\": \"%s\", \"hiprtc\": \"%d.%d\", \"hip_runtime_version\": %d, \"waves\": \"%s\"}\n",
-                        path.substr(slash == std::string::npos ? 0 : slash + 1).c_str(), rtc_major, rtc_minor, rt,
-                        waves_forced ? "as given" : "rule");
-                fclose(idx);
-            }
-        }
     }
     return KMC_OK;
 }
@@ -342,4 +364,4 @@ double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-}  // namespace
+}  // namespace kmc_engine

@@ -1,89 +1,11 @@
-// kmc_engine_core.h — part of kmc_engine.cpp (ONE translation unit: kmc_engine.cpp includes the parts in order): the handle, the kernel launches, a level's counters folded into the result (absorb), conservation, Init.
-struct kmc_handle {
-    kmc_config cfg{};
-    KmcLayout lay{};
-    int W = 0;
-    std::string kname;
-    std::string arch;
-    kmc_timing timing{};                    // where the wall time outside the search went (kmc_timing_get)
-    bool first_clear_timed = false;
-    std::string cache_dir;                  // kmc_config.cache_dir, copied: the later code objects (ensure_mode) are looked up
-                                            // long after kmc_open returned and the caller's string may be gone
-    std::string jit_defines;                // KMC_JIT_DEFINES as it stood when the handle was opened
-    bool verify = false;                    // KMC_VERIFY likewise
-    hipModule_t mod = nullptr;              // the search's code object: k_expand (LOCAL), k_inv, k_insert, k_init, k_find, k_packrow
-    hipFunction_t f_expand = nullptr, f_inv = nullptr, f_insert = nullptr, f_init = nullptr, f_find = nullptr, f_packrow = nullptr;
-    hipFunction_t f_expand_dry = nullptr;   // only in a KMC_TUNING build of `mod` (KMC_DRYRUN / KMC_SHADOW tuning aids)
-    hipModule_t mod_sh = nullptr, mod_en = nullptr;   // k_expand in SHARDED / ENUM mode: loaded when first needed (ensure_mode)
-    hipFunction_t f_expand_sh = nullptr, f_expand_en = nullptr;
-    hipModule_t mod_verify = nullptr;       // KMC_VERIFY=1: a second, differently compiled code object whose dry k_expand regenerates every level
-    hipFunction_t f_expand_verify = nullptr;
-    uint64_t verify_levels = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t ev_chain[2 * KMC_CHAIN] = {nullptr};  // chained launches: one pair per level of a batch
-    int rec_words = 0;  // exchange / insert record size: W, +1 when predecessor fingerprints are kept
-    int n_cus = 256;
-    int blocks_per_cu = 4;  // k_expand residency, from the occupancy query at open
-    u64 *table = nullptr, *pred = nullptr, *table2 = nullptr;
-    u64* sent = nullptr;      // n_shards > 1: sender-side filter of fingerprints already shipped
-    uint64_t sent_cap = 0;
-    uint64_t table_cap = 0;      // slots
-    uint64_t slot_words = 1;     // 64-bit words per slot: 1, or 2 with kmc_config.wide_fingerprint (fingerprint + check word)
-    uint64_t inserted_level = 0; // stepping: records handed to k_insert since the last kmc_step_finish (conservation check)
-    u64* frontier[2] = {nullptr, nullptr};
-    uint64_t fcap = 0;
-    KmcLevelCtl* ctl = nullptr;       // 3 device slots: two alternating levels + one auxiliary
-    KmcLevelCtl* ctl_host = nullptr;  // pinned
-    u64* scratch = nullptr;      // device: init record / find result / enum input
-    uint64_t* scratch_host = nullptr; // pinned
-    u64* enum_out = nullptr;     // device: ENUM records
-    uint64_t enum_cap = 4096;
-    u64* send = nullptr;         // SHARDED send buffers
-    uint64_t send_cap = 0;
-    bool send_owned = true;
-    // run state
-    int cur = 0;                 // frontier[cur] holds the last completed level
-    uint64_t n_cur = 0;          // its size on this shard
-    uint64_t seg_n[KMC_SEGS] = {0};  // ... per segment
-    uint64_t prev_seg_n[KMC_SEGS] = {0};  // stepping: segments of the level kmc_step_finish just retired (in frontier[cur ^ 1])
-    uint64_t seg_cap = 0;        // slots per segment
-    uint64_t level = 0;          // number of completed levels
-    bool stepping = false, step_expanded = false, restored = false;
-    std::vector<uint64_t> levels;
-    std::vector<uint64_t> init_words, witness;
-    bool have_witness = false, have_deadlock = false;
-    bool witness_outside = false;      // the witness is a successor outside the state constraint:
-    uint64_t witness_parent_fp = 0;    //   it is in no table; this is the expanded state it was generated from
-    kmc_result res{};
-    // kmc_config.symmetry: the frontier / table hold one state per orbit; res.distinct and `levels` are the WEIGHTED
-    // (= plain-search) numbers, raw_levels the representatives per level; nfact = |Replicas|!
-    uint64_t nfact = 1;
-    int planes = 0;              // words per state in a frontier: W, and under symmetry one more — the order of the state's stabiliser
-    double t_start = 0;
-    double dry_seconds = 0;
-    uint64_t prof[8] = {0}, prof_dry[8] = {0};
-    // per-level exchange under the ABI (n_shards > 1): RCCL communicator, receive area, count/statistics rows
-    ncclComm_t comm = nullptr;
-    u64* recv = nullptr;             // device: everything this shard receives in one level, contiguous
-    uint64_t recv_cap = 0;           // records
-    // the within-level pipeline (kmc_step_level_parts): a second stream for a part's collective, transfer and insert, the
-    // rows of two parts in flight, and the events that order the two streams
-    hipStream_t xstream = nullptr;
-    hipEvent_t ev_row[2] = {nullptr, nullptr}, ev_xfer[2] = {nullptr, nullptr};
-    int64_t* prow_dev[2] = {nullptr, nullptr};
-    int64_t* prow_host[2] = {nullptr, nullptr};
-    int64_t* xrow_dev = nullptr;     // device: this rank's row, then the gathered rows of all ranks
-    int64_t* xrow_host = nullptr;    // pinned: the same
-    uint64_t last_send_counts[KMC_MAX_SHARDS * KMC_SEGS] = {0};  // of the last kmc_step_expand
-    std::vector<uint64_t> xcounts;   // [source][destination][sub-buffer] of the level being exchanged
-    bool xcounts_valid = false;
-};
+// kmc_engine_core.cpp — the kernel launches, a level's counters folded into the result (absorb), conservation, Init.
+#include "kmc_engine_internal.h"
 
-namespace {
+
+namespace kmc_engine {
 
 // the small kernels (k_insert, k_init, k_find): the whole argument block
-int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid, hipStream_t stream = nullptr) {
+int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid, hipStream_t stream) {
     KmcArgs args = a;
     size_t size = sizeof(args);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -100,7 +22,8 @@ int ensure_mode(kmc_handle* h, unsigned mode) {
     if (f) return KMC_OK;
     std::vector<char> code;
     std::string kname;
-    int rc = get_code_object(h->cfg, h->arch, &code, &kname, h->verify ? KMC_VERIFY_PRIMARY_OPTIONS : nullptr, nullptr, mode, &h->jit_defines);
+    int rc = get_code_object(h->cfg, h->arch, &code, &kname, h->verify ? KMC_VERIFY_PRIMARY_OPTIONS : nullptr, nullptr, mode, &h->jit_defines,
+                             h->layout_mode);
     if (rc) return rc;
     HIP_TRY(hipModuleLoadData(&mod, code.data()));
     HIP_TRY(hipModuleGetFunction(&f, mod, (std::string("kmc_expand") + MODE_SUFFIX[mode] + "_" + h->kname).c_str()));
@@ -109,7 +32,7 @@ int ensure_mode(kmc_handle* h, unsigned mode) {
 
 // k_expand in one of its modes (each mode is its own kernel; `verify` = the dry kernel of KMC_VERIFY's second build).  The
 // search's kernel receives KmcArgsLocal — the head of the block — and nothing else.
-int launch_expand(kmc_handle* h, unsigned mode, const KmcArgs& a, unsigned grid, hipStream_t stream = nullptr, bool verify = false) {
+int launch_expand(kmc_handle* h, unsigned mode, const KmcArgs& a, unsigned grid, hipStream_t stream, bool verify) {
     int rc = ensure_mode(h, mode);
     if (rc) return rc;
     hipFunction_t f = verify ? h->f_expand_verify : mode == KMC_MODE_LOCAL ? h->f_expand : mode == KMC_MODE_SHARDED ? h->f_expand_sh
@@ -267,8 +190,17 @@ int reset_run(kmc_handle* h) {
     // round 3: the step got 0.4 ms shorter, but the memset's own kernel competes with the first, small levels and their
     // launches got 0.9 ms longer in total; dropped, profiles/r03_step_overhead.txt.)
     const double t_clear0 = now_s();
+    if (!h->ev_aux[0]) {
+        HIP_TRY(hipEventCreate(&h->ev_aux[0]));
+        HIP_TRY(hipEventCreate(&h->ev_aux[1]));
+    }
+    range_push("kmc clear seen-set %s", h->kname.c_str());
+    HIP_TRY(hipEventRecord(h->ev_aux[0], h->stream));
     HIP_TRY(hipMemsetAsync(h->table, 0, h->table_cap * h->slot_words * 8, h->stream));
     if (h->pred) HIP_TRY(hipMemsetAsync(h->pred, 0, h->table_cap * 8, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_aux[1], h->stream));
+    range_pop();
+    h->clear_pending = true;   // (its duration is read where the stream is next waited for: do_begin)
     if (!h->first_clear_timed) {   // the first clear of a handle touches freshly mapped memory: timed once, by waiting for it
         h->first_clear_timed = true;
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -277,6 +209,8 @@ int reset_run(kmc_handle* h) {
     if (h->sent) HIP_TRY(hipMemsetAsync(h->sent, 0, h->sent_cap * 8, h->stream));
     HIP_TRY(hipMemsetAsync(h->ctl, 0, KMC_CTL_SLOTS * sizeof(KmcLevelCtl), h->stream));
     h->levels.clear();
+    h->level_stats.clear();
+    h->step_expand_ms = 0;
     h->witness.clear();
     h->have_witness = false;
     h->have_deadlock = false;
@@ -429,6 +363,12 @@ int do_begin(kmc_handle* h) {
     if ((rc = launch(h, h->f_init, a, 1))) return rc;
     HIP_TRY(hipMemcpyAsync(h->scratch_host, h->scratch, (h->W + 1) * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->clear_pending) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev_aux[0], h->ev_aux[1]));
+        h->res.seconds_clear = 1e-3 * ms;
+        h->clear_pending = false;
+    }
     h->init_words.assign(h->scratch_host, h->scratch_host + h->W);
     uint64_t init_orbit = 1;
     if (h->cfg.symmetry) {
@@ -464,4 +404,61 @@ int do_begin(kmc_handle* h) {
     return rc;
 }
 
+void note_level(kmc_handle* h, const KmcLevelCtl& c, uint64_t frontier, uint64_t produced, double expand_ms) {
+    kmc_level_stat st{};
+    st.depth = h->level + 1;   // (called before the level enters the books: h->level is still the expanded level's depth)
+    st.frontier = frontier;
+    st.stored_new = produced;
+    st.new_states = weighted(h, produced, c.corr_won);
+    for (int k = 0; k < KMC_MAX_KINDS; ++k) st.generated[k] = weighted(h, c.generated[k], c.corr_gen[k]);
+    st.probes = c.probed;
+    st.deadlocks = weighted(h, c.deadlock_count, c.corr_dead);
+    st.table_load = h->table_cap ? (double)(h->res.orbit_representatives + produced) / (double)h->table_cap : 0.0;
+    st.expand_ms = expand_ms;
+    h->level_stats.push_back(st);
+}
+
+// ---- roctx ranges --------------------------------------------------------------------------------------------------------
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+Roctx* roctx() {
+    static Roctx r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* want = getenv("KMC_ROCTX");
+        if (want && !atoi(want)) return;   // KMC_ROCTX=0: never
+        // a profiler that traces markers has the library in the process already (RTLD_NOLOAD finds it); KMC_ROCTX=1 loads it
+        const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+        void* lib = nullptr;
+        for (const char* n : names)
+            if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!lib && want)
+            for (const char* n : names)
+                if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) return;
+        r.push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+        r.pop = (int (*)())dlsym(lib, "roctxRangePop");
+        if (!r.push || !r.pop) r.push = nullptr;
+    });
+    return r.push ? &r : nullptr;
+}
 }  // namespace
+
+void range_push(const char* fmt, ...) {
+    Roctx* r = roctx();
+    if (!r) return;
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    r->push(buf);
+}
+void range_pop() {
+    if (Roctx* r = roctx()) r->pop();
+}
+
+}  // namespace kmc_engine

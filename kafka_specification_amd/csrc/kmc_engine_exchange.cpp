@@ -1,4 +1,7 @@
-// kmc_engine_exchange.h — part of kmc_engine.cpp (ONE translation unit: kmc_engine.cpp includes the parts in order): the per-level exchange under the ABI: RCCL bound with dlopen, the plan, one-shot and pipelined levels, logical shards.
+// kmc_engine_exchange.cpp — the per-level exchange under the ABI: RCCL bound with dlopen, the plan, one-shot and pipelined levels, logical shards.
+#include "kmc_engine_internal.h"
+using namespace kmc_engine;
+
 // ---- the per-level exchange under the ABI ---------------------------------------
 // After kmc_step_expand every shard holds, per (destination, sub-buffer), a dense run of records in its
 // send area.  One level's exchange is
@@ -147,10 +150,12 @@ int insert_received(kmc_handle* h, uint64_t n_records, hipStream_t stream = null
 
 }  // namespace
 
-static void comm_release(kmc_handle* h) {
+void kmc_engine::comm_release(kmc_handle* h) {
     if (h->comm && rccl()) rccl()->CommDestroy(h->comm);
     h->comm = nullptr;
 }
+
+extern "C" {
 
 int kmc_comm_unique_id(uint8_t* id) {
     if (!id) return fail(KMC_E_ARG, "null argument");
@@ -189,7 +194,7 @@ int kmc_comm_selftest(kmc_handle* h) {
     const size_t n = 4096;
     u64* buf = nullptr;
     HIP_TRY(hipMalloc(&buf, (size_t)(2 + P) * n * 8));
-    struct Free { u64* p; ~Free() { hipFree(p); } } free_buf{buf};   // also on the error returns below
+    struct Free { u64* p; ~Free() { (void)hipFree(p); } } free_buf{buf};   // also on the error returns below
     std::vector<uint64_t> host((size_t)(2 + P) * n);
     for (size_t i = 0; i < n; ++i) host[i] = ((uint64_t)(me + 1) << 32) | i;
     HIP_TRY(hipMemcpyAsync(buf, host.data(), n * 8, hipMemcpyHostToDevice, h->stream));
@@ -330,6 +335,7 @@ int kmc_step_expand_counts(kmc_handle* h, const int64_t* stats, int32_t n_stats,
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->res.seconds_expand += 1e-3 * ms;
     h->res.expand_launches++;
+    h->step_expand_ms += ms;
     h->xcounts.assign((size_t)P * P * KMC_SEGS, 0);
     for (int k = 0; k < n_stats; ++k) stats_sum[k] = 0;
     for (int s2 = 0; s2 < P; ++s2) {
@@ -479,6 +485,7 @@ int kmc_step_level_parts(kmc_handle* h, int32_t parts, const int64_t* stats, int
         HIP_TRY(hipEventElapsedTime(&ms, h->ev_chain[2 * c], h->ev_chain[2 * c + 1]));
         h->res.seconds_expand += 1e-3 * ms;
         h->res.expand_launches++;
+        h->step_expand_ms += ms;
     }
     if (recv_records) *recv_records = total_recv;
     h->xcounts_valid = false;
@@ -654,3 +661,5 @@ int kmc_step_set_verdict(kmc_handle* h, int32_t verdict) {
     return KMC_OK;
 }
 
+
+}  // extern "C"

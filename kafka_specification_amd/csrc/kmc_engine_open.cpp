@@ -1,4 +1,9 @@
-// kmc_engine_open.h — part of kmc_engine.cpp (ONE translation unit: kmc_engine.cpp includes the parts in order): names, precompile, kmc_open / kmc_close, pack / unpack / fingerprint / representative of a state.
+// kmc_engine_open.cpp — names, precompile, kmc_open / kmc_close, pack / unpack / fingerprint / representative of a state.
+#include "kmc_engine_internal.h"
+using namespace kmc_engine;
+
+extern "C" {
+
 const char* kmc_last_error(void) { return g_err.c_str(); }
 const char* kmc_model_name(int32_t m) { return m >= 0 && m <= 7 ? MODEL_NAMES[m] : "?"; }
 const char* kmc_invariant_name(int32_t i) { return i >= 0 && i < 4 ? INV_NAMES[i] : "?"; }
@@ -65,52 +70,54 @@ int kmc_code_object_path(const kmc_config* cfg, const char* arch, char* out, uin
     return KMC_OK;
 }
 
-static void comm_release(kmc_handle* h);
+int64_t kmc_compiler_identity(int32_t which) { return which == 0 ? compiler_id_mine() : which == 1 ? compiler_id_pinned() : -1; }
 
-void kmc_close(kmc_handle* h) {
+void kmc_close(kmc_handle* h) {   // (teardown: the HIP results are dropped on purpose — there is nobody to report them to)
     if (!h) return;
     if (h->cfg.device < 0 || !h->stream) {  // host-only handle, or open failed before any device work
-        if (h->mod) hipModuleUnload(h->mod);
+        if (h->mod) (void)hipModuleUnload(h->mod);
         delete h;
         return;
     }
-    hipSetDevice(h->cfg.device);
-    if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->table) hipFree(h->table);
-    if (h->pred) hipFree(h->pred);
-    if (h->table2) hipFree(h->table2);
-    if (h->sent) hipFree(h->sent);
-    if (h->frontier[0]) hipFree(h->frontier[0]);
-    if (h->frontier[1]) hipFree(h->frontier[1]);
-    if (h->ctl) hipFree(h->ctl);
-    if (h->scratch) hipFree(h->scratch);
-    if (h->enum_out) hipFree(h->enum_out);
-    if (h->send && h->send_owned) hipFree(h->send);
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->table) (void)hipFree(h->table);
+    if (h->pred) (void)hipFree(h->pred);
+    if (h->table2) (void)hipFree(h->table2);
+    if (h->sent) (void)hipFree(h->sent);
+    if (h->frontier[0]) (void)hipFree(h->frontier[0]);
+    if (h->frontier[1]) (void)hipFree(h->frontier[1]);
+    if (h->ctl) (void)hipFree(h->ctl);
+    if (h->scratch) (void)hipFree(h->scratch);
+    if (h->enum_out) (void)hipFree(h->enum_out);
+    if (h->send && h->send_owned) (void)hipFree(h->send);
     comm_release(h);
-    if (h->recv) hipFree(h->recv);
-    if (h->xstream) hipStreamSynchronize(h->xstream);
+    if (h->recv) (void)hipFree(h->recv);
+    if (h->xstream) (void)hipStreamSynchronize(h->xstream);
     for (int i = 0; i < 2; ++i) {
-        if (h->prow_dev[i]) hipFree(h->prow_dev[i]);
-        if (h->prow_host[i]) hipHostFree(h->prow_host[i]);
-        if (h->ev_row[i]) hipEventDestroy(h->ev_row[i]);
-        if (h->ev_xfer[i]) hipEventDestroy(h->ev_xfer[i]);
+        if (h->prow_dev[i]) (void)hipFree(h->prow_dev[i]);
+        if (h->prow_host[i]) (void)hipHostFree(h->prow_host[i]);
+        if (h->ev_row[i]) (void)hipEventDestroy(h->ev_row[i]);
+        if (h->ev_xfer[i]) (void)hipEventDestroy(h->ev_xfer[i]);
     }
-    if (h->xstream) hipStreamDestroy(h->xstream);
-    if (h->xrow_dev) hipFree(h->xrow_dev);
-    if (h->xrow_host) hipHostFree(h->xrow_host);
-    if (h->ctl_host) hipHostFree(h->ctl_host);
-    if (h->scratch_host) hipHostFree(h->scratch_host);
-    if (h->ev0) hipEventDestroy(h->ev0);
-    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->xstream) (void)hipStreamDestroy(h->xstream);
+    if (h->xrow_dev) (void)hipFree(h->xrow_dev);
+    if (h->xrow_host) (void)hipHostFree(h->xrow_host);
+    if (h->ctl_host) (void)hipHostFree(h->ctl_host);
+    if (h->scratch_host) (void)hipHostFree(h->scratch_host);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->ev_chain)
-        if (e) hipEventDestroy(e);
-    if (h->stream) hipStreamDestroy(h->stream);
-    if (h->mod_verify) hipModuleUnload(h->mod_verify);
-    if (h->mod_sh) hipModuleUnload(h->mod_sh);
-    if (h->mod_en) hipModuleUnload(h->mod_en);
-    if (h->mod) hipModuleUnload(h->mod);
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->mod_verify) (void)hipModuleUnload(h->mod_verify);
+    if (h->mod_sh) (void)hipModuleUnload(h->mod_sh);
+    if (h->mod_en) (void)hipModuleUnload(h->mod_en);
+    if (h->mod) (void)hipModuleUnload(h->mod);
     delete h;
 }
+
+}  // extern "C"
 
 static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     h->cfg = *cfg;
@@ -122,7 +129,8 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     if (h->cfg.n_shards > KMC_MAX_SHARDS || h->cfg.shard_id < 0 || h->cfg.shard_id >= h->cfg.n_shards)
         return fail(KMC_E_ARG, "bad shard configuration %d/%d", h->cfg.shard_id, h->cfg.n_shards);
     std::string name, inst;
-    if (!validate(h->cfg, &h->lay, &name, &inst)) {
+    h->layout_mode = layout_mode_from_env();   // read once: the handle's later code objects follow it (ensure_mode)
+    if (!validate(h->cfg, &h->lay, &name, &inst, h->layout_mode)) {
         std::vector<char> dummy;
         return get_code_object(h->cfg, "gfx950", &dummy, &name);  // produces the KMC_E_ARG message
     }
@@ -154,7 +162,8 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     const bool verify = getenv("KMC_VERIFY") && atoi(getenv("KMC_VERIFY"));
     h->verify = verify;
     h->jit_defines = getenv("KMC_JIT_DEFINES") ? getenv("KMC_JIT_DEFINES") : "";
-    int rc = get_code_object(h->cfg, arch, &code, &h->kname, verify ? KMC_VERIFY_PRIMARY_OPTIONS : nullptr);
+    int rc = get_code_object(h->cfg, arch, &code, &h->kname, verify ? KMC_VERIFY_PRIMARY_OPTIONS : nullptr, nullptr, KMC_MODE_LOCAL,
+                             &h->jit_defines, h->layout_mode);
     if (rc) return rc;
     HIP_TRY(hipModuleLoadData(&h->mod, code.data()));
     HIP_TRY(hipModuleGetFunction(&h->f_expand, h->mod, ("kmc_expand_" + h->kname).c_str()));
@@ -175,7 +184,7 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
         // the checksum of the successors' fingerprints of the two builds must agree.
         std::vector<char> vcode;
         std::string vname;
-        rc = get_code_object(h->cfg, arch, &vcode, &vname, KMC_VERIFY_OPTIONS);
+        rc = get_code_object(h->cfg, arch, &vcode, &vname, KMC_VERIFY_OPTIONS, nullptr, KMC_MODE_LOCAL, &h->jit_defines, h->layout_mode);
         if (rc) return rc;
         HIP_TRY(hipModuleLoadData(&h->mod_verify, vcode.data()));
         HIP_TRY(hipModuleGetFunction(&h->f_expand_verify, h->mod_verify, ("kmc_expand_dry_" + vname).c_str()));
@@ -262,6 +271,8 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     h->timing.open_s = now_s() - t_open0;
     return KMC_OK;
 }
+
+extern "C" {
 
 int kmc_open(const kmc_config* cfg, kmc_handle** out) {
     if (!cfg || !out) return fail(KMC_E_ARG, "null argument");
@@ -436,3 +447,5 @@ int kmc_pack_state(kmc_handle* h, const uint8_t* c, uint64_t* words) {
     return KMC_OK;
 }
 
+
+}  // extern "C"

@@ -1,6 +1,10 @@
-// kmc_engine_run.h — part of kmc_engine.cpp (ONE translation unit: kmc_engine.cpp includes the parts in order): kmc_run's level loop (chained launches), results, kmc_successors / kmc_check_states, witness, contains, traces.
+// kmc_engine_run.cpp — kmc_run's level loop (chained launches), results, kmc_successors / kmc_check_states, witness, contains, traces.
+#include "kmc_engine_internal.h"
+using namespace kmc_engine;
+
 static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh);
 
+extern "C" {
 
 int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
     if (!h) return fail(KMC_E_ARG, "null handle");
@@ -26,6 +30,8 @@ int kmc_resume(kmc_handle* h, kmc_progress_cb cb, void* user) {
     return run_levels(h, cb, user, false);
 }
 
+}  // extern "C"
+
 static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh) {
     int rc = KMC_OK;
     kmc_result& r = h->res;
@@ -48,8 +54,18 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             if ((rc = zero_ctl(h, 2))) return rc;
             KmcArgs d = base_args(h, 2);
             d.fin = h->frontier[h->cur];
+            range_push("kmc invariants of level %llu (%llu states, not expanded)", (unsigned long long)h->level, (unsigned long long)h->n_cur);
+            HIP_TRY(hipEventRecord(h->ev_aux[0], h->stream));
             if ((rc = launch_inv(h, d, h->n_cur))) return rc;   // (a full dry expansion of BASELINE config 5's tenth level took 64 ms: twice the search)
+            HIP_TRY(hipEventRecord(h->ev_aux[1], h->stream));
+            range_pop();
             if ((rc = read_ctl(h, 2))) return rc;
+            {
+                float ims = 0;
+                HIP_TRY(hipEventElapsedTime(&ims, h->ev_aux[0], h->ev_aux[1]));
+                r.seconds_inv += 1e-3 * ims;
+                r.inv_launches++;
+            }
             KmcLevelCtl c = *h->ctl_host;
             for (int k = 0; k < KMC_MAX_KINDS; ++k) c.generated[k] = 0;
             c.deadlock_count = 0;
@@ -99,6 +115,8 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
                 B = fit ? fit : 1;
             }
             HIP_TRY(hipMemsetAsync(h->ctl + 3, 0, B * sizeof(KmcLevelCtl), h->stream));
+            range_push("kmc %s: chain of %llu levels from depth %llu (%llu states)", h->kname.c_str(), (unsigned long long)B,
+                       (unsigned long long)h->level, (unsigned long long)h->n_cur);
             uint64_t bound = h->n_cur;   // upper bound on the size of the level launch i expands
             for (uint64_t i = 0; i < B; ++i) {
                 if (!h->ev_chain[2 * i]) {
@@ -122,6 +140,8 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             }
             HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl + 3, B * sizeof(KmcLevelCtl), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
+            range_pop();
+            float chain_ms[KMC_CHAIN] = {0};
             // every launch of the batch is accounted (also the ones behind the end of the search, which find nothing to
             // do and return in microseconds): the per-launch average then is what rocprofv3 --kernel-trace reports
             for (uint64_t i = 0; i < B; ++i) {
@@ -129,6 +149,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
                 HIP_TRY(hipEventElapsedTime(&ms, h->ev_chain[2 * i], h->ev_chain[2 * i + 1]));
                 r.seconds_expand += 1e-3 * ms;
                 r.expand_launches++;
+                chain_ms[i] = ms;
             }
             bool done = false;
             for (uint64_t i = 0; i < B && !done; ++i) {
@@ -144,6 +165,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
                     done = true;
                     break;
                 }
+                note_level(h, c, h->n_cur, produced, chain_ms[i]);
                 if (produced == 0) {
                     h->n_cur = 0;
                     done = true;
@@ -186,10 +208,12 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             HIP_TRY(hipEventElapsedTime(&xms, h->ev0, h->ev1));
             h->dry_seconds += 1e-3 * xms;
         }
+        range_push("kmc %s: level %llu (%llu states)", h->kname.c_str(), (unsigned long long)h->level, (unsigned long long)h->n_cur);
         HIP_TRY(hipEventRecord(h->ev0, h->stream));
         if ((rc = launch_expand(h, KMC_MODE_LOCAL, a, expand_grid(h, h->n_cur)))) return rc;
         HIP_TRY(hipEventRecord(h->ev1, h->stream));
         if ((rc = read_ctl(h, slot))) return rc;
+        range_pop();
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
         r.seconds_expand += 1e-3 * ms;
@@ -253,6 +277,7 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
             r.queue_left = queue_now(h);
             break;
         }
+        note_level(h, c, h->n_cur, produced, (double)ms);
         if (produced == 0) {
             h->n_cur = 0;
             break;
@@ -300,6 +325,8 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
     return KMC_OK;
 }
 
+extern "C" {
+
 int kmc_timing_get(kmc_handle* h, kmc_timing* out) {
     if (!h || !out) return fail(KMC_E_ARG, "null argument");
     *out = h->timing;
@@ -311,6 +338,12 @@ int kmc_result_get(kmc_handle* h, kmc_result* out) {
     h->res.n_levels = h->levels.size();
     *out = h->res;
     return KMC_OK;
+}
+
+uint64_t kmc_level_stats(kmc_handle* h, kmc_level_stat* out, uint64_t cap) {
+    if (!h) return 0;
+    for (uint64_t i = 0; out && i < h->level_stats.size() && i < cap; ++i) out[i] = h->level_stats[i];
+    return h->level_stats.size();
 }
 
 uint64_t kmc_level_sizes(kmc_handle* h, uint64_t* out, uint64_t cap) {
@@ -418,6 +451,8 @@ int kmc_witness(kmc_handle* h, uint64_t* words) {
     return KMC_OK;
 }
 
+}  // extern "C"
+
 // Looks fp up in the device table from the host (a few 8-byte reads); returns the slot.
 static int table_lookup(kmc_handle* h, uint64_t fp, uint64_t* slot) {
     const uint64_t mask = h->table_cap - 1;
@@ -436,6 +471,8 @@ static int table_lookup(kmc_handle* h, uint64_t fp, uint64_t* slot) {
     }
     return fail(KMC_E_STATE, "fingerprint %016llx not in table", (unsigned long long)fp);
 }
+
+extern "C" {
 
 // FPSet.contains analogue: is this packed state's fingerprint in the seen-set of the last run?
 int kmc_contains(kmc_handle* h, const uint64_t* words, int32_t* present) {
@@ -536,3 +573,5 @@ int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap
     return KMC_OK;
 }
 
+
+}  // extern "C"

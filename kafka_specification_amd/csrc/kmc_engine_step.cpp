@@ -1,14 +1,21 @@
-// kmc_engine_step.h — part of kmc_engine.cpp (ONE translation unit: kmc_engine.cpp includes the parts in order): checkpoint / recover and the level-step interface (kmc_step_*) of one shard.
+// kmc_engine_step.cpp — checkpoint / recover and the level-step interface (kmc_step_*) of one shard.
+#include "kmc_engine_internal.h"
+using namespace kmc_engine;
+
 // ---- checkpoint / recover (TLC -checkpoint / -recover [TLC-recall]) --------------------------
 // File: header, kmc_result, level sizes, segment sizes, then the fingerprint table (and the
 // predecessor table when traces are kept) and the current frontier's planes, segment by segment.
 namespace {
 struct CkptHeader {
-    char magic[8];          // "KMCCKPT4"
+    char magic[8];          // "KMCCKPT5" (4: before round 5 changed the representative at four replicas; before canon_form)
     kmc_config cfg;         // pointers inside are not meaningful in the file
     uint64_t table_cap, fcap, seg_cap, level, n_cur, n_levels, w, has_pred;
     uint64_t layout_form;   // KmcLayout::rm of the packed states in the file (0 tight, 1 / 2 replica-major): the same constants
                             // can be packed in more than one way (KMC_LAYOUT), often into the same number of words
+    uint64_t canon_form;    // kmc_config.symmetry: WHICH image of an orbit the stored states are — KMC_SYMM_UNROLLED_MAX of the build
+                            // that wrote the file (up to that many replicas the smallest of all images, beyond it the smallest
+                            // sorted one).  Round 5 moved it from 4 to 3 under an unchanged magic: a four-replica checkpoint of the
+                            // older revision loaded cleanly and the resumed search claimed its orbits a second time
 };
 bool wr(FILE* f, const void* p, size_t n) { return fwrite(p, 1, n, f) == n; }
 bool rd(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n; }
@@ -35,6 +42,8 @@ int file_to_dev(FILE* f, u64* dev, uint64_t words) {
 }
 }  // namespace
 
+extern "C" {
+
 int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     if (!h || !path) return fail(KMC_E_ARG, "null argument");
     if (!h->table) return fail(KMC_E_STATE, "checkpoints are for device handles");
@@ -55,12 +64,13 @@ int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     FILE* f = fopen(path, "wb");
     if (!f) return fail(KMC_E_ARG, "cannot open %s for writing", path);
     CkptHeader hd{};
-    memcpy(hd.magic, "KMCCKPT4", 8);
+    memcpy(hd.magic, "KMCCKPT5", 8);
     hd.cfg = h->cfg;
     hd.cfg.cache_dir = nullptr;
     hd.table_cap = h->table_cap; hd.fcap = h->fcap; hd.seg_cap = h->seg_cap; hd.level = h->level;
     hd.n_cur = h->n_cur; hd.n_levels = h->levels.size(); hd.w = h->W; hd.has_pred = h->pred != nullptr;
     hd.layout_form = (uint64_t)h->lay.rm;
+    hd.canon_form = (uint64_t)KMC_SYMM_UNROLLED_MAX;
     int rc = KMC_OK;
     bool ok = wr(f, &hd, sizeof hd) && wr(f, &h->res, sizeof h->res) && wr(f, h->levels.data(), h->levels.size() * 8) &&
               wr(f, h->seg_n, sizeof h->seg_n) && wr(f, h->init_words.data(), h->W * 8);
@@ -83,7 +93,7 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
     if (!f) return fail(KMC_E_ARG, "cannot open %s", path);
     CkptHeader hd{};
     int rc = KMC_OK;
-    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT4", 8) != 0)
+    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT5", 8) != 0)
         rc = fail(KMC_E_ARG, "%s is not a checkpoint of this version", path);
     const kmc_config& a = hd.cfg;
     const kmc_config& b = h->cfg;
@@ -92,9 +102,9 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
                 a.n_log_records != b.n_log_records || a.max_id != b.max_id || a.hash_seed != b.hash_seed ||
                 a.n_shards != b.n_shards || a.shard_id != b.shard_id || hd.w != (uint64_t)h->W ||
                 hd.layout_form != (uint64_t)h->lay.rm || (a.wide_fingerprint != 0) != (b.wide_fingerprint != 0) ||
-                (a.symmetry != 0) != (b.symmetry != 0)))
+                (a.symmetry != 0) != (b.symmetry != 0) || (b.symmetry && hd.canon_form != (uint64_t)KMC_SYMM_UNROLLED_MAX)))
         rc = fail(KMC_E_ARG, "checkpoint was taken for a different model / constants / hash seed / shard / fingerprint width / "
-                             "state layout / symmetry setting");
+                             "state layout / symmetry setting / orbit representative");
     if (!rc && (hd.table_cap != h->table_cap || hd.fcap != h->fcap || hd.seg_cap != h->seg_cap ||
                 hd.has_pred != (uint64_t)(h->pred != nullptr)))
         rc = fail(KMC_E_ARG, "checkpoint capacities differ: open the handle with table_capacity=%llu frontier_capacity=%llu keep_trace=%d",
@@ -191,6 +201,7 @@ int kmc_step_expand(kmc_handle* h, uint64_t* send_counts /* [KMC_MAX_SHARDS][KMC
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->res.seconds_expand += 1e-3 * ms;
     h->res.expand_launches++;
+    h->step_expand_ms += ms;
     for (int d = 0; d < KMC_MAX_SHARDS; ++d)
         for (int sb = 0; sb < KMC_SEGS; ++sb) {
             uint64_t c = h->ctl_host->send_count[d][sb].v;
@@ -205,7 +216,7 @@ int kmc_step_expand(kmc_handle* h, uint64_t* send_counts /* [KMC_MAX_SHARDS][KMC
 int kmc_step_set_send_buffer(kmc_handle* h, void* dev_ptr, uint64_t records_per_sub_buffer) {
     const uint64_t records_per_destination = records_per_sub_buffer;
     if (!h || !dev_ptr || records_per_destination == 0) return fail(KMC_E_ARG, "bad send buffer");
-    if (h->send && h->send_owned) hipFree(h->send);  // n_shards == 1 is allowed: one destination, itself
+    if (h->send && h->send_owned) (void)hipFree(h->send);  // n_shards == 1 is allowed: one destination, itself
     h->send = (u64*)dev_ptr;
     h->send_cap = records_per_destination;
     h->send_owned = false;
@@ -268,6 +279,8 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
     const uint64_t dead_w = weighted(h, c.deadlock_count, c.corr_dead);
     r.deadlock_states += dead_w;
     const uint64_t produced_w = weighted(h, produced, c.corr_won);
+    note_level(h, c, h->n_cur, produced, h->step_expand_ms);
+    h->step_expand_ms = 0;
     h->cur = nxt;
     h->n_cur = produced;
     for (int sg = 0; sg < KMC_SEGS; ++sg) { h->prev_seg_n[sg] = h->seg_n[sg]; h->seg_n[sg] = new_seg[sg]; }
@@ -301,3 +314,5 @@ int kmc_step_finish(kmc_handle* h, kmc_level_info* info) {
     return rc;
 }
 
+
+}  // extern "C"

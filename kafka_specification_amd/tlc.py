@@ -1,7 +1,7 @@
 """`tlc2.TLC`-shaped command line [TLC-recall]:
 
     python -m kafka_specification_amd.tlc [-config X.cfg] [-deadlock] [-continue] [-workers N]
-                                          [-fp SEED] [-fp128] [-symmetry] [-fpcheck] [-verify] [-force] [-gpus P] [-table SLOTS]
+                                          [-fp SEED] [-fp128] [-symmetry] [-fpcheck] [-verify] [-force] [-levels-csv FILE] [-gpus P] [-table SLOTS]
                                           [-frontier STATES] Spec.tla
 
 Maps the root module's name to its lowered GPU model, reads constants / invariants from the
@@ -53,6 +53,15 @@ def collision_report(distinct: int, generated: int, wide: bool = False):
     return out
 
 
+def uncertified(distinct: int, wide: bool) -> bool:
+    """A finished 64-bit search whose birthday bound exceeds FP128_ADVICE_ABOVE: its distinct-state count is more likely to be
+    off than not (BASELINE's target is the bit-identical count) — both front ends then exit with UNCERTIFIED_EXIT_CODE."""
+    return (not wide) and distinct * distinct / 2.0 ** 65 > FP128_ADVICE_ABOVE
+
+
+UNCERTIFIED_EXIT_CODE = 14
+
+
 FP128_ADVICE_ABOVE = 0.1
 
 
@@ -92,6 +101,9 @@ def main(argv=None) -> int:
     ap.add_argument("-frontier", type=int, default=0)
     ap.add_argument("-device", type=int, default=0)
     ap.add_argument("-notrace", action="store_true", help="do not keep predecessor links (no counterexample trace)")
+    ap.add_argument("-levels-csv", dest="levels_csv", default=None, metavar="FILE",
+                    help="write one line per BFS level (one GPU): frontier expanded, new states, probes, deadlocks, table load, "
+                         "k_expand milliseconds, successors generated per disjunct of Next")
     ap.add_argument("-fp128", action="store_true",
                     help="128-bit seen-set entries: the fingerprint plus an independent 64-bit check word per state, in the same "
                          "cache line (no extra memory traffic per probe, twice the table bytes); a 64-bit fingerprint collision "
@@ -216,6 +228,8 @@ def main(argv=None) -> int:
         with ModelChecker(conf) as mc:
             res = mc.run(progress)
             timing.update(mc.timing())
+            nonlocal level_rows
+            level_rows = mc.level_stats()
             trace = []
             if res.verdict in ("invariant",) and conf.keep_trace:
                 trace = mc.trace()
@@ -225,6 +239,7 @@ def main(argv=None) -> int:
 
     second = None
     timing = {}
+    level_rows = None   # -levels-csv: the per-expansion records of the search on one GPU (kmc_level_stats)
     try:
         res, trace = search(cc, progress)
         if a.fpcheck:
@@ -269,6 +284,17 @@ def main(argv=None) -> int:
         probed = res.generated * stored // res.distinct
     for line in collision_report(stored, probed, a.fp128):
         print(line)
+    if rc == 0 and uncertified(stored, a.fp128):
+        print(f"Warning: the distinct-state count of this run is NOT certified (64-bit fingerprints, birthday bound "
+              f"{stored * stored / 2.0 ** 65:.2E} > {FP128_ADVICE_ABOVE}): exit code {UNCERTIFIED_EXIT_CODE}.")
+        rc = UNCERTIFIED_EXIT_CODE
+    if a.levels_csv and level_rows is not None:
+        names = list(res.action_generated)
+        with open(a.levels_csv, "w") as lf:
+            lf.write("depth,frontier,new_states,stored_new,probes,deadlocks,table_load,expand_ms," + ",".join(names) + "\n")
+            for st in level_rows:
+                lf.write(f"{st['depth']},{st['frontier']},{st['new_states']},{st['stored_new']},{st['probes']},{st['deadlocks']},"
+                         f"{st['table_load']:.6f},{st['expand_ms']:.4f}," + ",".join(str(st['generated'][n]) for n in names) + "\n")
     if second is not None:
         seed2, r2 = second
         same = (r2.verdict, r2.distinct, r2.generated, r2.depth) == (res.verdict, res.distinct, res.generated, res.depth)

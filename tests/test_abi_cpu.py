@@ -36,7 +36,14 @@ def test_struct_sizes_match_header_layout():
     # kmc_config: 6*i32 + i64 + u32 + 6*i32 + (pad) + 5*u64 + ptr + 2*i32 ; kmc_result: see header
     assert C.sizeof(nat.KmcConfig) == 120
     assert C.sizeof(nat.KmcLevelInfo) == 40 + 8 * 16 + 32 + 32 + 32 + 32 + 8 + 8 + 8
-    assert C.sizeof(nat.KmcResult) == 8 * 4 + 8 + 8 + 32 + 8 + 8 + 8 * 16 + 8 * 3 + 16 + 8 + 16 + 8 + 8
+    assert C.sizeof(nat.KmcResult) == 8 * 4 + 8 + 8 + 32 + 8 + 8 + 8 * 16 + 8 * 3 + 16 + 8 + 16 + 8 + 8 + 8 * 3
+    assert C.sizeof(nat.KmcLevelStat) == 8 * 4 + 8 * 16 + 8 * 2 + 8 * 2
+    # ... and the native front end, compiled against the header itself, agrees (it prints sizeof of both with -abi-sizes)
+    import subprocess
+    exe = os.path.join(ROOT, "kafka_specification_amd", "tlc")
+    out = subprocess.run([exe, "-abi-sizes"], capture_output=True, text=True).stdout.split()
+    assert [int(x) for x in out] == [C.sizeof(nat.KmcConfig), C.sizeof(nat.KmcLevelInfo), C.sizeof(nat.KmcResult),
+                                     C.sizeof(nat.KmcLevelStat), C.sizeof(nat.KmcTiming)]
 
 
 def test_names():
@@ -59,9 +66,10 @@ def test_specialises_for_gfx950_without_a_gpu(tmp_path):
     files = objects()
     assert len(files) == 1 and files[0].startswith("Kip101_N2_L3_R2_E1-gfx950-")
     assert open(os.path.join(tmp_path, files[0]), "rb").read(4) == b"\x7fELF"
-    # ... and who compiled it, beside it (the cache is keyed by what is compiled, not by who compiles)
-    rec = [json.loads(ln) for ln in open(os.path.join(tmp_path, "COMPILERS.jsonl"))]
-    assert [r["file"] for r in rec] == files and rec[0]["hip_runtime_version"] > 0 and "." in rec[0]["hiprtc"]
+    # ... and who compiled it, IN ITS NAME: two compilers can never write one file
+    from kafka_specification_amd import compiler_identity
+    mine = compiler_identity(0)
+    assert mine > 0 and files[0].endswith(f"-c{mine}.hsaco")
     precompile(cfg, "gfx950")          # ... and all three: k_expand for the level-step interface and as an enumerator beside it
     files = sorted(objects(), key=len)
     assert len(files) == 3 and files[1].endswith("-enum.hsaco") and files[2].endswith("-sharded.hsaco")
@@ -313,3 +321,69 @@ def test_the_search_kernel_takes_its_own_argument_block_and_holds_no_other_mode(
     names = re.findall(r"<(kmc_\w+)>:", text)
     assert not any(n.startswith(("kmc_expand_sh_", "kmc_expand_en_", "kmc_expand_dry_")) for n in names)
     assert any(n.startswith("kmc_inv_") for n in names)
+
+
+def test_the_cache_key_names_the_compiler_and_every_process_prefers_the_pinned_one(tmp_path, monkeypatch):
+    """The code-object cache (csrc/kmc_engine_codeobj.cpp): the compiler's identity is part of the file name, a process bound to
+    ANOTHER compiler loads the pinned compiler's object when the cache holds it (the bench under PyTorch's runtime and a rocprofv3
+    run under the system's execute the same machine code), compiles its own — under its own name — when it does not, and never
+    touches the other's file."""
+    import subprocess
+    import sys
+    code = ("import sys, os; sys.path.insert(0, %r); import kafka_specification_amd as kmc; "
+            "c = kmc.CheckerConfig(model='Kip320', n_replicas=2, log_size=1, max_records=1, max_leader_epoch=1, cache_dir=%r); "
+            "print(kmc.compiler_identity(0), kmc.compiler_identity(1), kmc.code_object_path(c))" % (ROOT, str(tmp_path)))
+
+    def run(**env):   # a fresh process: which HIP runtime (and with it which hiprtc / comgr) it binds is decided at its first import
+        e = {k: v for k, v in os.environ.items() if k not in ("KMC_NO_TORCH", "KMC_COMPILER_PIN", "KMC_JIT_DEFINES")}
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(e, **env), check=True).stdout.split()
+        return int(out[0]), int(out[1]), out[2]
+
+    torch_id, pinned, p1 = run()                         # PyTorch imported first: its bundled runtime
+    assert pinned == 70051831 == torch_id                # csrc/kmc_engine_internal.h, KMC_PINNED_COMPILER (profiles/r06_compiler_ab.txt)
+    assert re.search(rf"-c{torch_id}\.hsaco$", p1)
+    blob = open(p1, "rb").read()
+    sys_id, _, p2 = run(KMC_NO_TORCH="1")                # the system ROCm's runtime, same cache
+    assert sys_id != torch_id, "this image should hold two HIP runtimes (PyTorch's bundle and /opt/rocm)"
+    assert p2 == p1                                      # ... loads the pinned compiler's object
+    sys_id2, pin2, p3 = run(KMC_NO_TORCH="1", KMC_COMPILER_PIN="0")   # no preference: it compiles its own, under its own name
+    assert sys_id2 == sys_id and pin2 == 0
+    assert p3 != p1 and p3.endswith(f"-c{sys_id}.hsaco") and os.path.exists(p3)
+    assert open(p1, "rb").read() == blob                 # and never touches the other's file
+    assert sorted(os.listdir(tmp_path)) == sorted({os.path.basename(p1), os.path.basename(p3)})
+    _, _, p4 = run(KMC_COMPILER_PIN=str(sys_id))         # pinned to the system's: PyTorch's process now loads THAT object
+    assert p4 == p3
+
+
+def test_deferred_probe_load_is_issued_at_the_defer_point(tmp_path):
+    """the deferred probe's first load (kmc_expand_body, `pd_v = a.table[i]`) must be ISSUED where the batch is
+    deferred — ahead of the walk's leaves it is supposed to hide under — not sunk next to the compare-and-swap that consumes it.
+    In the ISA of a build that defers (forced onto a small configuration): inside the flush, after the fingerprint's last
+    multiply there is a global_load of the slot BEFORE the next LDS write of the successor ring / the next s_cbranch back into
+    the walk, and the cmpswap that follows it is separated from it by other work."""
+    import subprocess
+    cfg = CheckerConfig(model="Kip320", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1, cache_dir=str(tmp_path))
+    os.environ["KMC_JIT_DEFINES"] = "-DKMC_DEFER_MIN_WORDS=1"
+    try:
+        from kafka_specification_amd import code_object_path
+        path = code_object_path(cfg)
+    finally:
+        del os.environ["KMC_JIT_DEFINES"]
+    asm = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--no-show-raw-insn", path], capture_output=True, text=True,
+                         check=True).stdout
+    body = asm[asm.index("<kmc_expand_Kip320_N3_L2_R2_E1>:"):]
+    body = body[:body.index("\n\n", 10)] if "\n\n" in body[10:] else body
+    lines = [ln.split("//")[0].strip() for ln in body.splitlines()]
+    ops = [ln.split()[0] for ln in lines if ln and not ln.endswith(":") and not ln.startswith("<")]
+    cas = [i for i, o in enumerate(ops) if o.startswith("global_atomic_cmpswap")]
+    assert cas, "no compare-and-swap in the search's kernel?"
+    # every claim is preceded by a probe load; for the DEFERRED claim the nearest preceding 8-byte global load of a table slot
+    # lies far upstream (the whole walk is between them): at least one cmpswap whose previous global_load_dwordx2 is more than
+    # 200 instructions back, with LDS ring writes (ds_write) in between
+    def gap(i):
+        for j in range(i - 1, -1, -1):
+            if ops[j].startswith("global_load_dwordx2"):
+                return i - j, sum(1 for o in ops[j:i] if o.startswith("ds_write"))
+        return 0, 0
+    gaps = [gap(i) for i in cas]
+    assert any(g > 200 and w > 0 for g, w in gaps), gaps

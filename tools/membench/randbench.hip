@@ -13,6 +13,11 @@
 //           does a write that covers a whole 32-byte sector / 64-byte half line / 128-byte line escape the read-modify-write
 //           that an 8-byte store into an untouched DRAM line pays?  (round 4: what a claim protocol with wider slots could hope for)
 //   mode 12: load, then a plain 8-byte store when the slot was empty (a claim without the atomic)
+//   mode 13: the WIDE seen-set's mix (kmc_config.wide_fingerprint): one 16-byte load of a 16-byte slot, and for 35 % of the
+//           accesses a CAS on its first word and an agent-scope store of its second (KmcSink::claim_wide)
+// Round 6: footprints beyond 2^30 slots (RANDBENCH_MAX_LOG2, up to 2^34 = 128 GiB), for the regime of the 6.45 G-state stretch;
+// RANDBENCH_ALIGN_GIB=1 places the table at a 1 GiB-aligned address inside a larger allocation (does the driver map it with
+// larger fragments then?); RANDBENCH_MODES=1,3,7 runs only those modes.
 // Prints G accesses/s.  Build: hipcc --offload-arch=gfx950 -O3 randbench.hip -o randbench
 // Usage: randbench [first_mode [log2_slots ...]]  — with sizes given, every mode runs on a table of
 // each size (footprint sweep: does a seen-set partition that fits L2 / Infinity Cache probe faster?)
@@ -66,6 +71,19 @@ __global__ __launch_bounds__(256) void k(u64* table, u64 mask, int iters, int mo
             const uint4 v = make_uint4((unsigned)x, (unsigned)(x >> 32), (unsigned)i, 1u);
             for (int q = 0; q < quads; ++q) p[q] = v;
         }
+    } else if (mode == 13) {
+        const u64 smask = mask >> 1;   // 16-byte slots over the same footprint
+        for (int i = 0; i < iters; ++i) {
+            x = mix(x + 1);
+            u64* slot = table + 2 * (x & smask);
+            const ulonglong2 v = *(const ulonglong2*)slot;
+            u64 r = v.x ^ v.y;
+            if (((x >> 40) & 0xFF) < 90) {
+                r ^= atomicCAS(slot, v.x, x | 1);
+                __hip_atomic_store(slot + 1, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            acc ^= r;
+        }
     } else {
         for (int i = 0; i < iters; ++i) {
             x = mix(x + 1);
@@ -77,17 +95,29 @@ __global__ __launch_bounds__(256) void k(u64* table, u64 mask, int iters, int mo
     if (acc == 0x1234) sink[0] = acc;
 }
 int main(int argc, char** argv) {
-    const u64 max_slots = 1ull << 30;  // 8 GiB
-    u64 *table, *sink;
-    hipMalloc(&table, max_slots * 8); hipMalloc(&sink, 8);
+    const int max_log2 = getenv("RANDBENCH_MAX_LOG2") ? atoi(getenv("RANDBENCH_MAX_LOG2")) : 30;   // 30: 8 GiB
+    const u64 max_slots = 1ull << max_log2;
+    const bool align_gib = getenv("RANDBENCH_ALIGN_GIB") && atoi(getenv("RANDBENCH_ALIGN_GIB"));
+    bool want[14];
+    for (int m = 0; m < 14; ++m) want[m] = getenv("RANDBENCH_MODES") == nullptr;
+    if (const char* ms = getenv("RANDBENCH_MODES"))
+        for (const char* p = ms; *p;) { const int m = atoi(p); if (m >= 0 && m < 14) want[m] = true; while (*p && *p != ',') ++p; if (*p) ++p; }
+    u64 *raw, *table, *sink;
+    if (hipMalloc(&raw, max_slots * 8 + (align_gib ? (1ull << 30) : 0)) != hipSuccess) { printf("hipMalloc of 2^%d slots failed\n", max_log2); return 1; }
+    table = align_gib ? (u64*)(((unsigned long long)raw + (1ull << 30) - 1) & ~((1ull << 30) - 1)) : raw;
+    hipMalloc(&sink, 8);
+    if (getenv("RANDBENCH_MAX_LOG2") || align_gib)
+        printf("# allocation of 2^%d slots at %p (table at %p: aligned to 2^%d bytes)\n", max_log2, (void*)raw, (void*)table,
+               __builtin_ctzll((unsigned long long)table));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     int sizes[16] = {30}, nsizes = 1;
     if (argc > 2) { nsizes = 0; for (int i = 2; i < argc && nsizes < 16; ++i) sizes[nsizes++] = atoi(argv[i]); }
     for (int si = 0; si < nsizes; ++si) {
-    const u64 slots = 1ull << (sizes[si] < 10 ? 10 : sizes[si] > 30 ? 30 : sizes[si]);
+    const u64 slots = 1ull << (sizes[si] < 10 ? 10 : sizes[si] > max_log2 ? max_log2 : sizes[si]);
     if (nsizes > 1 || argc > 2) printf("# table of 2^%d slots = %.1f MiB\n", sizes[si], slots * 8 / 1048576.0);
-    for (int mode = (argc > 1 ? atoi(argv[1]) : 0); mode < 13; ++mode)
+    for (int mode = (argc > 1 ? atoi(argv[1]) : 0); mode < 14; ++mode)
         for (int bpc : {8}) {
+            if (!want[mode]) continue;
             hipMemset(table, 0, slots * 8);
             const int blocks = 256 * bpc, iters = (mode == 0 || mode == 6) ? 400 : 800;
             k<<<blocks, 256>>>(table, slots - 1, 8, mode, sink);  // warm-up

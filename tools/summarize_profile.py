@@ -88,6 +88,30 @@ try:
                 der["claims_per_distinct_state"] = ctr["TCC_EA0_ATOMIC_sum"] / run["config"]["distinct_states"]
 except OSError:
     pass
+# The invariant pass over a frontier that is not expanded (k_inv: the last level of a level-budgeted search) — its own row:
+# duration, counters, DRAM bytes.  A pure streaming read; VERDICT r5 found it unprofiled at 25 % of the HBM's rate.
+inv_names = [k for k in per if k.startswith("kmc_inv")]
+if inv_names:
+    ik = inv_names[0]
+    ictr = defaultdict(float)
+    for f in sorted(glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"] == ik:
+                ictr[r["Counter_Name"]] += float(r["Counter_Value"])
+    it = out["kernel_trace"][ik]
+    row = {"kernel": ik, "calls": it["calls"], "seconds_total": it["total_ns"] * 1e-9, "counters": dict(ictr)}
+    irow = [r for r in rows if r["Kernel_Name"] == ik][-1]
+    row["launch_cfg"] = {k: irow.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in irow}
+    if "TCC_EA0_RDREQ_DRAM_32B_sum" in ictr:
+        rb = 32 * ictr["TCC_EA0_RDREQ_DRAM_32B_sum"]
+        wb = 32 * (ictr.get("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", 0.0) + ictr.get("TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum", 0.0))
+        row.update(dram_read_bytes=rb, dram_write_and_atomic_bytes=wb, hbm_bytes=rb + wb, hbm_bytes_per_launch=(rb + wb) / max(it["calls"], 1),
+                   dram_GBps_over_kernel_time=(rb + wb) / max(it["total_ns"] * 1e-9, 1e-12) / 1e9)
+    if "SQ_WAVE_CYCLES" in ictr:
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if k in ictr:
+                row[k + "_frac_of_wave_cycles"] = ictr[k] / ictr["SQ_WAVE_CYCLES"]
+    out["kmc_inv"] = row
 out["derived"] = der
 out["kernel_seconds_total"] = t
 out["launches"] = n
@@ -122,4 +146,6 @@ if len(sys.argv) > 3 and ("dram_bytes" in der or "hbm_bytes_raw" in der):
     pm["run"] = out.get("run")
     pm["dominant_kernel"] = exp
     pm["kernel_seconds_total"] = t
+    if "kmc_inv" in out:
+        pm["kmc_inv"] = {k: v for k, v in out["kmc_inv"].items() if k != "counters"}
     open(sys.argv[3], "w").write(json.dumps(pm, indent=1) + "\n")
