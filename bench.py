@@ -323,6 +323,12 @@ BASELINE_LEGS = {
     "config4_kip279_5brokers": dict(
         c=dict(model="Kip279", n_replicas=5, log_size=2, max_records=2, max_leader_epoch=1, invariants=("TypeOk",)),
         table=1 << 30, frontier=1 << 26, cpu_states=0),     # cpu_baseline: the whole search (about ten seconds on 32 threads)
+    # ... and at SURVEY section 8(a.0)'s own sizing of config 4 (LogSize 4, MaxRecords 4, MaxLeaderEpoch 3: four words per state),
+    # where a log holds up to four epochs and Kip279's truncation (Kip279.tla:27-51) has three epochs in a log to look at: not
+    # exhaustible — twelve BFS levels, 318,475,476 states (tests/golden/oracle_kip279_5_4_4_3_levels12.json, exact), "exhausted": false
+    "config4_deep_kip279_5brokers_log4_levels12": dict(
+        c=dict(model="Kip279", n_replicas=5, log_size=4, max_records=4, max_leader_epoch=3, invariants=("TypeOk",), max_levels=12),
+        table=1 << 31, frontier=1 << 28, cpu_states=20_000_000),
     # Kip320.tla:150-159 at seven brokers, LogSize 8: nobody exhausts it — ten BFS levels, 197,561,008
     # states (tests/golden/oracle_kip320_7_8_8_3_levels10.json, exact), reported with "exhausted": false
     "config5_kip320_7brokers_levels10": dict(
@@ -610,8 +616,10 @@ def main():
         results, dt = run_single(c, a.steps, a.warmup, symmetry=a.symmetry)
         extra = {}
         scaling, parallelism = "strong", "1 GPU" + (", orbit counting over the permutations of Replicas" if a.symmetry else "")
-    stretch = stretch_leg(a) if (a.gpus > 1 or world > 1) and a.stretch else None
+    want_stretch = (a.gpus > 1 or world > 1) and a.stretch
     if rank != 0:
+        if want_stretch:
+            stretch_leg(a)      # (collective: every rank takes part; engines are opened under a cross-rank agreement, sharded.py)
         return
 
     r = results[-1]
@@ -755,8 +763,12 @@ def main():
         cs = cold_start(c)
         if cs:
             out["cold_start"] = cs
-    if stretch is not None:
-        out["stretch"] = stretch
+    if want_stretch:
+        # The headline line is complete here.  The stretch leg is another collective search (6.45 G states over the ranks): should
+        # it hang, the headline must not be lost with it — it goes to stderr first; stdout still carries ONE line.
+        sys.stderr.write("[bench.py: the headline line, before the stretch leg] " + json.dumps(out) + "\n")
+        sys.stderr.flush()
+        out["stretch"] = stretch_leg(a)
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(c, a.cpu_states or max(1_000_000, distinct // 4), distinct)
     print(json.dumps(out))

@@ -20,6 +20,11 @@ BASELINE_CONFIGS = {
     "config4_kip320_7brokers_log8": dict(model="Kip320", n_replicas=7, log_size=8, max_records=8,
                                          max_leader_epoch=3, invariants=("TypeOk",)),
 }
+# BASELINE config 4 at the sizing SURVEY section 8(a.0) gives it (LogSize 4, MaxRecords 4, MaxLeaderEpoch 3: W = 4 words): not
+# exhaustible — 26 M states at depth 10, growing 3x per level — so it is checked over a level budget, like config 5.  At these
+# constants a log holds up to four epochs: FirstNonMatchingOffsetFromTail (Kip279.tla:39-45) has something to truncate.
+CONFIG4_DEEP = dict(model="Kip279", n_replicas=5, log_size=4, max_records=4, max_leader_epoch=3, invariants=("TypeOk",))
+CONFIG4_DEEP_LEVELS = 12
 
 
 def precompile_list():
@@ -56,6 +61,8 @@ def precompile_list():
             for m in ("KafkaTruncateToHighWatermark", "Kip101", "Kip279")]
     out += [dict(model="Kip320FirstTry", n_replicas=3, log_size=2, max_records=3, max_leader_epoch=2)]
     out += [dict(model="Kip279", n_replicas=5, log_size=2, max_records=2, max_leader_epoch=2)]  # the non-exhaustible twin (prefix test)
+    # BASELINE config 4 at SURVEY 8(a.0)'s sizing: logs four deep, four epochs (bench.py's config4_deep leg, the per-state fixture)
+    out += [dict(model="Kip279", n_replicas=5, log_size=4, max_records=4, max_leader_epoch=3)]
     # tests/golden/oracle_r_ladder.json's 3/3/3/1 entries (round 4: the reference's text executed with logs three deep)
     out += [dict(model=m, n_replicas=3, log_size=3, max_records=3, max_leader_epoch=1) for m in KAFKA]
     out += [dict(model="Kip320", n_replicas=3, log_size=2, max_records=3, max_leader_epoch=2)]   # oracle_r_ladder.json: 1.69 M states

@@ -102,6 +102,10 @@ typedef unsigned int u32;
 #define KMC_DEFER_MIN_WORDS 8   // states of at least this many words (seven brokers with deep logs: 2 waves per SIMD by LDS) run
                                 // the search's flush with a DEFERRED probe: kmc_expand_body
 #endif
+#ifndef KMC_PROBE_AHEAD
+#define KMC_PROBE_AHEAD 4   // slots a probe chain looks at per memory round trip from its SECOND step on (KmcSink::claim_from; 1 = the
+                            // one-slot-per-step walk of rounds 1 - 5)
+#endif
 #ifndef KMC_SYMM
 #define KMC_SYMM 0        // 1 (kmc_config.symmetry): symmetry reduction with orbit counting — every successor is replaced by the
                           // representative of its orbit under the permutations of Replicas before it is fingerprinted, and

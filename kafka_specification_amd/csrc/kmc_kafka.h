@@ -890,7 +890,18 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
         return bad;
     }
 
-    static KMC_DEV u32 violated_pre(const Pre& p, u32 inv_mask) {
+    // The same invariants for a kernel that does nothing else (k_inv: a frontier streamed through, kmc_check_states): the view
+    // holds the state's words only — the guards' shared sub-predicates (extract: 49 following-epoch pairs at seven brokers, made
+    // opaque there and therefore never dead) are not the invariants' business — and the evaluation runs replica after replica
+    // (SEQ: an opaque point after each, and a leader nobody in the wave presumes is skipped), so that it fits the registers of
+    // four waves per SIMD instead of the 171 - 200 the interleaved form takes (profiles/r06_inv.txt).
+    static KMC_DEV u32 violated_stream(const u64* t, u32 inv_mask) {
+        Pre p;
+        p.w = t;
+        p.one = 1u; p.epok = 0; p.pm = 0; p.tm = 0; p.hm = 0; p.fm = 0;
+        return violated_pre<true>(p, inv_mask);
+    }
+    template <bool SEQ = false> static KMC_DEV u32 violated_pre(const Pre& p, u32 inv_mask) {
         if (inv_mask == 0) return 0;
         u32 bad = 0;
         if (inv_mask & 1u) {
@@ -902,6 +913,7 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
                 nb |= (p.end(r) > (u32)L ? 1u : 0u) | (p.hw(r) > (u32)L ? 1u : 0u) | (p.ep1(r) > (u32)(E + 1) ? 1u : 0u) |
                       (p.ldr1(r) > (u32)N ? 1u : 0u);
                 nb |= log_type_bad<r>(p);
+                if constexpr (SEQ) kmc_launder(nb);
             });
             kmc_static_for<0, E + 1>([&](auto EE) {
                 constexpr int e = decltype(EE)::value;
@@ -920,6 +932,9 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
                 constexpr int r1 = decltype(R1)::value;
                 const u32 hw = p.hw(r1);
                 const u32 act = (presumes<r1>(p) && hw > 0) ? 1u : 0u;
+                if constexpr (SEQ) {
+                    if (!kmc_any_lane(act != 0)) return;   // (wave-uniform: no state of this tile has r1 as a leader with hw > 0)
+                }
                 const LogT kb = keep_below(hw);
                 const LogT l1 = p.logv(r1);
                 const u32 short1 = hw > p.end(r1) ? 1u : 0u;
@@ -936,6 +951,7 @@ template <int MODEL, int N, int L, int R, int E, int LM = KMC_LAYOUT_AUTO> struc
                 const u32 m = act ? differs : 0u;
                 wbad |= m & p.isr(r1);
                 sbad |= m & qisr;
+                if constexpr (SEQ) { kmc_launder(wbad); kmc_launder(sbad); }
             });
             if ((inv_mask & 2u) && wbad) bad |= 2u;
             if ((inv_mask & 4u) && sbad) bad |= 4u;

@@ -22,6 +22,7 @@ template <long long MAXID> struct KmcIdSequence {
         return (inv_mask & 1u) && !((long long)p.nextId <= MAXID + 1) ? 1u : 0u;
     }
     static KMC_DEV u32 violated(const u64* t, u32 inv_mask) { return violated_pre(extract(t), inv_mask); }
+    static KMC_DEV u32 violated_stream(const u64* t, u32 inv_mask) { return violated(t, inv_mask); }   // (k_inv's entry: KmcKafka)
 };
 
 // ========================================================================================
@@ -83,6 +84,7 @@ template <int N, int L, int K> struct KmcFiniteReplicatedLog {
         }
     }
     static KMC_DEV u32 violated(const u64* t, u32 inv_mask) { return violated_pre(extract(t), inv_mask); }
+    static KMC_DEV u32 violated_stream(const u64* t, u32 inv_mask) { return violated(t, inv_mask); }   // (k_inv's entry: KmcKafka)
     static KMC_DEV u32 violated_pre(const Pre& p, u32 inv_mask) {  // TypeOk, :90-95
         if (!(inv_mask & 1u)) return 0;
         bool ok = true;
@@ -231,5 +233,6 @@ template <int N, int MO, int V> struct KmcAsyncIsr {
         return bad;
     }
     static KMC_DEV u32 violated(const u64* t, u32 inv_mask) { return violated_pre(extract(t), inv_mask); }
+    static KMC_DEV u32 violated_stream(const u64* t, u32 inv_mask) { return violated(t, inv_mask); }   // (k_inv's entry: KmcKafka)
 };
 

@@ -738,11 +738,28 @@ def make_engine_and_exchange(cfg: CheckerConfig, rank: int, world: int, local: i
     import sys
     factory = _engine_factory()
     want_native = device.type == "cuda" and factory is HipShardEngine and os.environ.get("KMC_EXCHANGE", "rccl") != "torch"
-    if not want_native:
-        eng = factory(cfg, rank, world, local)
-        return eng, DistExchange(device, eng.record_words)
     import torch
     import torch.distributed as dist
+    if not want_native:
+        # (the same agreement as below: a rank that cannot open its engine — out of memory at the stretch leg's capacities, a cold
+        # cache that does not compile — must not leave the others waiting in the first collective of the search: ADVICE r5)
+        eng, err = None, ""
+        try:
+            eng = factory(cfg, rank, world, local)
+        except Exception as e:   # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        if dist.is_initialized() and world > 1:
+            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item()) == 1
+        else:
+            ok = not err
+        if not ok:
+            if eng is not None:
+                eng.close()
+            raise RuntimeError(f"rank {rank}: a shard engine could not be created on some rank"
+                               f"{' (here: ' + err + ')' if err else ''}; no rank continues")
+        return eng, DistExchange(device, eng.record_words)
     eng, ex, err = None, None, ""
     try:
         eng = HipShardEngine(cfg, rank, world, local, native=True)

@@ -49,3 +49,7 @@ done
 # ... and four to eight (two CPU-hours, one of them the whole of Kip320 at seven replicas on one core; incremental: entries already
 # in the file are kept)
 # python tests/golden/make_oracle_r_golden.py --wide     # -> tests/golden/oracle_r_wide.json
+# BASELINE config 4 at SURVEY 8(a.0)'s own sizing (Kip279 5/4/4/3: logs four deep, four epochs; round 6): not exhaustible — the exact
+# oracle's PREFIX of twelve levels (318,475,476 states, 2.4 minutes on 7 threads, ~24 GB).  --max-states = the first eleven levels + 1,
+# so the search stops after the twelfth (the eleven-level sum comes from a first run with --max-states 38031472: 112,310,901)
+./oracle/kmc_oracle --model Kip279 --N 5 --L 4 --R 4 --E 3 --threads 7 --inv 1 --max-states 112310902 > tests/golden/oracle_kip279_5_4_4_3_levels12.json

@@ -154,3 +154,24 @@ def test_the_stretch_kip320_with_three_epochs_plain_search_with_wide_entries_mat
     assert (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"])
     assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
     assert r.deadlock_states == g["deadlock_states"]
+
+
+def test_baseline_config4_at_the_surveys_own_sizing_over_twelve_levels_matches_the_exact_oracle():
+    """BASELINE config 4 (Kip279, five brokers) at SURVEY section 8(a.0)'s sizing — LogSize 4, MaxRecords 4, MaxLeaderEpoch 3, four
+    words per state — where a log holds up to four epochs and FirstNonMatchingOffsetFromTail (Kip279.tla:39-45) has something to
+    truncate.  Not exhaustible (three times more states per level): the first twelve levels, 318,475,476 states, against the exact C
+    oracle's prefix (tests/golden/oracle_kip279_5_4_4_3_levels12.json) — level sizes, per-disjunct generated counts, deadlocks."""
+    from kafka_specification_amd.configs import CONFIG4_DEEP, CONFIG4_DEEP_LEVELS
+    g = json.load(open(os.path.join(GOLDEN, f"oracle_kip279_5_4_4_3_levels{CONFIG4_DEEP_LEVELS}.json")))
+    cfg = CheckerConfig(**CONFIG4_DEEP, max_levels=CONFIG4_DEEP_LEVELS, table_capacity=1 << 31, frontier_capacity=1 << 28)
+    with ModelChecker(cfg) as mc:
+        r = mc.run()
+        st = mc.level_stats()
+    assert r.verdict == "level_limit" and r.queue_left == g["levels"][-1]
+    assert (r.distinct, r.generated, r.depth, r.levels) == (g["distinct"], g["generated"], g["depth"], g["levels"]) and g["distinct"] == 318475476
+    assert list(r.action_generated.values()) == g["action_generated"][:len(r.action_generated)]
+    assert r.deadlock_states == g["deadlock_states"]
+    # ... and the per-level records (kmc_level_stats) are the same search, level by level
+    assert [x["new_states"] for x in st] == g["levels"][1:] and [x["frontier"] for x in st] == g["levels"][:-1]
+    assert sum(sum(x["generated"].values()) for x in st) + 1 == r.generated
+    assert all(x["expand_ms"] > 0 for x in st) and abs(sum(x["expand_ms"] for x in st) - 1e3 * r.seconds_expand) < 1e-3 * max(1.0, 1e3 * r.seconds_expand)

@@ -27,6 +27,7 @@ def test_the_fixtures_exist_for_every_binding_the_bench_and_baseline_name():
     for mod in ("KafkaTruncateToHighWatermark", "Kip101", "Kip279", "Kip320", "Kip320FirstTry"):
         assert (mod, 3, 6, 6, 2) in have
     assert ("Kip279", 5, 2, 2, 1) in have and ("Kip320", 7, 8, 8, 3) in have
+    assert ("Kip279", 5, 4, 4, 3) in have         # config 4 at SURVEY 8(a.0)'s sizing: three epochs in a log at five brokers
     assert ("MCAsyncIsr", 4, 3, 0, 4) in have     # models/MCAsyncIsr.cfg: AsyncIsr.tla under the state constraint
 
 
@@ -112,3 +113,26 @@ def test_invariants_on_arbitrary_states_equal_the_executed_reference(entry):
             got_d = host_emu.violated(cfg6, mc.pack(s), 15) & keep
             assert got_c == want, f"C oracle: {s.hex()} violates {got_c:04b}, the reference's text says {want:04b}"
             assert got_d == want, f"device templates: {s.hex()} violates {got_d:04b}, the reference's text says {want:04b}"
+
+
+def test_config4_deep_sample_has_three_epochs_in_a_log_at_five_brokers():
+    """VERDICT r5, missing 5: at Kip279 5/2/2/1 a log is at most two deep and holds two epochs — FirstNonMatchingOffsetFromTail
+    (Kip279.tla:39-45) never sees three.  At 5/4/4/3 the per-state file holds >= 10,000 states with a log >= 3 deep holding >= 3
+    distinct record epochs (recomputed from the state bytes)."""
+    e = [x for x in ENTRIES if (x[1]["module"], x[1]["N"], x[1]["L"], x[1]["R"], x[1]["E"]) == ("Kip279", 5, 4, 4, 3)]
+    assert e, "tests/golden/oracle_r_successors_kip279_5_4_4_3.npz is missing"
+    fx = ors.load(e[0][0])
+    N, L, E = 5, 4, 3
+    n3 = 0
+    for s in fx["states"]:
+        b = bytes(s)
+        for r in range(N):
+            o = r * (5 + L)
+            end = b[o]
+            if end >= 3 and len({(b[o + 5 + k] - 1) % (E + 1) for k in range(min(end, L)) if b[o + 5 + k]}) >= 3:
+                n3 += 1
+                break
+    assert n3 >= 10000, n3
+    # ... and the truncating disjunct fires on thousands of them
+    k = e[0][1]["actions"].index("BecomeFollowerTruncateKip279") if "BecomeFollowerTruncateKip279" in e[0][1]["actions"] else None
+    assert k is not None and int(fx["per_action"][:, k].sum()) > 10000

@@ -26,6 +26,11 @@ for set in "TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_WR
   timeout 90 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc$i" -o pmc -- $CMD > "$OUT/pmc$i.log" 2>&1
   echo "pass $i ($set): rc=$?" >> "$OUT/passes.log"
 done
+# roctx ranges (one per BFS level, or per chain of levels when kmc_run chains them; the clear of the seen-set and
+# the invariant pass have their own): a marker trace WITHOUT counters (gpurun refuses --pmc together with a marker trace)
+KMC_ROCTX=1 timeout 300 rocprofv3 --marker-trace --kernel-trace --output-format csv -d "$OUT/markers" -o markers -- $CMD > "$OUT/markers.log" 2>&1
+MK="$(find "$OUT/markers" -name '*marker_api_trace.csv' | head -1)"
+[ -n "$MK" ] && { echo "roctx ranges in the trace: $(grep -c 'kmc' "$MK")"; grep 'kmc' "$MK" | head -4 | cut -c1-220; cp "$MK" "$OUT/marker_api_trace.csv"; }
 grep -h '"metric"' "$OUT"/*.log | head -1 | cut -c1-400
 find "$OUT" -name "*.csv" | head -30
 python3 "$REPO/tools/summarize_profile.py" "$OUT" "$OUT/summary.json" "$OUT/pmc_summary.json" > /dev/null && echo summarised
