@@ -94,7 +94,9 @@ typedef struct kmc_config {
     int32_t device;             /* HIP device ordinal; -1 = host-only handle (pack/unpack/fingerprint only) */
     int32_t n_shards;           /* 1 = single GPU; P>1: this handle owns fingerprints with owner(fp)==shard_id */
     int32_t shard_id;
-    uint64_t table_capacity;    /* fingerprint slots (rounded up to a power of two); 0 = auto from free HBM */
+    uint64_t table_capacity;    /* fingerprint slots, rounded up to a multiple of 64 (any size: a table can fill the HBM there
+                                   is, 288 GB hold 2^34 narrow or 12.9 G wide entries beside the frontiers); 0 = auto from free
+                                   HBM (a power of two) */
     uint64_t frontier_capacity; /* states per frontier buffer; 0 = auto */
     uint64_t send_capacity;     /* n_shards>1: records per (destination, sub-buffer) per level; 0 = auto */
     uint64_t hash_seed;         /* results must not depend on it (collisions aside) */

@@ -102,10 +102,6 @@ typedef unsigned int u32;
 #define KMC_DEFER_MIN_WORDS 8   // states of at least this many words (seven brokers with deep logs: 2 waves per SIMD by LDS) run
                                 // the search's flush with a DEFERRED probe: kmc_expand_body
 #endif
-#ifndef KMC_PROBE_AHEAD
-#define KMC_PROBE_AHEAD 4   // slots a probe chain looks at per memory round trip from its SECOND step on (KmcSink::claim_from; 1 = the
-                            // one-slot-per-step walk of rounds 1 - 5)
-#endif
 #ifndef KMC_SYMM
 #define KMC_SYMM 0        // 1 (kmc_config.symmetry): symmetry reduction with orbit counting — every successor is replaced by the
                           // representative of its orbit under the permutations of Replicas before it is fingerprinted, and
@@ -191,7 +187,7 @@ struct KmcArgsLocal {
     u64* fout;         // next frontier
     u64 fout_stride;
     u64* table;        // open-addressed fingerprint table, 0 = empty
-    u64 table_mask;    // capacity-1 (capacity is a power of two)
+    u64 table_cap;     // slots: a multiple of 64, not necessarily a power of two (kmc_slot_of)
     u64* pred;         // optional: predecessor fingerprint per table slot (trace reconstruction)
     KmcLevelCtl* ctl;
     u64 seed;
@@ -330,6 +326,16 @@ template <int W> KMC_HD inline u64 kmc_fingerprint(const u64* w, u64 seed) {
     for (int k = 0; k < W; ++k) h = kmc_mix64(h ^ w[k]) + 0x9E3779B97F4A7C15ull;
     return h ? h : 1ull;
 }
+// The home slot of a fingerprint in a seen-set of `cap` slots — any multiple of 64, so that a table can be sized to the HBM it has
+// instead of to the power of two below it (round 6: the 6.45 G-state stretch with 128-bit entries fits 2^33 slots = 128 GiB at load
+// 0.75, where linear probing walks 4 - 8 slots per lookup and the probe rate falls to a quarter, or 12.9 G slots = 192 GiB at
+// load 0.5: profiles/r06_stretch.txt).  Bits 8..39 of the fingerprint scaled onto the 64-slot groups (one 32 x 32 -> high 32
+// multiply), bits 0..5 within the group; bits 40..63 choose the owner shard (kmc_owner), so a shard's fingerprints still spread
+// over its whole table.  The chain continues at the next slot, wrapping at cap.
+KMC_HD inline u64 kmc_slot_of(u64 fp, u64 cap) {
+    return ((((u64)(u32)(fp >> 8) * (u64)(u32)(cap >> 6)) >> 32) << 6) | (fp & 63ull);
+}
+KMC_HD inline u64 kmc_slot_next(u64 i, u64 cap) { return i + 1 == cap ? 0ull : i + 1; }
 // owner shard of a fingerprint: its bits 40..63 scaled onto 0..nshards-1 (a multiply and a shift; a run-time `% nshards`
 // on a 64-bit value is a ~100-instruction division on this ISA, once per successor)
 KMC_HD inline u32 kmc_owner(u64 fp, u32 nshards) { return (u32)((((fp >> 40) & 0xFFFFFFull) * (u64)nshards) >> 24); }

@@ -65,7 +65,7 @@ int launch_inv(kmc_handle* h, const KmcArgs& a, uint64_t n) {
 KmcArgs base_args(kmc_handle* h, int ctl_slot) {
     KmcArgs a{};
     a.table = h->table;
-    a.table_mask = h->table_cap - 1;
+    a.table_cap = h->table_cap;
     a.pred = h->pred;
     a.sent = h->sent;
     a.sent_mask = h->sent_cap ? h->sent_cap - 1 : 0;
@@ -143,7 +143,7 @@ int find_state(kmc_handle* h, const u64* frontier, const uint64_t seg[KMC_SEGS],
     a.fin = frontier;
     uint64_t n = 0;
     for (int sg = 0; sg < KMC_SEGS; ++sg) { a.seg_count[sg] = seg[sg]; n += seg[sg]; }
-    a.table_mask = fp;  // kmc_find_body takes the target here
+    a.table_cap = fp;  // kmc_find_body takes the target here
     a.send = h->scratch;
     HIP_TRY(hipMemsetAsync(h->scratch, 0xFF, (h->W + 1) * 8, h->stream));
     int rc = launch(h, h->f_find, a, expand_grid(h, n));

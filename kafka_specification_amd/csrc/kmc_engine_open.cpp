@@ -214,9 +214,12 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     // auto-sizing: half of the budget for the table; a shard also keeps a sender-side filter of twice the table
     // (0.15 + 0.30), two frontiers (2 x 0.09), a send area and a receive area (0.12 each)
     const double table_share = h->cfg.n_shards > 1 ? 0.15 : 0.5;
-    uint64_t tcap = cfg->table_capacity ? pow2_ceil(cfg->table_capacity)
+    // An explicit capacity is taken as given (rounded up to a whole 64-slot group: kmc_slot_of): a table may be sized to the
+    // memory there is, not to the power of two below it.  The automatic size stays a power of two.
+    uint64_t tcap = cfg->table_capacity ? (cfg->table_capacity + 63) / 64 * 64
                                         : pow2_floor((uint64_t)(budget * table_share) / slot_bytes);
     if (tcap < 1024) tcap = 1024;
+    if (tcap >> 6 > 0xFFFFFFFFull) return fail(KMC_E_ARG, "table_capacity %llu: at most 2^38 slots", (unsigned long long)tcap);
     uint64_t fcap = cfg->frontier_capacity;
     if (!fcap) {
         const double share = h->cfg.n_shards > 1 ? 0.09 : 0.20;
@@ -252,7 +255,7 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     if (h->cfg.wide_fingerprint) want_filter = false;
     if (want_filter) {
         // it may meet up to ~2x as many distinct remote fingerprints as it owns
-        h->sent_cap = tcap * 2;
+        h->sent_cap = pow2_floor(tcap * 2);   // (the filter's own index is a mask: first_time)
         if (hipMalloc(&h->sent, h->sent_cap * 8) != hipSuccess) { h->sent = nullptr; h->sent_cap = 0; }  // optional
     }
     if (h->cfg.n_shards > 1) {

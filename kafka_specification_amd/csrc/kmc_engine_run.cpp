@@ -455,9 +455,8 @@ int kmc_witness(kmc_handle* h, uint64_t* words) {
 
 // Looks fp up in the device table from the host (a few 8-byte reads); returns the slot.
 static int table_lookup(kmc_handle* h, uint64_t fp, uint64_t* slot) {
-    const uint64_t mask = h->table_cap - 1;
-    uint64_t i = fp & mask;
-    for (uint64_t probes = 0; probes <= mask; ++probes) {
+    uint64_t i = kmc_slot_of(fp, h->table_cap);
+    for (uint64_t probes = 0; probes < h->table_cap; ++probes) {
         uint64_t v = 0;
         HIP_TRY(hipMemcpy(&v, h->table + i * h->slot_words, 8, hipMemcpyDeviceToHost));
         // (with wide slots two distinct states may carry this fingerprint; the first one is reported — the check word
@@ -467,7 +466,7 @@ static int table_lookup(kmc_handle* h, uint64_t fp, uint64_t* slot) {
             return KMC_OK;
         }
         if (v == 0) break;
-        i = (i + 1) & mask;
+        i = kmc_slot_next(i, h->table_cap);
     }
     return fail(KMC_E_STATE, "fingerprint %016llx not in table", (unsigned long long)fp);
 }

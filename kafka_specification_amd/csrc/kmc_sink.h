@@ -136,7 +136,7 @@ template <class M> struct KmcSink {
     static constexpr int W = M::W;
 
     // probe/insert fp; returns true when this lane claimed the slot (the state is new)
-    static KMC_DEV bool claim(const KmcArgsLocal& a, u64 fp, u64 meta) { return claim_from(a, fp, fp & a.table_mask, meta); }
+    static KMC_DEV bool claim(const KmcArgsLocal& a, u64 fp, u64 meta) { return claim_from(a, fp, kmc_slot_of(fp, a.table_cap), meta); }
 
     // The same with 16-byte slots (KMC_FLAG_FP128): word 0 is the fingerprint and is claimed exactly as above; word 1 is a
     // second, independent 64-bit hash of the state, published by the claimer right after its CAS.  Both words sit in the same
@@ -147,48 +147,35 @@ template <class M> struct KmcSink {
     // (an atomic, like the claim itself) until it appears; the claimer's store precedes every wait in program order, so two
     // lanes of one wave cannot wait on each other.
     static KMC_DEV bool claim_wide(const KmcArgsLocal& a, u64 fp, u64 chk, u64 meta) {
-        u64 i = fp & a.table_mask;
-        const u64 max_probes = a.table_mask < (1ull << 10) ? a.table_mask : (1ull << 10);
-        // (the first step looks at ONE slot, every further step at KMC_PROBE_AHEAD consecutive ones — loaded together, judged in
-        // order: claim_from)
-        for (u64 probes = 0; probes <= max_probes;) {
-            const int n = probes == 0 ? 1 : KMC_PROBE_AHEAD;
-            KmcSlot2 vv[KMC_PROBE_AHEAD];
-#pragma unroll
-            for (int k = 0; k < KMC_PROBE_AHEAD; ++k)
-                if (k < n) vv[k] = *(const KmcSlot2*)(a.table + 2 * ((i + (u64)k) & a.table_mask));   // one 16-byte load each
-#pragma unroll
-            for (int k = 0; k < KMC_PROBE_AHEAD; ++k) {
-                if (k >= n) break;
-                const u64 ik = (i + (u64)k) & a.table_mask;
-                u64* slot = a.table + 2 * ik;
-                u64 v0 = vv[k].x, v1 = vv[k].y;
-                bool mine = false;
-                if (v0 == 0) {
-                    v0 = atomicCAS(slot, 0ull, fp);
-                    mine = v0 == 0;
-                    v1 = 0;  // somebody else's claim: its check word must be (re)read
-                }
-                // The publication sits HERE, in the straight-line body of the step and ahead of every wait below.  Written
-                // as "store; return true" inside the branch above it ended up in the loop's exit block, which a wave only
-                // executes once all its lanes have left the loop — and a lane of the same wave waiting for this very check
-                // word never leaves: the first -fp128 run of the headline hung in exactly that way (bounded, so it reported
-                // KMC_ERR_CHECK_WORD at level 3).  (With several slots per step the order still holds: a lane that claims at
-                // position k of its step publishes before any lane reaches a wait of position k or later.)
-                if (mine) {
-                    __hip_atomic_store(slot + 1, chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (a.pred) a.pred[ik] = meta;
-                }
-                const bool wait = !mine && v0 == fp;
-                if (wait) {
-                    for (u32 spins = 0; v1 == 0 && spins <= (1u << 16); ++spins) v1 = atomicOr(slot + 1, 0ull);
-                    if (v1 == 0) atomicOr(&a.ctl->err, KMC_ERR_CHECK_WORD);
-                }
-                if (mine) return true;
-                if (wait && (v1 == chk || v1 == 0)) return false;
+        u64 i = kmc_slot_of(fp, a.table_cap);
+        const u64 max_probes = a.table_cap - 1 < (1ull << 10) ? a.table_cap - 1 : (1ull << 10);
+        for (u64 probes = 0; probes <= max_probes; ++probes) {
+            u64* slot = a.table + 2 * i;
+            const KmcSlot2 v = *(const KmcSlot2*)slot;   // one 16-byte load
+            u64 v0 = v.x, v1 = v.y;
+            bool mine = false;
+            if (v0 == 0) {
+                v0 = atomicCAS(slot, 0ull, fp);
+                mine = v0 == 0;
+                v1 = 0;  // somebody else's claim: its check word must be (re)read
             }
-            i = (i + (u64)n) & a.table_mask;
-            probes += (u64)n;
+            // The publication sits HERE, in the straight-line body of the iteration and ahead of every wait below.  Written
+            // as "store; return true" inside the branch above it ended up in the loop's exit block, which a wave only
+            // executes once all its lanes have left the loop — and a lane of the same wave waiting for this very check
+            // word never leaves: the first -fp128 run of the headline hung in exactly that way (bounded, so it reported
+            // KMC_ERR_CHECK_WORD at level 3).
+            if (mine) {
+                __hip_atomic_store(slot + 1, chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.pred) a.pred[i] = meta;
+            }
+            const bool wait = !mine && v0 == fp;
+            if (wait) {
+                for (u32 spins = 0; v1 == 0 && spins <= (1u << 16); ++spins) v1 = atomicOr(slot + 1, 0ull);
+                if (v1 == 0) atomicOr(&a.ctl->err, KMC_ERR_CHECK_WORD);
+            }
+            if (mine) return true;
+            if (wait && (v1 == chk || v1 == 0)) return false;
+            i = kmc_slot_next(i, a.table_cap);
         }
         atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
         return false;
@@ -199,44 +186,24 @@ template <class M> struct KmcSink {
         // The probe chain is bounded: a table filled beyond ~95 % makes linear probing walk millions
         // of slots per insert (a run that looked hung), so a chain this long is reported as
         // "table full" instead.  At load <= 0.9 the chance of a 1 K chain is nil.
-        //
-        // A chain is walked KMC_PROBE_AHEAD slots per round trip from its second step on (round 6).  A wave leaves this loop
-        // when its LAST lane does: at load 0.6 - 0.75 — the second half of the 6.45 G-state stretch in a 2^33-slot table — an
-        // unsuccessful lookup walks 4 - 8 slots on average, the slowest of 64 lanes three times that, one dependent memory
-        // round trip each with ever fewer lanes busy: the stretch's probe rate fell from 34 G/s at load 0.03 to 8 G/s at 0.74
-        // with the footprint's own ceiling unchanged (profiles/r06_stretch.txt).  The slots of one step are loaded together (a
-        // stale value is as good as a fresh one for the reason above) and judged in chain order, so the result is the
-        // sequential walk's.  The first step stays ONE slot: at the headline's load it settles 90 % of the probes, and a second
-        // line fetched for nothing would cost the run its ceiling.
-        const u64 max_probes = a.table_mask < (1ull << 10) ? a.table_mask : (1ull << 10);
-        for (u64 probes = 0; probes <= max_probes;) {
-            const int n = probes == 0 ? 1 : KMC_PROBE_AHEAD;
-            u64 vv[KMC_PROBE_AHEAD];
-#pragma unroll
-            for (int k = 0; k < KMC_PROBE_AHEAD; ++k)
-                if (k < n) vv[k] = a.table[(i + (u64)k) & a.table_mask];
-#pragma unroll
-            for (int k = 0; k < KMC_PROBE_AHEAD; ++k) {
-                if (k >= n) break;
-                const u64 ik = (i + (u64)k) & a.table_mask;
-                u64 v = vv[k];
-                if (v == 0) {
+        const u64 max_probes = a.table_cap - 1 < (1ull << 10) ? a.table_cap - 1 : (1ull << 10);
+        for (u64 probes = 0; probes <= max_probes; ++probes) {
+            u64 v = a.table[i];
+            if (v == 0) {
 #if KMC_TUNING
-                    if (a.flags & KMC_FLAG_X_PLAINSTORE) {
-                        a.table[ik] = fp;
-                        return true;
-                    }
-#endif
-                    v = atomicCAS(&a.table[ik], 0ull, fp);
-                    if (v == 0) {
-                        if (a.pred) a.pred[ik] = meta;
-                        return true;
-                    }
+                if (a.flags & KMC_FLAG_X_PLAINSTORE) {
+                    a.table[i] = fp;
+                    return true;
                 }
-                if (v == fp) return false;
+#endif
+                v = atomicCAS(&a.table[i], 0ull, fp);
+                if (v == 0) {
+                    if (a.pred) a.pred[i] = meta;
+                    return true;
+                }
             }
-            i = (i + (u64)n) & a.table_mask;
-            probes += (u64)n;
+            if (v == fp) return false;
+            i = kmc_slot_next(i, a.table_cap);
         }
         atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
         return false;
@@ -254,7 +221,7 @@ template <class M> struct KmcSink {
             }
         }
         if (v == fp) return false;
-        return claim_from(a, fp, (i + 1) & a.table_mask, meta);
+        return claim_from(a, fp, kmc_slot_next(i, a.table_cap), meta);
     }
 
     // the narrow or the wide table, as the handle was opened (a wave-uniform branch); the check word is the same
@@ -329,14 +296,14 @@ template <class M> struct KmcSink {
         if constexpr (MODE == KMC_MODE_DRY) {
             u64 acc = fp;
             if (valid && (a.flags & KMC_FLAG_DRY_RAND)) {  // ONE load from an unrelated random slot per successor
-                acc ^= a.table[kmc_mix64(fp ^ 0xABCDEF12345ull) & a.table_mask];
+                acc ^= a.table[kmc_slot_of(kmc_mix64(fp ^ 0xABCDEF12345ull), a.table_cap)];
             } else if (valid && (a.flags & KMC_FLAG_DRY_PROBE)) {  // read-only probe sequence (the table is already full)
-                u64 i = fp & a.table_mask;
-                for (u64 probes = 0; probes <= a.table_mask; ++probes) {
+                u64 i = kmc_slot_of(fp, a.table_cap);
+                for (u64 probes = 0; probes < a.table_cap; ++probes) {
                     const u64 v = a.table[i];
                     acc ^= v;
                     if (v == fp || v == 0) break;
-                    i = (i + 1) & a.table_mask;
+                    i = kmc_slot_next(i, a.table_cap);
                 }
                 if (a.flags & KMC_FLAG_DRY_INV) acc ^= M::violated(t, a.inv_mask);
                 // ~35 % of the probes end in a no-op CAS on the slot they found: the same atomic

@@ -387,3 +387,48 @@ def test_deferred_probe_load_is_issued_at_the_defer_point(tmp_path):
         return 0, 0
     gaps = [gap(i) for i in cas]
     assert any(g > 200 and w > 0 for g, w in gaps), gaps
+
+
+def test_a_seen_set_of_any_multiple_of_64_slots_every_slot_reachable_and_evenly_loaded(tmp_path):
+    """kmc_slot_of / kmc_slot_next (csrc/kmc_common.h): the home slot of a fingerprint in a table of ANY multiple of 64 slots — what
+    lets the 6.45 G-state stretch use 192 GiB instead of the 128 GiB power of two — compiled for the host: always below the
+    capacity, the low six bits are the fingerprint's, the 64-slot groups are hit evenly (also by the fingerprints ONE shard owns:
+    the owner is chosen by other bits), and the chain wraps at the capacity."""
+    import subprocess
+    src = tmp_path / "slot.cpp"
+    src.write_text(r'''
+#define KMC_HOST_EMU 1
+#include "kmc_common.h"
+#include <cstdio>
+#include <vector>
+int main() {
+    const unsigned long long caps[] = {1024ull, 1088ull, 1ull << 20, 12500000000ull / 64 * 64, 1ull << 34, (1ull << 38) - 64};
+    unsigned long long x = 0x9E3779B97F4A7C15ull;
+    for (unsigned long long cap : caps) {
+        const unsigned long long groups = cap >> 6, buckets = groups < 997 ? groups : 997;
+        std::vector<unsigned long long> hist(buckets, 0), hist_shard(buckets, 0);
+        unsigned long long n_shard = 0;
+        for (int k = 0; k < 2000000; ++k) {
+            x = kmc_mix64(x + 0x9E3779B97F4A7C15ull);
+            const unsigned long long fp = x ? x : 1, i = kmc_slot_of(fp, cap);
+            if (i >= cap || (i & 63) != (fp & 63)) { printf("BAD slot %llu of %llu\n", i, cap); return 1; }
+            hist[(unsigned long long)((__uint128_t)(i >> 6) * buckets / groups)]++;
+            if (kmc_owner(fp, 8) == 3) { hist_shard[(unsigned long long)((__uint128_t)(i >> 6) * buckets / groups)]++; ++n_shard; }
+        }
+        for (unsigned long long b = 0; b < buckets; ++b) {
+            const double want = 2000000.0 / buckets, got = (double)hist[b], wants = (double)n_shard / buckets, gots = (double)hist_shard[b];
+            if (got < 0.8 * want || got > 1.2 * want || gots < 0.6 * wants || gots > 1.4 * wants) {
+                printf("UNEVEN cap %llu bucket %llu: %.0f of %.0f, shard 3 of 8: %.0f of %.0f\n", cap, b, got, want, gots, wants);
+                return 1;
+            }
+        }
+        if (kmc_slot_next(cap - 1, cap) != 0 || kmc_slot_next(5, cap) != 6) { printf("BAD wrap\n"); return 1; }
+    }
+    printf("ok\n");
+    return 0;
+}
+''')
+    exe = tmp_path / "slot"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "kafka_specification_amd", "csrc"), "-o", str(exe), str(src)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout
