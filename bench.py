@@ -288,7 +288,7 @@ def run_single(c, steps, warmup, symmetry=False, table=None, frontier=None):
     import kafka_specification_amd as kmc
     # (under symmetry the seen-set and the frontiers hold one state per orbit: a quarter of the slots keeps the same load)
     cfg = kmc.CheckerConfig(**c, device=0, symmetry=symmetry,
-                            table_capacity=int(os.environ.get("KMC_BENCH_TABLE", table or ((1 << 28) if symmetry else (1 << 30)))),
+                            table_capacity=int(os.environ.get("KMC_BENCH_TABLE", table or ((3 << 27) if symmetry else (1 << 30)))),
                             frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", frontier or ((1 << 24) if symmetry else (1 << 26)))),
                             wide_fingerprint=os.environ.get("KMC_BENCH_FP128", "0") == "1")   # tuning: 128-bit entries
     results = []
@@ -334,9 +334,9 @@ BASELINE_LEGS = {
     "config5_kip320_7brokers_levels10": dict(
         c=dict(model="Kip320", n_replicas=7, log_size=8, max_records=8, max_leader_epoch=3,
                invariants=("TypeOk", "WeakIsr", "StrongIsr"), max_levels=10),
-        # (table: 2^30 slots = load 0.18 at the tenth level.  Round 5 ran it at 2^31: 2.8 ms of every 35 ms step went into
-        # clearing 16 GiB for 197 M states; profiles/r06_config5.txt holds the A/B)
-        table=int(os.environ.get("KMC_BENCH_TABLE5", 1 << 30)), frontier=1 << 29, cpu_states=5_000_000),
+        # (table: 1.75 x 2^30 slots — any multiple of 64 since round 6 — where k_expand + the clear of the table is smallest:
+        # 2^31 as in round 5 pays 2.8 ms of clear, 2^30 pays 2 ms of longer probe chains; profiles/r06_config5.txt holds the A/B)
+        table=int(os.environ.get("KMC_BENCH_TABLE5", 7 << 28)), frontier=1 << 29, cpu_states=40_000_000),
 }
 
 
@@ -422,16 +422,18 @@ STRETCH = dict(model="Kip320", n_replicas=3, log_size=6, max_records=6, max_lead
 def stretch_1gpu_leg():
     """The one exhaustible workload that needs the HBM north_star talks about, on ONE GPU, in the driver's own run: Kip320 3/6/6/3
     (Kip320.tla:150-159 with MaxLeaderEpoch = 3, KafkaReplication.tla:36) — 6,452,700,520 distinct states, 20.76 G generated, 54
-    levels — with 128-bit seen-set entries (2^33 slots of 16 bytes = 128 GiB; the 64-bit table loses one state to the collision
-    n^2 / 2^65 = 1.1 predicts) and two frontiers of 2^30 states (48 GiB).  One search, counts held level by level to Oracle-O's exact
+    levels — with 128-bit seen-set entries (the 64-bit table loses one state to the collision n^2 / 2^65 = 1.1 predicts) in a table
+    sized to the HBM there is: 15 G slots of 16 bytes = 224 GiB, load 0.43 at the end (the largest power of two that fits, 2^33 =
+    128 GiB, ends at load 0.75 and takes 1.22 s instead of 0.82: profiles/r06_stretch.txt), and two frontiers of 6.0e8 states (27 GiB;
+    the widest level holds 521,281,965).  One search, counts held level by level to Oracle-O's exact
     fixture (tests/golden/orbit_kip320_3_6_6_3.json: no fingerprint anywhere).  Roofline: unit = distinct state, algorithmic bytes
     A = 2*S + 16*g + 16 (the probe reads a 16-byte entry, the claim writes one).  Never part of `value`."""
     import kafka_specification_amd as kmc
     c = dict(STRETCH)
     try:
         cfg = kmc.CheckerConfig(**c, device=0, wide_fingerprint=True,
-                                table_capacity=int(os.environ.get("KMC_BENCH_STRETCH_TABLE", 1 << 33)),
-                                frontier_capacity=int(os.environ.get("KMC_BENCH_STRETCH_FRONTIER", 1 << 30)))
+                                table_capacity=int(os.environ.get("KMC_BENCH_STRETCH_TABLE", 15_000_000_000)),
+                                frontier_capacity=int(os.environ.get("KMC_BENCH_STRETCH_FRONTIER", 600_000_000)))
         t_open = time.perf_counter()
         with kmc.ModelChecker(cfg) as mc:
             open_s = time.perf_counter() - t_open

@@ -89,7 +89,7 @@ typedef unsigned int u32;
                                           // slower everywhere (headline 38.9 ms against 31.8, config 5's first ten levels 61
                                           // against 29: profiles/r03_runtime_guards.txt) — the block shares its sub-terms
                                           // across instances, a loop cannot.  KMC_VERIFY's second build sets it to 0: its
-                                          // guards are then a second, independent lowering (kmc_engine.cpp)
+                                          // guards are then a second, independent lowering (kmc_engine_internal.h)
 #endif
 #ifndef KMC_FULL_LEAVES_MIN_INSTANCES
 #define KMC_FULL_LEAVES_MIN_INSTANCES 200     // orbit counting on Kafka configurations with at least this many action instances

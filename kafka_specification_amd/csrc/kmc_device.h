@@ -33,7 +33,7 @@
 // not part of /root/reference].
 //
 // The source is split into parts (each cites the spec text it lowers): kmc_common.h, kmc_models_small.h, kmc_kafka.h,
-// kmc_symm.h, kmc_sink.h, kmc_kernels.h.  gen_sources.py embeds them in this order; kmc_engine.cpp concatenates them for hiprtc.
+// kmc_symm.h, kmc_sink.h, kmc_kernels.h.  gen_sources.py embeds them in this order; kmc_engine_codeobj.cpp concatenates them for hiprtc.
 #pragma once
 #include "kmc_common.h"
 #include "kmc_models_small.h"

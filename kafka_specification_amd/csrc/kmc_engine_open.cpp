@@ -232,6 +232,8 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     h->fcap = fcap;
     h->seg_cap = fcap / KMC_SEGS;
     if (hipMalloc(&h->table, tcap * h->slot_words * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate %llu table slots", (unsigned long long)tcap);
+    if (getenv("KMC_VERBOSE"))
+        fprintf(stderr, "[kmc] seen-set: %llu slots x %llu B at %p\n", (unsigned long long)tcap, (unsigned long long)(h->slot_words * 8), (void*)h->table);
     if (cfg->keep_trace && hipMalloc(&h->pred, tcap * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate predecessor table");
     for (int i = 0; i < 2; ++i)
         if (hipMalloc(&h->frontier[i], fcap * 8ull * h->planes) != hipSuccess)

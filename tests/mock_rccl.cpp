@@ -3,7 +3,7 @@
 // tests/mock_rccl_selfcheck.cpp load it through KMC_RCCL_LIB); nothing under kafka_specification_amd/ refers to it.
 //
 // Why it exists: RCCL refuses two ranks on one device and a gpurun box has one GPU, so the exchange under the C ABI
-// (csrc/kmc_engine.cpp: kmc_comm_init / kmc_comm_selftest / kmc_step_exchange_counts / kmc_step_exchange_payload) could
+// (csrc/kmc_engine_exchange.cpp: kmc_comm_init / kmc_comm_selftest / kmc_step_exchange_counts / kmc_step_exchange_payload) could
 // only ever run with world size 1, where it returns before any collective.  With this library in RCCL's place the very same
 // code runs with P > 1 concurrent ranks: the all-gather row layout, the posting order of the grouped sends and receives,
 // their offsets into the send and receive areas, the 1 GiB cuts, the k_insert queued behind the receives.  What stays

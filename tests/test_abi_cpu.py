@@ -262,7 +262,7 @@ def test_async_isr_pack_unpack_property_random_fields():
 
 
 def test_no_cached_expand_kernel_spills_vector_registers():
-    """The register budget follows the kernel (kmc_engine.cpp, get_code_object): k_expand is recompiled
+    """The register budget follows the kernel (kmc_engine_codeobj.cpp, get_code_object): k_expand is recompiled
     with fewer waves per SIMD until it spills at most 8 VGPRs.  At 184 spilled VGPRs the 7-replica Kip320
     kernel lost successors, so every code object the build step cached is checked here."""
     import glob

@@ -194,3 +194,37 @@ def test_one_code_object_whoever_compiles():
         assert p.returncode == 0, p.stderr[-800:]
         outs.append(p.stdout.strip().splitlines()[-2:])
     assert outs[0] == outs[1]
+
+
+def test_every_leg_of_the_bench_line_has_its_exact_fixture_and_its_constants_compile(bench):
+    """The driver's line holds BASELINE configs 4 (at two sizings) and 5 and the 6.45 G-state stretch beside the headline: each leg's
+    binding has a committed exact fixture (so `matches_oracle_golden` is never null there) whose level sizes it is held to."""
+    from kafka_specification_amd import CheckerConfig
+    for name, spec in bench.BASELINE_LEGS.items():
+        c = dict(spec["c"])
+        CheckerConfig(**c).to_native()
+        exp = bench.expected_counts(c)
+        assert exp is not None and exp["levels"] and sum(exp["levels"]) == exp["distinct"], name
+        if c.get("max_levels"):
+            assert len(exp["levels"]) == c["max_levels"] == exp["depth"], name
+        assert spec["table"] % 64 == 0 and spec["table"] * 0.5 > exp["distinct"] * 0.3     # (a load the leg's A/B chose, below 0.6)
+    exp = bench.expected_counts(dict(bench.STRETCH))
+    assert exp and exp["distinct"] == 6452700520 and exp["depth"] == 54 and exp["file"].endswith("orbit_kip320_3_6_6_3.json")
+    deep = bench.BASELINE_LEGS["config4_deep_kip279_5brokers_log4_levels12"]["c"]
+    assert (deep["n_replicas"], deep["log_size"], deep["max_records"], deep["max_leader_epoch"]) == (5, 4, 4, 3)   # SURVEY 8(a.0)'s sizing
+
+
+def test_the_stretch_leg_is_read_against_the_microbenchmark_of_its_own_footprint(bench):
+    """profiles/rNN_randbench_sweep.txt holds randbench at 2^33 eight-byte slots (64 GiB) and beyond: the ceiling the stretch leg's
+    probe rate is divided by is the one measured AT that footprint, not the 8 GiB figure (missing 4)."""
+    rates, src = bench.randbench_rates_at(33)
+    assert src and src.endswith("randbench_sweep.txt")
+    assert 40e9 < rates[1] < 60e9 and 25e9 < rates[13] < 40e9 and 25e9 < rates[7] < 40e9
+    r30, _ = bench.randbench_rates_at(30)
+    assert r30 and abs(r30[1] / rates[1] - 1.0) < 0.1          # random loads: the same rate at 8 GiB and at 64 GiB
+    assert bench.randbench_rates_at(12) == ({}, None)
+
+
+def test_step_breakdown_accounts_for_the_whole_step(bench):
+    b = bench.step_breakdown(31.4, 25.8e-3, 2.4e-3, 2.78e-3)
+    assert abs(sum(b.values()) - 31.4) < 1e-9 and b["k_inv_ms"] == pytest.approx(2.4) and b["host_and_rest_ms"] == pytest.approx(0.42)

@@ -81,7 +81,7 @@ def test_frontier_and_table_overflow_are_reported():
 @pytest.mark.parametrize("model,N,L,R,E", [("KafkaTruncateToHighWatermark", 3, 2, 2, 2), ("Kip101", 3, 3, 2, 2),
                                            ("Kip279", 3, 2, 3, 1), ("Kip320", 3, 3, 3, 1),
                                            ("Kip320FirstTry", 3, 2, 2, 2), ("Kip320", 4, 2, 1, 1),
-                                           # wide kernels: the register budget follows the kernel (kmc_engine.cpp,
+                                           # wide kernels: the register budget follows the kernel (kmc_engine_codeobj.cpp,
                                            # get_code_object) after Kip320 with 7 replicas lost successors at 80 VGPRs
                                            ("Kip320", 7, 1, 1, 0), ("Kip279", 7, 1, 1, 0),
                                            ("Kip320FirstTry", 8, 1, 1, 0)])

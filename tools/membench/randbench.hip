@@ -103,6 +103,12 @@ int main(int argc, char** argv) {
     if (const char* ms = getenv("RANDBENCH_MODES"))
         for (const char* p = ms; *p;) { const int m = atoi(p); if (m >= 0 && m < 14) want[m] = true; while (*p && *p != ',') ++p; if (*p) ++p; }
     u64 *raw, *table, *sink;
+    // RANDBENCH_SKIP=K: K allocations of the same size are made (and kept) first, so that the table lands elsewhere in the HBM
+    // (round 6: does WHERE an 8 GiB table lies change its rate?  The headline's kernel differs by 5 - 8 % from process to process)
+    for (int k = 0; k < (getenv("RANDBENCH_SKIP") ? atoi(getenv("RANDBENCH_SKIP")) : 0); ++k) {
+        u64* other;
+        if (hipMalloc(&other, max_slots * 8) != hipSuccess) { printf("hipMalloc %d failed\n", k); return 1; }
+    }
     if (hipMalloc(&raw, max_slots * 8 + (align_gib ? (1ull << 30) : 0)) != hipSuccess) { printf("hipMalloc of 2^%d slots failed\n", max_log2); return 1; }
     table = align_gib ? (u64*)(((unsigned long long)raw + (1ull << 30) - 1) & ~((1ull << 30) - 1)) : raw;
     hipMalloc(&sink, 8);
