@@ -117,6 +117,7 @@ typedef unsigned int u32;
 #define KMC_FLAG_X_NOSTAGE 32u    // tuning (shadow pass only): winners are not appended
 #define KMC_FLAG_X_NOINV 64u      // tuning: skip invariants
 #define KMC_FLAG_X_PLAINSTORE 128u  // tuning: claim with a plain store instead of atomicCAS (racy, timing only)
+#define KMC_FLAG_X_NOWALK 2048u   // tuning (shadow pass only, with X_PLAINSTORE): a probe chain ends at its first slot — occupied by anything = seen
 #define KMC_FLAG_DRY_RAND 256u  // tuning: DRY mode does one load from an uncorrelated random table slot
 #define KMC_FLAG_ENUM_MATCH 512u  // ENUM lists only the successors whose fingerprint is KmcArgs::match_fp, with their parent's fp
 #define KMC_FLAG_META 2u  // the ring carries a meta plane (predecessor fp for traces / kind for ENUM)
@@ -307,11 +308,17 @@ KMC_DEV void kmc_launder(u32& x) { KMC_OPAQUE(x); }
 KMC_DEV void kmc_launder(u64& x) { KMC_OPAQUE(x); }
 
 // 64-bit fingerprint of a packed state.  Never 0 (0 marks an empty table slot).
-// Every state word is absorbed through a full-avalanche bijection (the splitmix64 / murmur3
-// finaliser: two multiplies, three xor-shifts).  A single multiply + xor-shift per word is NOT
-// enough here: packed states are highly structured, differences that survive one weak round
-// line up with differences in the next word and produce systematic collisions (seen as 32
-// missing states out of 75,569,791 on Kip320 3/5/5/2).
+// States of up to KMC_FOLD_MIN_WORDS - 1 words: every word is absorbed through a full-avalanche bijection (the splitmix64 /
+// murmur3 finaliser: two multiplies, three xor-shifts).  A single multiply + xor-shift per word is NOT enough here: packed states
+// are highly structured, differences that survive one weak round line up with differences in the next word and produce
+// systematic collisions (seen as 32 missing states out of 75,569,791 on Kip320 3/5/5/2).
+// Wider states (seven brokers with deep logs: ten words) absorb TWO words per 64 x 64 -> 128-bit multiply, high half folded onto
+// low (the multiply-fold of wyhash: the two words multiply each other, every input bit reaches both halves of the product), and
+// pass through one finaliser at the end: a third of the per-word chain's multiplies.  The fingerprint of a ten-word state was ~250
+// of a flush's vector instructions, 13.5 times per tile — a quarter of BASELINE config 5's kernel: 26.6 -> 25.2 ms on one box,
+// every count equal to the exact fixtures (profiles/r06_fingerprint.txt).  Its quality on real states — 20 M reachable ten-word
+// states, collisions in 32 / 36 / 40-bit windows of the fingerprint AND of the chain before its finaliser against the birthday
+// expectation, three seeds: ratios 0.97 - 1.03 everywhere, as for the per-word chain — is tools/fp_quality/.
 KMC_HD inline u64 kmc_mix64(u64 x) {
     x ^= x >> 30;
     x *= 0xbf58476d1ce4e5b9ull;
@@ -320,10 +327,27 @@ KMC_HD inline u64 kmc_mix64(u64 x) {
     x ^= x >> 31;
     return x;
 }
+#ifndef KMC_FOLD_MIN_WORDS
+#define KMC_FOLD_MIN_WORDS 8   // (part of what a checkpoint's fingerprints mean: kmc_engine_step.cpp's magic)
+#endif
+// the 128-bit product of a and b, high half xor low half
+KMC_HD inline u64 kmc_mum(u64 a, u64 b) {
+    const unsigned __int128 p = (unsigned __int128)a * (unsigned __int128)b;
+    return (u64)p ^ (u64)(p >> 64);
+}
 template <int W> KMC_HD inline u64 kmc_fingerprint(const u64* w, u64 seed) {
     u64 h = kmc_mix64(seed + 0x9E3779B97F4A7C15ull * (u64)(W + 1));
+    if constexpr (W >= KMC_FOLD_MIN_WORDS) {
+        // (a word equal to the first constant would blind its partner: packed states leave their top bits clear, the constant
+        // does not; the second operand carries the running hash)
 #pragma unroll
-    for (int k = 0; k < W; ++k) h = kmc_mix64(h ^ w[k]) + 0x9E3779B97F4A7C15ull;
+        for (int k = 0; k + 1 < W; k += 2) h = kmc_mum(w[k] ^ 0xe7037ed1a0b428dbull, w[k + 1] ^ h) + 0x9E3779B97F4A7C15ull;
+        if constexpr ((W & 1) != 0) h = kmc_mum(w[W - 1] ^ 0xe7037ed1a0b428dbull, h ^ 0x8ebc6af09c88c6e3ull);
+        h = kmc_mix64(h);
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) h = kmc_mix64(h ^ w[k]) + 0x9E3779B97F4A7C15ull;
+    }
     return h ? h : 1ull;
 }
 // The home slot of a fingerprint in a seen-set of `cap` slots — any multiple of 64, so that a table can be sized to the HBM it has

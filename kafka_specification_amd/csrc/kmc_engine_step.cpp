@@ -7,7 +7,10 @@ using namespace kmc_engine;
 // predecessor table when traces are kept) and the current frontier's planes, segment by segment.
 namespace {
 struct CkptHeader {
-    char magic[8];          // "KMCCKPT5" (4: before round 5 changed the representative at four replicas; before canon_form)
+    char magic[8];          // "KMCCKPT6" (4: before round 5 changed the representative at four replicas; before canon_form.  5: before
+                            // round 6 changed what a stored fingerprint MEANS — its home slot, kmc_slot_of, and for states of eight
+                            // words and more the fingerprint itself, kmc_fingerprint: an older table would be searched in the wrong
+                            // places and the resumed search would claim its states a second time)
     kmc_config cfg;         // pointers inside are not meaningful in the file
     uint64_t table_cap, fcap, seg_cap, level, n_cur, n_levels, w, has_pred;
     uint64_t layout_form;   // KmcLayout::rm of the packed states in the file (0 tight, 1 / 2 replica-major): the same constants
@@ -64,7 +67,7 @@ int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     FILE* f = fopen(path, "wb");
     if (!f) return fail(KMC_E_ARG, "cannot open %s for writing", path);
     CkptHeader hd{};
-    memcpy(hd.magic, "KMCCKPT5", 8);
+    memcpy(hd.magic, "KMCCKPT6", 8);
     hd.cfg = h->cfg;
     hd.cfg.cache_dir = nullptr;
     hd.table_cap = h->table_cap; hd.fcap = h->fcap; hd.seg_cap = h->seg_cap; hd.level = h->level;
@@ -93,7 +96,7 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
     if (!f) return fail(KMC_E_ARG, "cannot open %s", path);
     CkptHeader hd{};
     int rc = KMC_OK;
-    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT5", 8) != 0)
+    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT6", 8) != 0)
         rc = fail(KMC_E_ARG, "%s is not a checkpoint of this version", path);
     const kmc_config& a = hd.cfg;
     const kmc_config& b = h->cfg;

@@ -135,8 +135,73 @@ struct alignas(16) KmcSlot2 { u64 x, y; };   // a wide seen-set slot: fingerprin
 template <class M> struct KmcSink {
     static constexpr int W = M::W;
 
-    // probe/insert fp; returns true when this lane claimed the slot (the state is new)
-    static KMC_DEV bool claim(const KmcArgsLocal& a, u64 fp, u64 meta) { return claim_from(a, fp, kmc_slot_of(fp, a.table_cap), meta); }
+    // ---- probe / claim -----------------------------------------------------------------------------------------------------
+    // Open addressing, linear probing.  Slots only ever change 0 -> fp, so a plain (possibly stale) load can only mis-report
+    // "empty", which the compare-and-swap then corrects.  The chain is bounded: a table filled beyond ~95 % makes linear probing
+    // walk millions of slots per insert (a run that looked hung), so a chain this long is reported as "table full" instead.  At
+    // load <= 0.9 the chance of a 1 K chain is nil.
+    //
+    // ONE ROUND TRIP PER STEP FOR EVERY LANE (round 6).  The textbook loop — load; where the slot read empty, compare-and-swap;
+    // walk on — is executed by a wave as the SUM of what its lanes need: the lanes whose slot read empty send their CAS while the
+    // lanes that must walk on wait, then those send their load while the claimers wait: three to five dependent round trips for
+    // a batch in which no lane needs more than two or three.  Here every step is one round trip in which each walking lane sends
+    // what IT needs next — the CAS of the slot it saw empty, or the load of its next slot — and the wave waits once for both
+    // (tests/test_abi_cpu.py::test_a_probe_step_sends_the_claims_and_the_next_loads_together reads the ISA).  v = what slot i
+    // held when the lane last looked; a lane whose CAS lost takes the claimer's fingerprint as its v — its own (a duplicate) or
+    // another's (walk on).  The memory traffic is the loop's, request for request.  Same box, loop -> steps (profiles/
+    // r06_probe_steps.txt): headline 31.8 -> 31.5 ms, config 5 26.2 -> 25.6, the 6.45 G-state stretch 0.683 -> 0.657 s (narrow).
+    //
+    // A step comes in two halves so that a caller can put other work between the requests and their answers.
+    static KMC_DEV void step_issue(const KmcArgsLocal& a, bool& active, u64 fp, u64& i, u64 v, bool& docas, u64& r_cas, u64& r_load) {
+        active = active && v != fp;                 // v == fp: the state is in the table
+        docas = active && v == 0;
+#if KMC_TUNING
+        const bool doload = active && v != 0 && !(a.flags & KMC_FLAG_X_NOWALK);
+        if (a.flags & KMC_FLAG_X_NOWALK) active = docas;
+#else
+        const bool doload = active && v != 0;
+#endif
+        if (doload) i = kmc_slot_next(i, a.table_cap);
+        r_cas = 1;
+        r_load = 0;
+        if (docas) {
+#if KMC_TUNING
+            if (a.flags & KMC_FLAG_X_PLAINSTORE) {
+                a.table[i] = fp;
+                r_cas = 0;
+            } else
+#endif
+            r_cas = atomicCAS(&a.table[i], 0ull, fp);
+        }
+        if (doload) r_load = a.table[i];
+    }
+    static KMC_DEV bool step_resolve(const KmcArgsLocal& a, bool& active, u64 i, u64 meta, bool docas, u64 r_cas, u64 r_load, u64& v) {
+        const bool won = docas && r_cas == 0;
+        if (won) {
+            active = false;
+            if (a.pred) a.pred[i] = meta;
+        }
+        v = docas ? r_cas : r_load;
+        return won;
+    }
+    // Walks the chain of fp from slot i, of which the lane has seen v (called by the whole wave; the lanes with active = false
+    // only take part in the ballots).  True when this lane claimed a slot: the state is new.
+    static KMC_DEV bool claim_steps(const KmcArgsLocal& a, bool active, u64 fp, u64 i, u64 v, u64 meta) {
+        bool won = false;
+        const u64 max_probes = a.table_cap - 1 < (1ull << 10) ? a.table_cap - 1 : (1ull << 10);
+        for (u64 steps = 0;; ++steps) {
+            if (__ballot(active && v != fp) == 0) break;
+            if (steps > 2 * max_probes + 2) {           // (a lane sends at most one load and one CAS per slot)
+                if (active && v != fp) atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
+                break;
+            }
+            bool docas;
+            u64 r_cas, r_load;
+            step_issue(a, active, fp, i, v, docas, r_cas, r_load);
+            won = step_resolve(a, active, i, meta, docas, r_cas, r_load, v) || won;
+        }
+        return won;
+    }
 
     // The same with 16-byte slots (KMC_FLAG_FP128): word 0 is the fingerprint and is claimed exactly as above; word 1 is a
     // second, independent 64-bit hash of the state, published by the claimer right after its CAS.  Both words sit in the same
@@ -144,91 +209,66 @@ template <class M> struct KmcSink {
     // fingerprint compares the check word: equal -> the same state; different -> a 64-bit collision between two distinct
     // states, which the narrow table would have lost — the probe goes on to the next slot.  A check word that is still 0
     // (the claimer has not published yet, or this XCD's L2 holds the line from before it did) is re-read at the memory side
-    // (an atomic, like the claim itself) until it appears; the claimer's store precedes every wait in program order, so two
-    // lanes of one wave cannot wait on each other.
-    static KMC_DEV bool claim_wide(const KmcArgsLocal& a, u64 fp, u64 chk, u64 meta) {
-        u64 i = kmc_slot_of(fp, a.table_cap);
+    // until it appears (rare: two lanes meeting on one new state within a microsecond; waited for inside the step).
+    // The publication sits in the straight-line body of the step, ahead of every wait of the same step: written as "store;
+    // return true" inside a branch it once ended up in the loop's exit block, which a wave only executes once all its lanes
+    // have left the loop — and a lane of the same wave waiting for this very check word never leaves: the first -fp128 run of
+    // the headline hung in exactly that way (bounded, so it reported KMC_ERR_CHECK_WORD at level 3).
+    // A lane's step is the CAS of the fingerprint word of the slot it saw empty, or the 16-byte load of its next slot.
+    static KMC_DEV bool claim_wide_steps(const KmcArgsLocal& a, bool active, u64 fp, u64 chk, u64 i, KmcSlot2 v, u64 meta) {
+        bool won = false;
+        bool walk = false;   // slot i is known to hold ANOTHER state with this fingerprint
         const u64 max_probes = a.table_cap - 1 < (1ull << 10) ? a.table_cap - 1 : (1ull << 10);
-        for (u64 probes = 0; probes <= max_probes; ++probes) {
-            u64* slot = a.table + 2 * i;
-            const KmcSlot2 v = *(const KmcSlot2*)slot;   // one 16-byte load
-            u64 v0 = v.x, v1 = v.y;
-            bool mine = false;
-            if (v0 == 0) {
-                v0 = atomicCAS(slot, 0ull, fp);
-                mine = v0 == 0;
-                v1 = 0;  // somebody else's claim: its check word must be (re)read
+        for (u64 steps = 0;; ++steps) {
+            // what the lane knows about slot i: v.x its fingerprint word, v.y its check word (0: not read yet / not published yet)
+            if (__ballot(active) == 0) break;
+            if (steps > 2 * max_probes + 2) {
+                if (active) atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
+                break;
             }
-            // The publication sits HERE, in the straight-line body of the iteration and ahead of every wait below.  Written
-            // as "store; return true" inside the branch above it ended up in the loop's exit block, which a wave only
-            // executes once all its lanes have left the loop — and a lane of the same wave waiting for this very check
-            // word never leaves: the first -fp128 run of the headline hung in exactly that way (bounded, so it reported
-            // KMC_ERR_CHECK_WORD at level 3).
-            if (mine) {
+            const bool docas = active && !walk && v.x == 0;
+            bool same = active && !walk && v.x == fp;   // the slot holds this fingerprint: the check word decides
+            const bool doload = active && !docas && !same;
+            walk = false;
+            if (doload) i = kmc_slot_next(i, a.table_cap);
+            u64* slot = a.table + 2 * i;
+            u64 r_cas = 1;
+            KmcSlot2 r_load = {0, 0};
+            if (docas) r_cas = atomicCAS(slot, 0ull, fp);
+            if (doload) r_load = *(const KmcSlot2*)slot;   // one 16-byte load
+            if (docas && r_cas == 0) {                  // mine: publish the check word before anybody of this wave waits for one
                 __hip_atomic_store(slot + 1, chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (a.pred) a.pred[i] = meta;
+                won = true;
+                active = false;
             }
-            const bool wait = !mine && v0 == fp;
-            if (wait) {
-                for (u32 spins = 0; v1 == 0 && spins <= (1u << 16); ++spins) v1 = atomicOr(slot + 1, 0ull);
-                if (v1 == 0) atomicOr(&a.ctl->err, KMC_ERR_CHECK_WORD);
+            if (docas && r_cas != 0) {                  // somebody else's claim: its check word must be (re)read
+                v.x = r_cas;
+                v.y = 0;
+                same = r_cas == fp;
             }
-            if (mine) return true;
-            if (wait && (v1 == chk || v1 == 0)) return false;
-            i = kmc_slot_next(i, a.table_cap);
+            if (doload) v = r_load;
+            if (same) {
+                u64 y = v.y;
+                for (u32 spins = 0; y == 0 && spins <= (1u << 16); ++spins) y = atomicOr(slot + 1, 0ull);
+                if (y == 0) atomicOr(&a.ctl->err, KMC_ERR_CHECK_WORD);
+                if (y == chk || y == 0) active = false;   // the same state
+                else walk = true;                         // a 64-bit collision between two states: walk on
+            }
         }
-        atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
-        return false;
-    }
-    static KMC_DEV bool claim_from(const KmcArgsLocal& a, u64 fp, u64 i, u64 meta) {
-        // open addressing, linear probing.  Slots only ever change 0 -> fp, so a plain
-        // (possibly stale) load can only mis-report "empty", which the CAS then corrects.
-        // The probe chain is bounded: a table filled beyond ~95 % makes linear probing walk millions
-        // of slots per insert (a run that looked hung), so a chain this long is reported as
-        // "table full" instead.  At load <= 0.9 the chance of a 1 K chain is nil.
-        const u64 max_probes = a.table_cap - 1 < (1ull << 10) ? a.table_cap - 1 : (1ull << 10);
-        for (u64 probes = 0; probes <= max_probes; ++probes) {
-            u64 v = a.table[i];
-            if (v == 0) {
-#if KMC_TUNING
-                if (a.flags & KMC_FLAG_X_PLAINSTORE) {
-                    a.table[i] = fp;
-                    return true;
-                }
-#endif
-                v = atomicCAS(&a.table[i], 0ull, fp);
-                if (v == 0) {
-                    if (a.pred) a.pred[i] = meta;
-                    return true;
-                }
-            }
-            if (v == fp) return false;
-            i = kmc_slot_next(i, a.table_cap);
-        }
-        atomicOr(&a.ctl->err, KMC_ERR_TABLE_FULL);
-        return false;
+        return won;
     }
 
-    // claim() for a successor whose FIRST probe was issued earlier (kmc_expand_body's deferred probe): v = what table[i] held
-    // then.  Slots only ever change 0 -> fp, so the old value is as good as a fresh one: a stale 0 is corrected by the CAS,
-    // anything else is still there.  Further steps of the chain, if any, probe as usual.
-    static KMC_DEV bool claim_loaded(const KmcArgsLocal& a, u64 fp, u64 i, u64 v, u64 meta) {
-        if (v == 0) {
-            v = atomicCAS(&a.table[i], 0ull, fp);
-            if (v == 0) {
-                if (a.pred) a.pred[i] = meta;
-                return true;
-            }
+    // The narrow or the wide table, as the handle was opened (a wave-uniform branch); the check word is the same fingerprint
+    // function under another seed.  Called by the whole wave: the lanes with valid = false only take part in the ballots.
+    static KMC_DEV bool claim_any(const KmcArgsLocal& a, bool valid, const u64* t, u64 fp, u64 meta) {
+        const u64 i = kmc_slot_of(fp, a.table_cap);
+        if (a.flags & KMC_FLAG_FP128) {
+            KmcSlot2 v = {0, 0};
+            if (valid) v = *(const KmcSlot2*)(a.table + 2 * i);
+            return claim_wide_steps(a, valid, fp, kmc_fingerprint<W>(t, a.seed ^ 0x6a09e667f3bcc908ull), i, v, meta);
         }
-        if (v == fp) return false;
-        return claim_from(a, fp, kmc_slot_next(i, a.table_cap), meta);
-    }
-
-    // the narrow or the wide table, as the handle was opened (a wave-uniform branch); the check word is the same
-    // fingerprint function under another seed
-    static KMC_DEV bool claim_any(const KmcArgsLocal& a, const u64* t, u64 fp, u64 meta) {
-        if (a.flags & KMC_FLAG_FP128) return claim_wide(a, fp, kmc_fingerprint<W>(t, a.seed ^ 0x6a09e667f3bcc908ull), meta);
-        return claim(a, fp, meta);
+        return claim_steps(a, valid, fp, i, valid ? a.table[i] : fp, meta);
     }
 
     // Sender-side duplicate filter of the sharded path: true when fp was not yet in `set` (and is now).
@@ -322,7 +362,7 @@ template <class M> struct KmcSink {
             // (Resolving the successors of one batch that share a fingerprint only once — a per-wave LDS lane map — and walking
             // a probe chain inside its 128-byte line before moving on were measured in round 3 and change nothing:
             // profiles/r03_probe_knobs.txt.)
-            const bool isnew = valid && claim_any(a, t, fp, meta);
+            const bool isnew = claim_any(a, valid, t, fp, meta);
 #if KMC_SYMM
             out.corr_won += isnew ? KmcSymm<M>::deficit(stab) : 0u;
 #endif
@@ -334,7 +374,7 @@ template <class M> struct KmcSink {
             // successors this shard owns take the local path at once (probe, claim, stage): only
             // the (P-1)/P that belong elsewhere travel
             const u32 dst = valid ? kmc_owner(fp, a.nshards) : ~0u;
-            const bool isnew = dst == a.shard && claim_any(a, t, fp, meta);
+            const bool isnew = claim_any(a, dst == a.shard, t, fp, meta);
 #if KMC_SYMM
             out.corr_won += isnew ? KmcSymm<M>::deficit(stab) : 0u;   // (remote successors are weighed where they are claimed: k_insert)
 #endif

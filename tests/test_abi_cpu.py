@@ -389,6 +389,30 @@ def test_deferred_probe_load_is_issued_at_the_defer_point(tmp_path):
     assert any(g > 200 and w > 0 for g, w in gaps), gaps
 
 
+def test_a_probe_step_sends_the_claims_and_the_next_loads_together(tmp_path):
+    """KmcSink::claim_steps (round 6): in one step of a wave's walk the lanes that saw an empty slot send their compare-and-swap
+    and the lanes that must walk on send the load of their next slot, and the wave waits ONCE for both.  Nothing in the language
+    says so — a `s_waitcnt vmcnt(0)` between the two requests would turn the step back into the textbook loop's two round
+    trips — so the ISA is read: in the search's kernel every probe-loop compare-and-swap is followed by a global load of a table
+    slot before the next wait on the vector-memory counter."""
+    import subprocess
+    cfg = CheckerConfig(model="Kip320", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1, cache_dir=str(tmp_path))
+    from kafka_specification_amd import code_object_path
+    path = code_object_path(cfg)
+    asm = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--no-show-raw-insn", path], capture_output=True, text=True,
+                         check=True).stdout
+    body = asm[asm.index("<kmc_expand_Kip320_N3_L2_R2_E1>:"):]
+    body = body[:body.index("\n\n", 10)] if "\n\n" in body[10:] else body
+    lines = [ln.split("//")[0].strip() for ln in body.splitlines()]
+    ins = [ln for ln in lines if ln and not ln.endswith(":") and not ln.startswith("<")]
+    cas = [i for i, o in enumerate(ins) if o.startswith("global_atomic_cmpswap")]
+    assert len(cas) >= 2, "the narrow and the wide walk each hold one compare-and-swap"
+    for i in cas:
+        nxt = next(j for j in range(i + 1, len(ins)) if ins[j].startswith("s_waitcnt") and "vmcnt" in ins[j])
+        between = [o.split()[0] for o in ins[i + 1:nxt]]
+        assert any(o.startswith("global_load_dwordx") for o in between), (ins[i], between)
+
+
 def test_a_seen_set_of_any_multiple_of_64_slots_every_slot_reachable_and_evenly_loaded(tmp_path):
     """kmc_slot_of / kmc_slot_next (csrc/kmc_common.h): the home slot of a fingerprint in a table of ANY multiple of 64 slots — what
     lets the 6.45 G-state stretch use 192 GiB instead of the 128 GiB power of two — compiled for the host: always below the
