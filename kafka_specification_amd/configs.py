@@ -172,6 +172,7 @@ SYMMETRY_KAFKA = [(m, N, L, R, E) for m in KAFKA
     # five and six replicas: the adjacent-transposition walk instead of unrolled permutations (BASELINE config 4 among them)
     ("Kip279", 5, 1, 1, 1), ("Kip320", 5, 1, 1, 1), ("KafkaTruncateToHighWatermark", 6, 1, 1, 1), ("Kip101", 5, 2, 1, 1),
     ("Kip279", 5, 2, 2, 1),
+    ("Kip279", 5, 4, 4, 3),   # config 4 at SURVEY's sizing: the per-state fixture under orbit counting (tests/test_gpu_oracle_r_successors.py)
     # seven replicas, BASELINE config 5 among them
     ("Kip320", 7, 1, 1, 0), ("Kip279", 7, 1, 1, 0), ("Kip320", 7, 8, 8, 3)]
 SYMMETRY_LAYOUTS = [("Kip320", 3, 2, 2, 2), ("Kip279", 3, 2, 2, 1), ("Kip101", 4, 2, 1, 1)]
