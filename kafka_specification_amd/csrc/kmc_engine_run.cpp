@@ -12,6 +12,27 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
     if (h->cfg.n_shards != 1) return fail(KMC_E_STATE, "kmc_run drives one GPU; use the kmc_step_* interface for shards");
     HIP_TRY(hipSetDevice(h->cfg.device));
     h->stepping = false;
+    if (const char* which = getenv("KMC_DEBUG_REALLOC")) {
+        // tuning aid (profiles/r06_table_size_and_placement.txt, item 3): ONE of the handle's buffers — table | f0 | f1 | ctl — is
+        // moved to another place in the HBM before this search; k_expand's time follows where the seen-set lies
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        auto move = [&](u64*& p, size_t bytes) -> int {
+            u64* q = nullptr;
+            void* pad = nullptr;
+            (void)hipMalloc(&pad, 768ull << 20);   // (leaked: shifts where the next buffers land)
+            if (hipMalloc(&q, bytes) != hipSuccess) return fail(KMC_E_NOMEM, "debug realloc");
+            HIP_TRY(hipMemcpy(q, p, bytes, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipFree(p));
+            p = q;
+            return KMC_OK;
+        };
+        int rc0 = KMC_OK;
+        if (!strcmp(which, "table")) rc0 = move(h->table, h->table_cap * h->slot_words * 8);
+        else if (!strcmp(which, "f0")) rc0 = move(h->frontier[0], h->fcap * 8ull * h->planes);
+        else if (!strcmp(which, "f1")) rc0 = move(h->frontier[1], h->fcap * 8ull * h->planes);
+        else if (!strcmp(which, "ctl")) { u64* c = (u64*)h->ctl; rc0 = move(c, KMC_CTL_SLOTS * sizeof(KmcLevelCtl)); h->ctl = (KmcLevelCtl*)c; }
+        if (rc0) return rc0;
+    }
     int rc = do_begin(h);
     if (rc) return rc;
     return run_levels(h, cb, user, true);
