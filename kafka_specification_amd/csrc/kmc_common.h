@@ -327,8 +327,15 @@ KMC_HD inline u64 kmc_mix64(u64 x) {
     x ^= x >> 31;
     return x;
 }
-#ifndef KMC_FOLD_MIN_WORDS
-#define KMC_FOLD_MIN_WORDS 8   // (part of what a checkpoint's fingerprints mean: kmc_engine_step.cpp's magic)
+// (The threshold is part of what a fingerprint MEANS — the host computes fingerprints with it for `contains`, traces, checkpoints
+// (kmc_engine_step.cpp's magic) and the owner of Init — so a device build cannot be given another one behind the host's back:
+// only the host-side tools (tools/fp_quality) and a tuning build's A/B, whose searches ask the host for no fingerprint, may.)
+#ifdef KMC_FOLD_MIN_WORDS
+#if !defined(KMC_HOST_EMU) && !KMC_TUNING
+#error "KMC_FOLD_MIN_WORDS is shared by host and device: only a tuning build (-DKMC_TUNING=1) may override it"
+#endif
+#else
+#define KMC_FOLD_MIN_WORDS 8
 #endif
 // the 128-bit product of a and b, high half xor low half
 KMC_HD inline u64 kmc_mum(u64 a, u64 b) {

@@ -323,6 +323,20 @@ def test_the_search_kernel_takes_its_own_argument_block_and_holds_no_other_mode(
     assert any(n.startswith("kmc_inv_") for n in names)
 
 
+@pytest.mark.parametrize("defines", ["-DKMC_PROFILE=1", "-DKMC_FAULT_DROP=1", "-DKMC_TEST_FP_BITS=10", "-DKMC_FOLD_MIN_WORDS=4"])
+def test_a_diagnostic_define_without_a_tuning_build_fails_loudly(tmp_path, monkeypatch, defines):
+    """csrc/kmc_common.h: the diagnostic switches only exist in a -DKMC_TUNING=1 build (a stale script asking for one
+    without it must not run a normal kernel under another cache key and pass vacuously), and the fingerprint's fold threshold is
+    shared with the host, which computes fingerprints for `contains`, traces and checkpoints: a device build cannot be given
+    another one behind its back.  Asked for plainly, each is a compile error, not a cached object."""
+    monkeypatch.setenv("KMC_JIT_DEFINES", defines)
+    cfg = CheckerConfig(model="Kip320", n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1, cache_dir=str(tmp_path))
+    with pytest.raises(KmcError) as e:
+        precompile(cfg, "gfx950", 0)
+    assert "tuning build" in str(e.value)
+    assert not any(f.endswith(".hsaco") for f in os.listdir(tmp_path))
+
+
 def test_the_cache_key_names_the_compiler_and_every_process_prefers_the_pinned_one(tmp_path, monkeypatch):
     """The code-object cache (csrc/kmc_engine_codeobj.cpp): the compiler's identity is part of the file name, a process bound to
     ANOTHER compiler loads the pinned compiler's object when the cache holds it (the bench under PyTorch's runtime and a rocprofv3
