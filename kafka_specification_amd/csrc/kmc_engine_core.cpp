@@ -62,6 +62,76 @@ int launch_inv(kmc_handle* h, const KmcArgs& a, uint64_t n) {
     return KMC_OK;
 }
 
+// The seen-set is NOT one hipMalloc.  Where a handle's table lies decides how fast its random probes are served: the headline's
+// k_expand ran at one of three discrete levels — 28.4 / 30.5 / 31.5 ms with a 12 GiB table, 30.6 / 31.6 with 8 GiB — that followed
+// the table's allocation and nothing else (one handle, only the table moved: all three levels; profiles/r06_table_size_and_
+// placement.txt), with a hipMalloc of several GiB being a few huge physically contiguous blocks.  Mapped from 8 MiB chunks (HIP's
+// virtual-memory API: one range of addresses, every chunk its own physical allocation) the same table runs at the fast level in
+// every handle of every process: headline 31.3 - 31.6 -> 28.5 ms, BASELINE config 4 18.6 -> 16.8, config 4 at SURVEY's sizing
+// 43.1 -> 38.7, config 5 25.6 -> 25.1 (it is bound by instructions), same box, interleaved, counts exact (profiles/r06_chunked_
+// seen_set.txt).  2 / 4 / 8 MiB chunks are alike, 32 MiB less steady, 1 - 2 GiB chunks behave like hipMalloc: what matters is the
+// size of the physically contiguous pieces (the translation hardware's handling of huge fragments is the suspect: user space
+// cannot see more).  The frontiers gain nothing from it (streams) and stay hipMalloc's.  KMC_SEEN_SET_CHUNK_LOG2 overrides the
+// chunk (0: one hipMalloc); any failure of the mapping falls back to hipMalloc.
+u64* seen_set_alloc(kmc_handle* h, size_t bytes) {
+    static const int lg = getenv("KMC_SEEN_SET_CHUNK_LOG2") ? atoi(getenv("KMC_SEEN_SET_CHUNK_LOG2")) : 23;
+    void* va = nullptr;
+    size_t total = 0, done = 0;
+    if (lg > 0) {
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = h->cfg.device;
+        size_t gran = 0;
+        bool ok = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0;
+        size_t chunk = (size_t)1 << (lg < 40 ? lg : 40);
+        if (ok && chunk < gran) chunk = gran;
+        if (ok) {
+            total = (bytes + chunk - 1) / chunk * chunk;
+            ok = hipMemAddressReserve(&va, total, chunk, nullptr, 0) == hipSuccess;
+            if (!ok) va = nullptr;
+        }
+        for (; ok && done < total; done += chunk) {
+            hipMemGenericAllocationHandle_t piece;
+            ok = hipMemCreate(&piece, chunk, &prop, 0) == hipSuccess;
+            if (!ok) break;
+            ok = hipMemMap((char*)va + done, chunk, 0, piece, 0) == hipSuccess;
+            (void)hipMemRelease(piece);   // (the mapping keeps the chunk alive; it goes with hipMemUnmap)
+            if (!ok) break;
+        }
+        if (ok) {
+            hipMemAccessDesc d{};
+            d.location = prop.location;
+            d.flags = hipMemAccessFlagsProtReadWrite;
+            ok = hipMemSetAccess(va, total, &d, 1) == hipSuccess;
+        }
+        if (ok) {
+            h->mapped.emplace_back(va, total);
+            return (u64*)va;
+        }
+        // undo what was mapped and fall back
+        if (va) {
+            if (done) (void)hipMemUnmap(va, done);
+            (void)hipMemAddressFree(va, total);
+        }
+        (void)hipGetLastError();
+    }
+    u64* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+void seen_set_free(kmc_handle* h, u64* p) {
+    if (!p) return;
+    for (size_t k = 0; k < h->mapped.size(); ++k)
+        if (h->mapped[k].first == (void*)p) {
+            (void)hipMemUnmap(p, h->mapped[k].second);
+            (void)hipMemAddressFree(p, h->mapped[k].second);
+            h->mapped.erase(h->mapped.begin() + (long)k);
+            return;
+        }
+    (void)hipFree(p);
+}
+
 KmcArgs base_args(kmc_handle* h, int ctl_slot) {
     KmcArgs a{};
     a.table = h->table;

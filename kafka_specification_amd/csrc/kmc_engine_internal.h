@@ -91,6 +91,7 @@ struct kmc_handle {
     int n_cus = 256;
     int blocks_per_cu = 4;  // k_expand residency, from the occupancy query at open
     u64 *table = nullptr, *pred = nullptr, *table2 = nullptr;
+    std::vector<std::pair<void*, size_t>> mapped;   // buffers that are mapped ranges of chunks, not hipMalloc's (seen_set_alloc): base, bytes
     u64* sent = nullptr;      // n_shards > 1: sender-side filter of fingerprints already shipped
     uint64_t sent_cap = 0;
     uint64_t table_cap = 0;      // slots
@@ -176,6 +177,9 @@ int launch(kmc_handle* h, hipFunction_t f, const KmcArgs& a, unsigned grid, hipS
 int ensure_mode(kmc_handle* h, unsigned mode);
 int launch_expand(kmc_handle* h, unsigned mode, const KmcArgs& a, unsigned grid, hipStream_t stream = nullptr, bool verify = false);
 int launch_inv(kmc_handle* h, const KmcArgs& a, uint64_t n);
+// the seen-set's memory: a range of addresses mapped from 8 MiB physical chunks (hipMalloc when that cannot be had) — see the definition
+u64* seen_set_alloc(kmc_handle* h, size_t bytes);
+void seen_set_free(kmc_handle* h, u64* p);
 KmcArgs base_args(kmc_handle* h, int ctl_slot);
 uint64_t max_fanout(const kmc_handle* h);
 unsigned expand_grid(kmc_handle* h, uint64_t n);

@@ -81,7 +81,7 @@ void kmc_close(kmc_handle* h) {   // (teardown: the HIP results are dropped on p
     }
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->table) (void)hipFree(h->table);
+    seen_set_free(h, h->table);
     if (h->pred) (void)hipFree(h->pred);
     if (h->table2) (void)hipFree(h->table2);
     if (h->sent) (void)hipFree(h->sent);
@@ -231,9 +231,10 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     h->table_cap = tcap;
     h->fcap = fcap;
     h->seg_cap = fcap / KMC_SEGS;
-    if (hipMalloc(&h->table, tcap * h->slot_words * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate %llu table slots", (unsigned long long)tcap);
+    if (!(h->table = seen_set_alloc(h, tcap * h->slot_words * 8))) return fail(KMC_E_NOMEM, "cannot allocate %llu table slots", (unsigned long long)tcap);
     if (getenv("KMC_VERBOSE"))
-        fprintf(stderr, "[kmc] seen-set: %llu slots x %llu B at %p\n", (unsigned long long)tcap, (unsigned long long)(h->slot_words * 8), (void*)h->table);
+        fprintf(stderr, "[kmc] seen-set: %llu slots x %llu B at %p (%s)\n", (unsigned long long)tcap, (unsigned long long)(h->slot_words * 8), (void*)h->table,
+                h->mapped.empty() ? "one hipMalloc" : "mapped from chunks");
     if (cfg->keep_trace && hipMalloc(&h->pred, tcap * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate predecessor table");
     for (int i = 0; i < 2; ++i)
         if (hipMalloc(&h->frontier[i], fcap * 8ull * h->planes) != hipSuccess)

@@ -27,7 +27,14 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
             return KMC_OK;
         };
         int rc0 = KMC_OK;
-        if (!strcmp(which, "table")) rc0 = move(h->table, h->table_cap * h->slot_words * 8);
+        if (!strcmp(which, "table")) {   // (through the seen-set's own allocator: chunks, or one hipMalloc under KMC_SEEN_SET_CHUNK_LOG2=0)
+            void* pad = nullptr;
+            (void)hipMalloc(&pad, 768ull << 20);
+            u64* q = seen_set_alloc(h, h->table_cap * h->slot_words * 8);
+            if (!q) return fail(KMC_E_NOMEM, "debug realloc");
+            seen_set_free(h, h->table);
+            h->table = q;
+        }
         else if (!strcmp(which, "f0")) rc0 = move(h->frontier[0], h->fcap * 8ull * h->planes);
         else if (!strcmp(which, "f1")) rc0 = move(h->frontier[1], h->fcap * 8ull * h->planes);
         else if (!strcmp(which, "ctl")) { u64* c = (u64*)h->ctl; rc0 = move(c, KMC_CTL_SLOTS * sizeof(KmcLevelCtl)); h->ctl = (KmcLevelCtl*)c; }
