@@ -290,7 +290,8 @@ def run_single(c, steps, warmup, symmetry=False, table=None, frontier=None):
     cfg = kmc.CheckerConfig(**c, device=0, symmetry=symmetry,
                             table_capacity=int(os.environ.get("KMC_BENCH_TABLE", table or ((3 << 27) if symmetry else (1 << 30)))),
                             frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", frontier or ((1 << 24) if symmetry else (1 << 26)))),
-                            wide_fingerprint=os.environ.get("KMC_BENCH_FP128", "0") == "1")   # tuning: 128-bit entries
+                            wide_fingerprint=os.environ.get("KMC_BENCH_FP128", "0") == "1",   # tuning: 128-bit entries
+                            keep_trace=os.environ.get("KMC_BENCH_TRACE", "0") == "1")         # tuning: the predecessor table of a CLI run
     results = []
     with kmc.ModelChecker(cfg) as mc:
         for _ in range(warmup):

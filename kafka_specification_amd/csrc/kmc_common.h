@@ -126,6 +126,9 @@ typedef unsigned int u32;
 #define KMC_FLAG_FP128 1024u  // the seen-set's slots are 16 bytes: the fingerprint and a second, independent 64-bit hash of the
                               // state (kmc_config.wide_fingerprint): a 64-bit collision is then recognised, not lost
 
+#define KMC_FLAG_PAIRED 4096u  // a run that keeps traces on 64-bit entries: the slots are 16 bytes, fingerprint + predecessor (KmcArgs::pred
+                               // = table + 1, both indexed 2 i) — the claim and its predecessor dirty ONE line instead of two random ones
+
 // A counter alone on its 128-byte line.  Device-scope atomics serialise per cache line at the
 // memory side (~90 M/s): eight "separate" 8-byte append counters packed into one 64-byte line were
 // still ONE hot spot — adjacent BFS levels of equal size ran 0.24 vs 0.18 ns/state depending only

@@ -73,8 +73,9 @@ int launch_inv(kmc_handle* h, const KmcArgs& a, uint64_t n) {
 // size of the physically contiguous pieces (the translation hardware's handling of huge fragments is the suspect: user space
 // cannot see more).  The frontiers gain nothing from it (streams) and stay hipMalloc's.  KMC_SEEN_SET_CHUNK_LOG2 overrides the
 // chunk (0: one hipMalloc); any failure of the mapping falls back to hipMalloc.
-u64* seen_set_alloc(kmc_handle* h, size_t bytes) {
-    static const int lg = getenv("KMC_SEEN_SET_CHUNK_LOG2") ? atoi(getenv("KMC_SEEN_SET_CHUNK_LOG2")) : 23;
+u64* seen_set_alloc(kmc_handle* h, size_t bytes, bool chunks) {
+    static const int lg_env = getenv("KMC_SEEN_SET_CHUNK_LOG2") ? atoi(getenv("KMC_SEEN_SET_CHUNK_LOG2")) : 23;
+    const int lg = chunks ? lg_env : 0;
     void* va = nullptr;
     size_t total = 0, done = 0;
     if (lg > 0) {
@@ -142,7 +143,7 @@ KmcArgs base_args(kmc_handle* h, int ctl_slot) {
     a.ctl = h->ctl + ctl_slot;
     a.seed = h->cfg.hash_seed;
     a.inv_mask = h->cfg.invariant_mask;
-    a.flags = (h->cfg.keep_trace ? KMC_FLAG_TRACE : 0u) | (h->slot_words == 2 ? KMC_FLAG_FP128 : 0u);
+    a.flags = (h->cfg.keep_trace ? KMC_FLAG_TRACE : 0u) | (h->slot_words == 2 ? KMC_FLAG_FP128 : 0u) | (h->paired ? KMC_FLAG_PAIRED : 0u);
     a.nshards = (uint32_t)h->cfg.n_shards;
     a.shard = (uint32_t)h->cfg.shard_id;
     a.rec_words = (uint32_t)h->rec_words;
@@ -266,8 +267,8 @@ int reset_run(kmc_handle* h) {
     }
     range_push("kmc clear seen-set %s", h->kname.c_str());
     HIP_TRY(hipEventRecord(h->ev_aux[0], h->stream));
-    HIP_TRY(hipMemsetAsync(h->table, 0, h->table_cap * h->slot_words * 8, h->stream));
-    if (h->pred) HIP_TRY(hipMemsetAsync(h->pred, 0, h->table_cap * 8, h->stream));
+    HIP_TRY(hipMemsetAsync(h->table, 0, h->table_cap * h->stride_words() * 8, h->stream));
+    if (h->pred && !h->paired) HIP_TRY(hipMemsetAsync(h->pred, 0, h->table_cap * 8, h->stream));
     HIP_TRY(hipEventRecord(h->ev_aux[1], h->stream));
     range_pop();
     h->clear_pending = true;   // (its duration is read where the stream is next waited for: do_begin)

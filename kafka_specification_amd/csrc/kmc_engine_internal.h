@@ -96,6 +96,9 @@ struct kmc_handle {
     uint64_t sent_cap = 0;
     uint64_t table_cap = 0;      // slots
     uint64_t slot_words = 1;     // 64-bit words per slot: 1, or 2 with kmc_config.wide_fingerprint (fingerprint + check word)
+    bool paired = false;         // keep_trace on 64-bit entries: 16-byte slots of fingerprint + predecessor (pred = table + 1, KMC_FLAG_PAIRED)
+    uint64_t stride_words() const { return paired ? 2 : slot_words; }        // words from one slot to the next
+    uint64_t pred_stride() const { return paired ? 2 : 1; }                  // ... and from one predecessor to the next
     uint64_t inserted_level = 0; // stepping: records handed to k_insert since the last kmc_step_finish (conservation check)
     u64* frontier[2] = {nullptr, nullptr};
     uint64_t fcap = 0;
@@ -178,7 +181,7 @@ int ensure_mode(kmc_handle* h, unsigned mode);
 int launch_expand(kmc_handle* h, unsigned mode, const KmcArgs& a, unsigned grid, hipStream_t stream = nullptr, bool verify = false);
 int launch_inv(kmc_handle* h, const KmcArgs& a, uint64_t n);
 // the seen-set's memory: a range of addresses mapped from 8 MiB physical chunks (hipMalloc when that cannot be had) — see the definition
-u64* seen_set_alloc(kmc_handle* h, size_t bytes);
+u64* seen_set_alloc(kmc_handle* h, size_t bytes, bool chunks = true);
 void seen_set_free(kmc_handle* h, u64* p);
 KmcArgs base_args(kmc_handle* h, int ctl_slot);
 uint64_t max_fanout(const kmc_handle* h);

@@ -82,9 +82,9 @@ void kmc_close(kmc_handle* h) {   // (teardown: the HIP results are dropped on p
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     seen_set_free(h, h->table);
-    if (h->pred) (void)hipFree(h->pred);
+    if (!h->paired) seen_set_free(h, h->pred);   // (paired: the predecessors are the slots' second words)
     if (h->table2) (void)hipFree(h->table2);
-    if (h->sent) (void)hipFree(h->sent);
+    seen_set_free(h, h->sent);
     if (h->frontier[0]) (void)hipFree(h->frontier[0]);
     if (h->frontier[1]) (void)hipFree(h->frontier[1]);
     if (h->ctl) (void)hipFree(h->ctl);
@@ -210,6 +210,17 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double budget = 0.85 * (double)free_b;
     h->slot_words = cfg->wide_fingerprint ? 2 : 1;
+    // A run that keeps traces on 64-bit entries stores a claim's predecessor in the claim's own slot (16-byte slots: fingerprint,
+    // predecessor) instead of a table of its own: the claim then dirties ONE random line, not two.  The second line cost a quarter
+    // of the headline's kernel wherever the predecessor table lay (k_expand 28.4 ms without traces, 34.6 - 36.4 with); in the slot:
+    // headline 34.9 -> 30.6 ms, BASELINE config 4 20.2 -> 18.3, same box, fresh processes, interleaved, counts exact (profiles/
+    // r06_chunked_seen_set.txt, items 7 - 8).  States of KMC_DEFER_MIN_WORDS words and more keep the separate table: their kernel
+    // issues a batch's first probe one flush early (kmc_kernels.h: DEFER), the paired slots take the undeferred walk, and at seven
+    // brokers that costs more than the second line (config 5, ten levels: 26.9 ms separate, 27.6 paired).  KMC_PAIRED_SLOTS=0
+    // restores the separate table everywhere (A/B), =2 forces the slots on wide states too; 128-bit entries keep it (their slot is full).
+    static const int paired_env = getenv("KMC_PAIRED_SLOTS") ? atoi(getenv("KMC_PAIRED_SLOTS")) : 1;
+    const bool paired_ok = paired_env == 2 || (paired_env == 1 && h->W < KMC_DEFER_MIN_WORDS);
+    h->paired = cfg->keep_trace && !cfg->wide_fingerprint && paired_ok;
     const uint64_t slot_bytes = 8 * h->slot_words + (cfg->keep_trace ? 8 : 0);
     // auto-sizing: half of the budget for the table; a shard also keeps a sender-side filter of twice the table
     // (0.15 + 0.30), two frontiers (2 x 0.09), a send area and a receive area (0.12 each)
@@ -231,11 +242,12 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     h->table_cap = tcap;
     h->fcap = fcap;
     h->seg_cap = fcap / KMC_SEGS;
-    if (!(h->table = seen_set_alloc(h, tcap * h->slot_words * 8))) return fail(KMC_E_NOMEM, "cannot allocate %llu table slots", (unsigned long long)tcap);
+    if (!(h->table = seen_set_alloc(h, tcap * h->stride_words() * 8))) return fail(KMC_E_NOMEM, "cannot allocate %llu table slots", (unsigned long long)tcap);
     if (getenv("KMC_VERBOSE"))
-        fprintf(stderr, "[kmc] seen-set: %llu slots x %llu B at %p (%s)\n", (unsigned long long)tcap, (unsigned long long)(h->slot_words * 8), (void*)h->table,
+        fprintf(stderr, "[kmc] seen-set: %llu slots x %llu B at %p (%s)\n", (unsigned long long)tcap, (unsigned long long)(h->stride_words() * 8), (void*)h->table,
                 h->mapped.empty() ? "one hipMalloc" : "mapped from chunks");
-    if (cfg->keep_trace && hipMalloc(&h->pred, tcap * 8) != hipSuccess) return fail(KMC_E_NOMEM, "cannot allocate predecessor table");
+    if (h->paired) h->pred = h->table + 1;
+    else if (cfg->keep_trace && !(h->pred = seen_set_alloc(h, tcap * 8))) return fail(KMC_E_NOMEM, "cannot allocate predecessor table");
     for (int i = 0; i < 2; ++i)
         if (hipMalloc(&h->frontier[i], fcap * 8ull * h->planes) != hipSuccess)
             return fail(KMC_E_NOMEM, "cannot allocate frontier of %llu states", (unsigned long long)fcap);
@@ -259,7 +271,7 @@ static int open_impl(const kmc_config* cfg, kmc_handle* h) {
     if (want_filter) {
         // it may meet up to ~2x as many distinct remote fingerprints as it owns
         h->sent_cap = pow2_floor(tcap * 2);   // (the filter's own index is a mask: first_time)
-        if (hipMalloc(&h->sent, h->sent_cap * 8) != hipSuccess) { h->sent = nullptr; h->sent_cap = 0; }  // optional
+        if (!(h->sent = seen_set_alloc(h, h->sent_cap * 8))) h->sent_cap = 0;  // optional (random probes and claims, like the seen-set's)
     }
     if (h->cfg.n_shards > 1) {
         uint64_t scap = cfg->send_capacity;

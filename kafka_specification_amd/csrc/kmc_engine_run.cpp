@@ -30,10 +30,11 @@ int kmc_run(kmc_handle* h, kmc_progress_cb cb, void* user) {
         if (!strcmp(which, "table")) {   // (through the seen-set's own allocator: chunks, or one hipMalloc under KMC_SEEN_SET_CHUNK_LOG2=0)
             void* pad = nullptr;
             (void)hipMalloc(&pad, 768ull << 20);
-            u64* q = seen_set_alloc(h, h->table_cap * h->slot_words * 8);
+            u64* q = seen_set_alloc(h, h->table_cap * h->stride_words() * 8);
             if (!q) return fail(KMC_E_NOMEM, "debug realloc");
             seen_set_free(h, h->table);
             h->table = q;
+            if (h->paired) h->pred = q + 1;
         }
         else if (!strcmp(which, "f0")) rc0 = move(h->frontier[0], h->fcap * 8ull * h->planes);
         else if (!strcmp(which, "f1")) rc0 = move(h->frontier[1], h->fcap * 8ull * h->planes);
@@ -221,11 +222,12 @@ static int run_levels(kmc_handle* h, kmc_progress_cb cb, void* user, bool fresh)
         a.fin = h->frontier[h->cur];
         a.fout = h->frontier[nxt];
         if (shadow) {  // tuning aid: the identical level first runs on a copy of the table, with KMC_XFLAGS applied
-            if (!h->table2) HIP_TRY(hipMalloc(&h->table2, h->table_cap * h->slot_words * 8));
-            HIP_TRY(hipMemcpyAsync(h->table2, h->table, h->table_cap * h->slot_words * 8, hipMemcpyDeviceToDevice, h->stream));
+            if (!h->table2) HIP_TRY(hipMalloc(&h->table2, h->table_cap * h->stride_words() * 8));
+            HIP_TRY(hipMemcpyAsync(h->table2, h->table, h->table_cap * h->stride_words() * 8, hipMemcpyDeviceToDevice, h->stream));
             HIP_TRY(hipMemsetAsync(h->ctl + 2, 0, sizeof(KmcLevelCtl), h->stream));
             KmcArgs x = a;
             x.table = h->table2;
+            if (h->paired) x.pred = h->table2 + 1;
             x.ctl = h->ctl + 2;
             x.flags |= getenv("KMC_XFLAGS") ? (uint32_t)atoi(getenv("KMC_XFLAGS")) : 0u;
             HIP_TRY(hipEventRecord(h->ev0, h->stream));
@@ -486,7 +488,7 @@ static int table_lookup(kmc_handle* h, uint64_t fp, uint64_t* slot) {
     uint64_t i = kmc_slot_of(fp, h->table_cap);
     for (uint64_t probes = 0; probes < h->table_cap; ++probes) {
         uint64_t v = 0;
-        HIP_TRY(hipMemcpy(&v, h->table + i * h->slot_words, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&v, h->table + i * h->stride_words(), 8, hipMemcpyDeviceToHost));
         // (with wide slots two distinct states may carry this fingerprint; the first one is reported — the check word
         // needs the state, which the callers of this lookup do not have)
         if (v == fp) {
@@ -528,7 +530,7 @@ int kmc_pred_of(kmc_handle* h, uint64_t fp, uint64_t* pred, int32_t* found) {
     *found = table_lookup(h, fp, &slot) == KMC_OK;
     g_err.clear();
     *pred = 0;
-    if (*found) HIP_TRY(hipMemcpy(pred, h->pred + slot, 8, hipMemcpyDeviceToHost));
+    if (*found) HIP_TRY(hipMemcpy(pred, h->pred + slot * h->pred_stride(), 8, hipMemcpyDeviceToHost));
     return KMC_OK;
 }
 
@@ -564,7 +566,7 @@ int kmc_trace(kmc_handle* h, uint8_t* canon_states, int32_t* kinds, uint64_t cap
         int rc = table_lookup(h, fp, &slot);
         if (rc) return rc;
         uint64_t p = 0;
-        HIP_TRY(hipMemcpy(&p, h->pred + slot, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&p, h->pred + slot * h->pred_stride(), 8, hipMemcpyDeviceToHost));
         if (p == 0) break;
         fp = p;
     }

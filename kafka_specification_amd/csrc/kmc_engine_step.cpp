@@ -7,12 +7,15 @@ using namespace kmc_engine;
 // predecessor table when traces are kept) and the current frontier's planes, segment by segment.
 namespace {
 struct CkptHeader {
-    char magic[8];          // "KMCCKPT6" (4: before round 5 changed the representative at four replicas; before canon_form.  5: before
+    char magic[8];          // "KMCCKPT7" (4: before round 5 changed the representative at four replicas; before canon_form.  5: before
                             // round 6 changed what a stored fingerprint MEANS — its home slot, kmc_slot_of, and for states of eight
                             // words and more the fingerprint itself, kmc_fingerprint: an older table would be searched in the wrong
-                            // places and the resumed search would claim its states a second time)
+                            // places and the resumed search would claim its states a second time.  6: before a run that keeps traces
+                            // on 64-bit entries stored the predecessors in the slots, has_pred = 2)
     kmc_config cfg;         // pointers inside are not meaningful in the file
-    uint64_t table_cap, fcap, seg_cap, level, n_cur, n_levels, w, has_pred;
+    uint64_t table_cap, fcap, seg_cap, level, n_cur, n_levels, w;
+    uint64_t has_pred;      // 0: no predecessors; 1: a table of their own follows the fingerprints; 2: 16-byte slots of fingerprint +
+                            // predecessor (kmc_handle::paired) — what the handle that loads the file must have too
     uint64_t layout_form;   // KmcLayout::rm of the packed states in the file (0 tight, 1 / 2 replica-major): the same constants
                             // can be packed in more than one way (KMC_LAYOUT), often into the same number of words
     uint64_t canon_form;    // kmc_config.symmetry: WHICH image of an orbit the stored states are — KMC_SYMM_UNROLLED_MAX of the build
@@ -20,6 +23,7 @@ struct CkptHeader {
                             // sorted one).  Round 5 moved it from 4 to 3 under an unchanged magic: a four-replica checkpoint of the
                             // older revision loaded cleanly and the resumed search claimed its orbits a second time
 };
+uint64_t pred_form(const kmc_handle* h) { return !h->pred ? 0u : h->paired ? 2u : 1u; }
 bool wr(FILE* f, const void* p, size_t n) { return fwrite(p, 1, n, f) == n; }
 bool rd(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n; }
 // device <-> file through a bounded pinned staging buffer
@@ -67,19 +71,19 @@ int kmc_checkpoint_save(kmc_handle* h, const char* path) {
     FILE* f = fopen(path, "wb");
     if (!f) return fail(KMC_E_ARG, "cannot open %s for writing", path);
     CkptHeader hd{};
-    memcpy(hd.magic, "KMCCKPT6", 8);
+    memcpy(hd.magic, "KMCCKPT7", 8);
     hd.cfg = h->cfg;
     hd.cfg.cache_dir = nullptr;
     hd.table_cap = h->table_cap; hd.fcap = h->fcap; hd.seg_cap = h->seg_cap; hd.level = h->level;
-    hd.n_cur = h->n_cur; hd.n_levels = h->levels.size(); hd.w = h->W; hd.has_pred = h->pred != nullptr;
+    hd.n_cur = h->n_cur; hd.n_levels = h->levels.size(); hd.w = h->W; hd.has_pred = pred_form(h);
     hd.layout_form = (uint64_t)h->lay.rm;
     hd.canon_form = (uint64_t)KMC_SYMM_UNROLLED_MAX;
     int rc = KMC_OK;
     bool ok = wr(f, &hd, sizeof hd) && wr(f, &h->res, sizeof h->res) && wr(f, h->levels.data(), h->levels.size() * 8) &&
               wr(f, h->seg_n, sizeof h->seg_n) && wr(f, h->init_words.data(), h->W * 8);
     if (!ok) rc = fail(KMC_E_STATE, "checkpoint: short write");
-    if (!rc) rc = dev_to_file(f, h->table, h->table_cap * h->slot_words);
-    if (!rc && h->pred) rc = dev_to_file(f, h->pred, h->table_cap);
+    if (!rc) rc = dev_to_file(f, h->table, h->table_cap * h->stride_words());
+    if (!rc && h->pred && !h->paired) rc = dev_to_file(f, h->pred, h->table_cap);
     for (int sg = 0; sg < KMC_SEGS && !rc; ++sg)
         for (int k = 0; k < h->planes && !rc; ++k)
             if (h->seg_n[sg])
@@ -96,7 +100,7 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
     if (!f) return fail(KMC_E_ARG, "cannot open %s", path);
     CkptHeader hd{};
     int rc = KMC_OK;
-    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT6", 8) != 0)
+    if (!rd(f, &hd, sizeof hd) || memcmp(hd.magic, "KMCCKPT7", 8) != 0)
         rc = fail(KMC_E_ARG, "%s is not a checkpoint of this version", path);
     const kmc_config& a = hd.cfg;
     const kmc_config& b = h->cfg;
@@ -109,9 +113,9 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
         rc = fail(KMC_E_ARG, "checkpoint was taken for a different model / constants / hash seed / shard / fingerprint width / "
                              "state layout / symmetry setting / orbit representative");
     if (!rc && (hd.table_cap != h->table_cap || hd.fcap != h->fcap || hd.seg_cap != h->seg_cap ||
-                hd.has_pred != (uint64_t)(h->pred != nullptr)))
+                hd.has_pred != pred_form(h)))
         rc = fail(KMC_E_ARG, "checkpoint capacities differ: open the handle with table_capacity=%llu frontier_capacity=%llu keep_trace=%d",
-                  (unsigned long long)hd.table_cap, (unsigned long long)hd.fcap, (int)hd.has_pred);
+                  (unsigned long long)hd.table_cap, (unsigned long long)hd.fcap, (int)(hd.has_pred != 0));
     // the file is not trusted: every size is checked against the handle before it sizes a buffer or a device copy
     if (!rc && (hd.n_levels == 0 || hd.n_levels > 4096 || hd.level != hd.n_levels || hd.n_cur > hd.fcap))
         rc = fail(KMC_E_ARG, "checkpoint header is inconsistent (levels %llu, level %llu, frontier %llu of %llu)",
@@ -153,8 +157,8 @@ int kmc_checkpoint_load(kmc_handle* h, const char* path) {
             h->init_words = init;
         }
     }
-    if (!rc) rc = file_to_dev(f, h->table, h->table_cap * h->slot_words);
-    if (!rc && h->pred) rc = file_to_dev(f, h->pred, h->table_cap);
+    if (!rc) rc = file_to_dev(f, h->table, h->table_cap * h->stride_words());
+    if (!rc && h->pred && !h->paired) rc = file_to_dev(f, h->pred, h->table_cap);
     h->cur = 0;
     for (int sg = 0; sg < KMC_SEGS && !rc; ++sg)
         for (int k = 0; k < h->planes && !rc; ++k)

@@ -152,6 +152,8 @@ template <class M> struct KmcSink {
     // r06_probe_steps.txt): headline 31.8 -> 31.5 ms, config 5 26.2 -> 25.6, the 6.45 G-state stretch 0.683 -> 0.657 s (narrow).
     //
     // A step comes in two halves so that a caller can put other work between the requests and their answers.
+    // SH = 1: 16-byte slots of fingerprint + predecessor (KMC_FLAG_PAIRED): slot i's fingerprint is word 2 i, a.pred = a.table + 1.
+    template <int SH = 0>
     static KMC_DEV void step_issue(const KmcArgsLocal& a, bool& active, u64 fp, u64& i, u64 v, bool& docas, u64& r_cas, u64& r_load) {
         active = active && v != fp;                 // v == fp: the state is in the table
         docas = active && v == 0;
@@ -167,25 +169,27 @@ template <class M> struct KmcSink {
         if (docas) {
 #if KMC_TUNING
             if (a.flags & KMC_FLAG_X_PLAINSTORE) {
-                a.table[i] = fp;
+                a.table[i << SH] = fp;
                 r_cas = 0;
             } else
 #endif
-            r_cas = atomicCAS(&a.table[i], 0ull, fp);
+            r_cas = atomicCAS(&a.table[i << SH], 0ull, fp);
         }
-        if (doload) r_load = a.table[i];
+        if (doload) r_load = a.table[i << SH];
     }
+    template <int SH = 0>
     static KMC_DEV bool step_resolve(const KmcArgsLocal& a, bool& active, u64 i, u64 meta, bool docas, u64 r_cas, u64 r_load, u64& v) {
         const bool won = docas && r_cas == 0;
         if (won) {
             active = false;
-            if (a.pred) a.pred[i] = meta;
+            if (a.pred) a.pred[i << SH] = meta;
         }
         v = docas ? r_cas : r_load;
         return won;
     }
     // Walks the chain of fp from slot i, of which the lane has seen v (called by the whole wave; the lanes with active = false
     // only take part in the ballots).  True when this lane claimed a slot: the state is new.
+    template <int SH = 0>
     static KMC_DEV bool claim_steps(const KmcArgsLocal& a, bool active, u64 fp, u64 i, u64 v, u64 meta) {
         bool won = false;
         const u64 max_probes = a.table_cap - 1 < (1ull << 10) ? a.table_cap - 1 : (1ull << 10);
@@ -197,8 +201,8 @@ template <class M> struct KmcSink {
             }
             bool docas;
             u64 r_cas, r_load;
-            step_issue(a, active, fp, i, v, docas, r_cas, r_load);
-            won = step_resolve(a, active, i, meta, docas, r_cas, r_load, v) || won;
+            step_issue<SH>(a, active, fp, i, v, docas, r_cas, r_load);
+            won = step_resolve<SH>(a, active, i, meta, docas, r_cas, r_load, v) || won;
         }
         return won;
     }
@@ -259,7 +263,7 @@ template <class M> struct KmcSink {
         return won;
     }
 
-    // The narrow or the wide table, as the handle was opened (a wave-uniform branch); the check word is the same fingerprint
+    // The narrow, the paired (fingerprint + predecessor) or the wide table, as the handle was opened (a wave-uniform branch); the check word is the same fingerprint
     // function under another seed.  Called by the whole wave: the lanes with valid = false only take part in the ballots.
     static KMC_DEV bool claim_any(const KmcArgsLocal& a, bool valid, const u64* t, u64 fp, u64 meta) {
         const u64 i = kmc_slot_of(fp, a.table_cap);
@@ -268,6 +272,7 @@ template <class M> struct KmcSink {
             if (valid) v = *(const KmcSlot2*)(a.table + 2 * i);
             return claim_wide_steps(a, valid, fp, kmc_fingerprint<W>(t, a.seed ^ 0x6a09e667f3bcc908ull), i, v, meta);
         }
+        if (a.flags & KMC_FLAG_PAIRED) return claim_steps<1>(a, valid, fp, i, valid ? a.table[2 * i] : fp, meta);
         return claim_steps(a, valid, fp, i, valid ? a.table[i] : fp, meta);
     }
 

@@ -420,7 +420,7 @@ def test_a_probe_step_sends_the_claims_and_the_next_loads_together(tmp_path):
     lines = [ln.split("//")[0].strip() for ln in body.splitlines()]
     ins = [ln for ln in lines if ln and not ln.endswith(":") and not ln.startswith("<")]
     cas = [i for i, o in enumerate(ins) if o.startswith("global_atomic_cmpswap")]
-    assert len(cas) >= 2, "the narrow and the wide walk each hold one compare-and-swap"
+    assert len(cas) >= 3, "the narrow, the paired (fingerprint + predecessor) and the wide walk each hold one compare-and-swap"
     for i in cas:
         nxt = next(j for j in range(i + 1, len(ins)) if ins[j].startswith("s_waitcnt") and "vmcnt" in ins[j])
         between = [o.split()[0] for o in ins[i + 1:nxt]]

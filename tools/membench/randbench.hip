@@ -18,6 +18,9 @@
 // Round 6: footprints beyond 2^30 slots (RANDBENCH_MAX_LOG2, up to 2^34 = 128 GiB), for the regime of the 6.45 G-state stretch;
 // RANDBENCH_ALIGN_GIB=1 places the table at a 1 GiB-aligned address inside a larger allocation (does the driver map it with
 // larger fragments then?); RANDBENCH_MODES=1,3,7 runs only those modes.
+// RANDBENCH_CHUNK_LOG2=23 (round 6, after the seen-set's own change): the table is a range of addresses mapped from physical chunks of
+// 2^23 bytes (hipMemAddressReserve + hipMemCreate / hipMemMap per chunk, as KmcEngine's seen_set_alloc does) instead of one hipMalloc:
+// the ceilings of the memory the product's seen-set now lies in.
 // Prints G accesses/s.  Build: hipcc --offload-arch=gfx950 -O3 randbench.hip -o randbench
 // Usage: randbench [first_mode [log2_slots ...]]  — with sizes given, every mode runs on a table of
 // each size (footprint sweep: does a seen-set partition that fits L2 / Infinity Cache probe faster?)
@@ -109,6 +112,40 @@ int main(int argc, char** argv) {
         u64* other;
         if (hipMalloc(&other, max_slots * 8) != hipSuccess) { printf("hipMalloc %d failed\n", k); return 1; }
     }
+    const int chunk_lg = getenv("RANDBENCH_CHUNK_LOG2") ? atoi(getenv("RANDBENCH_CHUNK_LOG2")) : 0;
+    if (chunk_lg > 0) {
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) { printf("no granularity\n"); return 1; }
+        size_t chunk = (size_t)1 << chunk_lg;
+        if (chunk < gran) chunk = gran;
+        const size_t total = (max_slots * 8 + chunk - 1) / chunk * chunk;
+        void* va = nullptr;
+        if (hipMemAddressReserve(&va, total, chunk, nullptr, 0) != hipSuccess) { printf("hipMemAddressReserve failed\n"); return 1; }
+        // RANDBENCH_SPREAD=k: k chunks are created per chunk kept, the others released after the last one is mapped - the kept ones
+        // then lie over k times the physical extent (does a table spread over more of the HBM take random writes faster still?)
+        const int spread = getenv("RANDBENCH_SPREAD") ? atoi(getenv("RANDBENCH_SPREAD")) : 1;
+        static hipMemGenericAllocationHandle_t extra[1 << 16];
+        size_t n_extra = 0;
+        for (size_t done = 0; done < total; done += chunk) {
+            hipMemGenericAllocationHandle_t piece;
+            if (hipMemCreate(&piece, chunk, &prop, 0) != hipSuccess || hipMemMap((char*)va + done, chunk, 0, piece, 0) != hipSuccess) { printf("chunk at %zu failed\n", done); return 1; }
+            (void)hipMemRelease(piece);
+            for (int s = 1; s < spread && n_extra < (1 << 16); ++s)
+                if (hipMemCreate(&extra[n_extra], chunk, &prop, 0) == hipSuccess) ++n_extra; else { printf("# spread: out of memory after %zu extra chunks\n", n_extra); break; }
+        }
+        for (size_t k = 0; k < n_extra; ++k) (void)hipMemRelease(extra[k]);
+        if (spread > 1) printf("# spread %d: %zu chunks created beside the table's and released\n", spread, n_extra);
+        hipMemAccessDesc d{};
+        d.location = prop.location;
+        d.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemSetAccess(va, total, &d, 1) != hipSuccess) { printf("hipMemSetAccess failed\n"); return 1; }
+        raw = (u64*)va;
+        printf("# table of 2^%d slots mapped from %zu chunks of %zu MiB (granularity %zu KiB)\n", max_log2, total / chunk, chunk >> 20, gran >> 10);
+    } else
     if (hipMalloc(&raw, max_slots * 8 + (align_gib ? (1ull << 30) : 0)) != hipSuccess) { printf("hipMalloc of 2^%d slots failed\n", max_log2); return 1; }
     table = align_gib ? (u64*)(((unsigned long long)raw + (1ull << 30) - 1) & ~((1ull << 30) - 1)) : raw;
     hipMalloc(&sink, 8);
