@@ -284,14 +284,15 @@ def cpu_baseline(c, budget_states, total_states, whole="the reachable set"):
     return out
 
 
-def run_single(c, steps, warmup, symmetry=False, table=None, frontier=None):
+def run_single(c, steps, warmup, symmetry=False, table=None, frontier=None, keep_trace=None):
     import kafka_specification_amd as kmc
     # (under symmetry the seen-set and the frontiers hold one state per orbit: a quarter of the slots keeps the same load)
     cfg = kmc.CheckerConfig(**c, device=0, symmetry=symmetry,
                             table_capacity=int(os.environ.get("KMC_BENCH_TABLE", table or ((3 << 27) if symmetry else (1 << 30)))),
                             frontier_capacity=int(os.environ.get("KMC_BENCH_FRONTIER", frontier or ((1 << 24) if symmetry else (1 << 26)))),
                             wide_fingerprint=os.environ.get("KMC_BENCH_FP128", "0") == "1",   # tuning: 128-bit entries
-                            keep_trace=os.environ.get("KMC_BENCH_TRACE", "0") == "1")         # tuning: the predecessor table of a CLI run
+                            # (predecessors for counterexample traces, what both CLIs keep by default: the traces_kept leg; env: tuning)
+                            keep_trace=(os.environ.get("KMC_BENCH_TRACE", "0") == "1") if keep_trace is None else keep_trace)
     results = []
     with kmc.ModelChecker(cfg) as mc:
         for _ in range(warmup):
@@ -574,6 +575,7 @@ def main():
                     help="the timed region runs the orbit-counting search (kmc_config.symmetry) instead of the plain one: for "
                          "profiling that kernel; the default line times the plain search and reports orbit counting beside it")
     ap.add_argument("--no-orbit-counting", action="store_true", help="skip the orbit_counting leg of the default line")
+    ap.add_argument("--no-traces-leg", action="store_true", help="skip the traces_kept leg (the headline with predecessors kept, as a CLI run keeps them)")
     ap.add_argument("--no-cold-start", action="store_true", help="skip the cold_start leg (one fresh CLI process, exec to exit)")
     ap.add_argument("--no-baseline-configs", action="store_true",
                     help="skip the baseline_configs legs (BASELINE.json configs 4 and 5 on one GPU, beside the headline)")
@@ -757,6 +759,24 @@ def main():
                          "note": "algorithmic bytes of the STORED states (the same per-state figure) over this search's "
                                  "k_expand time; the kernel is instruction-bound here (the representative of every successor "
                                  "is the smallest of its images under the permutations: profiles/r03_symmetry.txt)"}}
+    if (world == 1 and not a.symmetry and not a.level_budget and not a.no_traces_leg and not a.workload and not a.small
+            and os.environ.get("KMC_BENCH_TRACE", "0") != "1" and r.verdict == "ok"):
+        # The same check as a CLI user runs it: predecessors kept for counterexample traces (TLC always keeps them; `value` above
+        # is the search alone, as BASELINE.json's metric is).  Since round 6 a claim's predecessor is the second word of the claim's
+        # own 16-byte slot: one dirty line per claim, not two.  Never part of `value`.
+        try:
+            tres, tdt = run_single(c, a.config_steps, 1, keep_trace=True)
+            tr = tres[-1]
+            out["traces_kept"] = {
+                "ms_per_step": 1e3 * tdt / len(tres), "k_expand_ms": 1e3 * sum(x.seconds_expand for x in tres) / len(tres),
+                "clear_seen_set_ms": 1e3 * sum(getattr(x, "seconds_clear", 0.0) for x in tres) / len(tres),
+                "value": sum(x.distinct for x in tres) / tdt, "unit": "distinct states/s", "steps": len(tres),
+                "slowdown_over_the_search_alone": (tdt / len(tres)) / (dt / a.steps),
+                "every_count_equals_the_plain_run": ((tr.verdict, tr.distinct, tr.generated, tr.depth, tr.levels) ==
+                                                     (r.verdict, r.distinct, r.generated, r.depth, r.levels)),
+                "seen_set": "16-byte slots: fingerprint + predecessor (kmc_handle::paired)"}
+        except Exception as e:   # (a leg beside the headline never takes the line down)
+            out["traces_kept"] = {"error": repr(e)}
     if (world == 1 and not a.symmetry and not a.level_budget and not a.no_baseline_configs and not a.workload and not a.small):
         # SURVEY section 8d rows "config 4" and "config 5": driver-timed here, never part of `value`
         out["baseline_configs"] = {name: baseline_leg(name, a.config_steps, 1, with_cpu=not a.no_cpu_baseline) for name in BASELINE_LEGS}

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 export KMC_NO_TORCH=1
 # PROFILE_BENCH_ARGS: e.g. --symmetry (the orbit-counting search in the timed region); the default line's orbit_counting leg is
 # left out of a profiled run either way, so that every kmc_expand launch in the trace belongs to ONE search
-CMD="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-orbit-counting --no-cold-start --no-baseline-configs --no-stretch ${PROFILE_BENCH_ARGS:-}"
+CMD="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-orbit-counting --no-traces-leg --no-cold-start --no-baseline-configs --no-stretch ${PROFILE_BENCH_ARGS:-}"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1
 i=0
 # (the two *_DRAM_32B passes are the HBM byte count: on gfx950 FETCH_SIZE tallies a 128-byte read request as 64 bytes and
