@@ -84,33 +84,41 @@ u64* seen_set_alloc(kmc_handle* h, size_t bytes, bool chunks) {
         prop.location.type = hipMemLocationTypeDevice;
         prop.location.id = h->cfg.device;
         size_t gran = 0;
-        bool ok = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0;
+        const char* step = "hipMemGetAllocationGranularity";   // (the call that failed, for KMC_VERBOSE)
+        hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+        if (e == hipSuccess && gran == 0) e = hipErrorInvalidValue;
         size_t chunk = (size_t)1 << (lg < 40 ? lg : 40);
-        if (ok && chunk < gran) chunk = gran;
-        if (ok) {
+        if (e == hipSuccess && chunk < gran) chunk = gran;
+        if (e == hipSuccess) {
             total = (bytes + chunk - 1) / chunk * chunk;
-            ok = hipMemAddressReserve(&va, total, chunk, nullptr, 0) == hipSuccess;
-            if (!ok) va = nullptr;
+            step = "hipMemAddressReserve";
+            e = hipMemAddressReserve(&va, total, chunk, nullptr, 0);
+            if (e != hipSuccess) va = nullptr;
         }
-        for (; ok && done < total; done += chunk) {
+        for (; e == hipSuccess && done < total; done += chunk) {
             hipMemGenericAllocationHandle_t piece;
-            ok = hipMemCreate(&piece, chunk, &prop, 0) == hipSuccess;
-            if (!ok) break;
-            ok = hipMemMap((char*)va + done, chunk, 0, piece, 0) == hipSuccess;
+            step = "hipMemCreate";
+            if ((e = hipMemCreate(&piece, chunk, &prop, 0)) != hipSuccess) break;
+            step = "hipMemMap";
+            e = hipMemMap((char*)va + done, chunk, 0, piece, 0);
             (void)hipMemRelease(piece);   // (the mapping keeps the chunk alive; it goes with hipMemUnmap)
-            if (!ok) break;
+            if (e != hipSuccess) break;
         }
-        if (ok) {
+        if (e == hipSuccess) {
             hipMemAccessDesc d{};
             d.location = prop.location;
             d.flags = hipMemAccessFlagsProtReadWrite;
-            ok = hipMemSetAccess(va, total, &d, 1) == hipSuccess;
+            step = "hipMemSetAccess";
+            e = hipMemSetAccess(va, total, &d, 1);
         }
-        if (ok) {
+        if (e == hipSuccess) {
             h->mapped.emplace_back(va, total);
             return (u64*)va;
         }
         // undo what was mapped and fall back
+        if (getenv("KMC_VERBOSE"))
+            fprintf(stderr, "[kmc] seen-set memory: %s failed after %zu of %zu bytes in chunks of %zu (%s): falling back to one hipMalloc\n",
+                    step, done, total, chunk, hipGetErrorString(e));
         if (va) {
             if (done) (void)hipMemUnmap(va, done);
             (void)hipMemAddressFree(va, total);
@@ -125,8 +133,13 @@ void seen_set_free(kmc_handle* h, u64* p) {
     if (!p) return;
     for (size_t k = 0; k < h->mapped.size(); ++k)
         if (h->mapped[k].first == (void*)p) {
+            const double t0 = now_s();
             (void)hipMemUnmap(p, h->mapped[k].second);
+            const double t1 = now_s();
             (void)hipMemAddressFree(p, h->mapped[k].second);
+            if (getenv("KMC_VERBOSE"))
+                fprintf(stderr, "[kmc] released %.1f GiB of chunks: unmap %.3f s, address range %.3f s\n",
+                        (double)h->mapped[k].second / (double)(1ull << 30), t1 - t0, now_s() - t1);
             h->mapped.erase(h->mapped.begin() + (long)k);
             return;
         }
