@@ -66,12 +66,13 @@ int launch_inv(kmc_handle* h, const KmcArgs& a, uint64_t n) {
 // k_expand ran at one of three discrete levels — 28.4 / 30.5 / 31.5 ms with a 12 GiB table, 30.6 / 31.6 with 8 GiB — that followed
 // the table's allocation and nothing else (one handle, only the table moved: all three levels; profiles/r06_table_size_and_
 // placement.txt), with a hipMalloc of several GiB being a few huge physically contiguous blocks.  Mapped from 8 MiB chunks (HIP's
-// virtual-memory API: one range of addresses, every chunk its own physical allocation) the same table runs at the fast level in
-// every handle of every process: headline 31.3 - 31.6 -> 28.5 ms, BASELINE config 4 18.6 -> 16.8, config 4 at SURVEY's sizing
+// virtual-memory API: one range of addresses, every chunk its own physical allocation) the same table ran at the fast level in
+// every handle of every process of that box (and in most processes since - item 9 of the profile file has the exceptions: a level
+// per process and box remains, never worse than hipMalloc's slow one): headline 31.3 - 31.6 -> 28.5 ms, BASELINE config 4 18.6 -> 16.8, config 4 at SURVEY's sizing
 // 43.1 -> 38.7, config 5 25.6 -> 25.1 (it is bound by instructions), same box, interleaved, counts exact (profiles/r06_chunked_
 // seen_set.txt).  2 / 4 / 8 MiB chunks are alike, 32 MiB less steady, 1 - 2 GiB chunks behave like hipMalloc: what matters is the
-// size of the physically contiguous pieces (the translation hardware's handling of huge fragments is the suspect: user space
-// cannot see more).  The frontiers gain nothing from it (streams) and stay hipMalloc's.  KMC_SEEN_SET_CHUNK_LOG2 overrides the
+// size of the physically contiguous pieces, and what they change is the random WRITES (randbench in chunked memory: stores +30 %,
+// claims +16 %, loads nothing - profiles/r06_randbench.txt); why, user space cannot see.  The frontiers gain nothing from it (streams) and stay hipMalloc's.  KMC_SEEN_SET_CHUNK_LOG2 overrides the
 // chunk (0: one hipMalloc); any failure of the mapping falls back to hipMalloc.
 u64* seen_set_alloc(kmc_handle* h, size_t bytes, bool chunks) {
     static const int lg_env = getenv("KMC_SEEN_SET_CHUNK_LOG2") ? atoi(getenv("KMC_SEEN_SET_CHUNK_LOG2")) : 23;
