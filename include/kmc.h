@@ -90,7 +90,8 @@ typedef struct kmc_config {
     uint32_t invariant_mask;    /* KMC_INV_* bits to check on every new state */
     int32_t check_deadlock;     /* TLC default is on; these bounded models need it off (-deadlock) */
     int32_t continue_on_violation; /* TLC -continue: keep exploring after the first violation */
-    int32_t keep_trace;         /* keep predecessor fingerprints (8 B per table slot) for kmc_trace */
+    int32_t keep_trace;         /* keep predecessor fingerprints (8 B per table slot) for kmc_trace: the second word of the claim's own
+                                   16-byte slot on 64-bit entries of states below eight words, a table of their own otherwise */
     int32_t device;             /* HIP device ordinal; -1 = host-only handle (pack/unpack/fingerprint only) */
     int32_t n_shards;           /* 1 = single GPU; P>1: this handle owns fingerprints with owner(fp)==shard_id */
     int32_t shard_id;
