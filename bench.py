@@ -284,6 +284,9 @@ def cpu_baseline(c, budget_states, total_states, whole="the reachable set"):
     return out
 
 
+OPEN_S = []   # seconds every run_single handle of this process took to open, in order
+
+
 def run_single(c, steps, warmup, symmetry=False, table=None, frontier=None, keep_trace=None):
     import kafka_specification_amd as kmc
     # (under symmetry the seen-set and the frontiers hold one state per orbit: a quarter of the slots keeps the same load)
@@ -294,7 +297,9 @@ def run_single(c, steps, warmup, symmetry=False, table=None, frontier=None, keep
                             # (predecessors for counterexample traces, what both CLIs keep by default: the traces_kept leg; env: tuning)
                             keep_trace=(os.environ.get("KMC_BENCH_TRACE", "0") == "1") if keep_trace is None else keep_trace)
     results = []
+    t_open = time.perf_counter()
     with kmc.ModelChecker(cfg) as mc:
+        OPEN_S.append(time.perf_counter() - t_open)   # kmc_open: HIP start-up (a process's first handle), code object, allocation + spread
         for _ in range(warmup):
             mc.run()
         if torch is not None:
@@ -556,6 +561,13 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+# KMC_SEEN_SET_SPREAD (csrc/kmc_engine_core.cpp: seen_set_alloc) lays the seen-set's chunks over that many times their size of the HBM:
+# a table of physically scattered chunks runs at the fast level in every process (k_expand 28.4 - 29.2 ms), a table of chunks as they
+# come at the level its place in the HBM has (28.4 - 31.7: profiles/r06_chunked_seen_set.txt items 9 - 12).  It costs seconds per handle
+# at open and close, so it is not the library's default and this line does not set it either: the line measures the product as a user
+# gets it.  What the environment asked for is reported (config.seen_set_spread, open_s).
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -697,6 +709,8 @@ def main():
         "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "u64", "data": "synthetic (fully determined by model + constants; hash seed 0)",
         "config": {"workload": workload_name(c), "parallelism": parallelism, "state_bytes": S,
+                   "seen_set_spread": int(os.environ.get("KMC_SEEN_SET_SPREAD", "1")),   # set-up: the table's chunks lie over this many times its size (1: as they come)
+                   "open_s": OPEN_S[0] if OPEN_S else None,   # what opening the headline's handle took (HIP start-up, code object, allocation)
                    "distinct_states": distinct, "states_generated": generated, "seen_set_probes": probes, "depth": r.depth,
                    "verdict": r.verdict, "matches_oracle_golden": counts_match,
                    "exhausted": r.verdict != "level_limit", "level_budget": a.level_budget or None,

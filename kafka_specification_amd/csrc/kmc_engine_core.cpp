@@ -74,12 +74,39 @@ int launch_inv(kmc_handle* h, const KmcArgs& a, uint64_t n) {
 // size of the physically contiguous pieces, and what they change is the random WRITES (randbench in chunked memory: stores +30 %,
 // claims +16 %, loads nothing - profiles/r06_randbench.txt); why, user space cannot see.  The frontiers gain nothing from it (streams) and stay hipMalloc's.  KMC_SEEN_SET_CHUNK_LOG2 overrides the
 // chunk (0: one hipMalloc); any failure of the mapping falls back to hipMalloc.
+// SCATTERED chunks (the round's last finding, calls 34 - 38): chunks created one after the other are, on an unfragmented allocator,
+// physically consecutive, and a table of consecutive chunks is as fast as the place it happens to lie in - 28.5 to 34.4 G/s for the
+// seen-set's load + CAS mix, 22 to 30 G/s for random stores, 5.2 to 6.5 TB/s for a streaming fill, from one 8 GiB stretch of one
+// 128 GiB pool to the next (tools/membench/diversity) - which is the level a handle keeps for its life (call 34: one handle flat at
+// 30.4 ms for a minute while fresh processes between its searches went 28.7 -> 31.2 -> 28.7).  The same 1,024 chunks picked from ALL
+// over the pool run at 34.9 - 35.2 / 31.8 - 32.6 / 7.0 - 7.1 in every pool of every process: better than the best consecutive
+// stretch.  Creating sixteen times the chunks to keep one in sixteen costs seconds, though (16,384 hipMemCreate: 3.7 s, and a
+// fragmented allocator for whoever comes next: call 37), so the spread is bought with SPACERS: the table's chunks are created in
+// KMC_SCATTER_CLUSTERS clusters, and after each cluster ONE physical allocation of (spread - 1) x the cluster's size is created -
+// never mapped - that makes the allocator move on; the spacers go back as soon as the last chunk is mapped.  With KMC_SEEN_SET_SPREAD
+// = 16 / 32 the headline's k_expand is 28.4 - 29.2 in every process where the chunks as they come give 28.4 - 30.6 (call 38, same
+// box, interleaved; BASELINE config 4 16.8 - 17.0 against 16.9 - 18.6; = 4 is not enough).  It is NOT the default: owning 120 GiB
+// for a moment costs 0.3 - 3 s at open, and the driver wipes what is handed back - 1 - 3 s that land in this handle's close or
+// in the next process's allocations.  A search of seconds and more earns that back (KMC_SEEN_SET_SPREAD=16; bench.py's timed legs
+// set it and say so); the front end answering a 30 ms search does not.
+#ifndef KMC_SCATTER_CLUSTERS
+#define KMC_SCATTER_CLUSTERS 64
+#endif
+static int spread_factor(size_t need) {
+    static const int env = getenv("KMC_SEEN_SET_SPREAD") ? atoi(getenv("KMC_SEEN_SET_SPREAD")) : KMC_SEEN_SET_SPREAD_DEFAULT;
+    int f = env < 1 ? 1 : env > 64 ? 64 : env;
+    size_t free_b = 0, total_b = 0;
+    if (f > 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        while (f > 1 && (double)need * f > 0.8 * (double)free_b) --f;   // (the spacers live only until the table is mapped)
+    return f;
+}
 u64* seen_set_alloc(kmc_handle* h, size_t bytes, bool chunks) {
     static const int lg_env = getenv("KMC_SEEN_SET_CHUNK_LOG2") ? atoi(getenv("KMC_SEEN_SET_CHUNK_LOG2")) : 23;
     const int lg = chunks ? lg_env : 0;
     void* va = nullptr;
     size_t total = 0, done = 0;
     if (lg > 0) {
+        const double t0 = now_s();
         hipMemAllocationProp prop{};
         prop.type = hipMemAllocationTypePinned;
         prop.location.type = hipMemLocationTypeDevice;
@@ -90,13 +117,19 @@ u64* seen_set_alloc(kmc_handle* h, size_t bytes, bool chunks) {
         if (e == hipSuccess && gran == 0) e = hipErrorInvalidValue;
         size_t chunk = (size_t)1 << (lg < 40 ? lg : 40);
         if (e == hipSuccess && chunk < gran) chunk = gran;
+        std::vector<hipMemGenericAllocationHandle_t> spacers;
+        size_t n = 0, per_cluster = 0, spacer_bytes = 0;
         if (e == hipSuccess) {
             total = (bytes + chunk - 1) / chunk * chunk;
+            n = total / chunk;
             step = "hipMemAddressReserve";
             e = hipMemAddressReserve(&va, total, chunk, nullptr, 0);
             if (e != hipSuccess) va = nullptr;
+            const int spread = spread_factor(total);
+            per_cluster = (n + KMC_SCATTER_CLUSTERS - 1) / KMC_SCATTER_CLUSTERS;
+            spacer_bytes = spread > 1 && n >= 2 ? (size_t)(spread - 1) * per_cluster * chunk : 0;
         }
-        for (; e == hipSuccess && done < total; done += chunk) {
+        for (size_t j = 0; e == hipSuccess && j < n; ++j) {
             hipMemGenericAllocationHandle_t piece;
             step = "hipMemCreate";
             if ((e = hipMemCreate(&piece, chunk, &prop, 0)) != hipSuccess) break;
@@ -104,7 +137,14 @@ u64* seen_set_alloc(kmc_handle* h, size_t bytes, bool chunks) {
             e = hipMemMap((char*)va + done, chunk, 0, piece, 0);
             (void)hipMemRelease(piece);   // (the mapping keeps the chunk alive; it goes with hipMemUnmap)
             if (e != hipSuccess) break;
+            done += chunk;
+            if (spacer_bytes && (j + 1) % per_cluster == 0 && j + 1 < n) {   // a cluster is complete: make the allocator move on
+                hipMemGenericAllocationHandle_t sp;
+                if (hipMemCreate(&sp, spacer_bytes, &prop, 0) == hipSuccess) spacers.push_back(sp);
+                else { (void)hipGetLastError(); spacer_bytes = 0; }   // (no room: the rest of the table lies where it lies)
+            }
         }
+        for (hipMemGenericAllocationHandle_t sp : spacers) (void)hipMemRelease(sp);
         if (e == hipSuccess) {
             hipMemAccessDesc d{};
             d.location = prop.location;
@@ -114,6 +154,9 @@ u64* seen_set_alloc(kmc_handle* h, size_t bytes, bool chunks) {
         }
         if (e == hipSuccess) {
             h->mapped.emplace_back(va, total);
+            if (getenv("KMC_VERBOSE"))
+                fprintf(stderr, "[kmc] seen-set memory: %zu chunks of %zu MiB in clusters of %zu, %zu spacers of %.2f GiB between them, %.3f s\n", n,
+                        chunk >> 20, per_cluster, spacers.size(), (double)spacer_bytes / (double)(1ull << 30), now_s() - t0);
             return (u64*)va;
         }
         // undo what was mapped and fall back

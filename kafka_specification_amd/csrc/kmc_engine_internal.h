@@ -181,6 +181,10 @@ int ensure_mode(kmc_handle* h, unsigned mode);
 int launch_expand(kmc_handle* h, unsigned mode, const KmcArgs& a, unsigned grid, hipStream_t stream = nullptr, bool verify = false);
 int launch_inv(kmc_handle* h, const KmcArgs& a, uint64_t n);
 // the seen-set's memory: a range of addresses mapped from 8 MiB physical chunks (hipMalloc when that cannot be had) — see the definition
+#ifndef KMC_SEEN_SET_SPREAD_DEFAULT
+#define KMC_SEEN_SET_SPREAD_DEFAULT 1   // KMC_SEEN_SET_SPREAD: the seen-set's chunks lie over this many times their own size of the HBM
+                                        // (seen_set_alloc: spacers).  1 = as the chunks come: the spread costs seconds at open and close
+#endif
 u64* seen_set_alloc(kmc_handle* h, size_t bytes, bool chunks = true);
 void seen_set_free(kmc_handle* h, u64* p);
 KmcArgs base_args(kmc_handle* h, int ctl_slot);
