@@ -116,3 +116,50 @@ def test_checkpoint_of_a_trace_keeping_run_resumes_with_its_predecessors(tmp_pat
         assert (rest.verdict, rest.distinct, rest.generated, rest.depth) == (whole.verdict, whole.distinct, whole.generated, whole.depth)
         tr = mc.trace()
         assert len(tr) == len(whole_trace) and tr[0][1] == whole_trace[0][1]
+
+
+@pytest.mark.parametrize("spread", ["1", "4", "64", "1000"])
+@pytest.mark.parametrize("extra", [(), ("-notrace",)])
+def test_a_spread_seen_set_gives_the_same_search(spread, extra):
+    """KMC_SEEN_SET_SPREAD (opt-in; seen_set_alloc's spacers): the table's chunks are created in clusters with one unmapped
+    allocation between two clusters, released once the table is mapped.  Where the chunks lie changes no answer; the verbose line
+    says how many spacers there were (none at 1; one less than the chunks' clusters otherwise; the factor is clamped to 64)."""
+    r, got = cli({"KMC_SEEN_SET_SPREAD": spread}, *extra)
+    assert got == "mapped from chunks", r.stderr[-2000:]
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "1190091 states generated, 116281 distinct states found, 0 states left on queue." in r.stdout
+    m = re.search(r"\[kmc\] seen-set memory: (\d+) chunks of (\d+) MiB in clusters of (\d+), (\d+) spacers of ([\d.]+) GiB", r.stderr)
+    assert m, r.stderr[-2000:]
+    chunks, mib, per_cluster, spacers, gib = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5))
+    assert chunks * mib * (1 << 20) >= 64 * 100003 * 8 and per_cluster >= 1
+    if spread == "1":
+        assert spacers == 0
+    else:
+        clusters = (chunks + per_cluster - 1) // per_cluster
+        assert spacers == clusters - 1
+        assert abs(gib - (min(int(spread), 64) - 1) * per_cluster * mib / 1024) < 0.01
+
+
+def test_the_spacers_of_a_spread_seen_set_go_back_at_open():
+    """A handle opened with KMC_SEEN_SET_SPREAD=16 owns sixteen times its table for a moment; after kmc_open the device's free memory
+    is down by the handle's own buffers only (own process: the factor is read once)."""
+    code = (
+        "import ctypes, os\n"
+        "from kafka_specification_amd import CheckerConfig, ModelChecker\n"
+        "hip = ctypes.CDLL('libamdhip64.so'); f0, f1, t = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()\n"
+        "cfg = CheckerConfig(model='Kip320', n_replicas=3, log_size=2, max_records=2, max_leader_epoch=1,\n"
+        "                    invariants=('TypeOk', 'WeakIsr', 'StrongIsr'), table_capacity=1 << 27, frontier_capacity=1 << 20)\n"
+        "with ModelChecker(cfg) as mc: mc.run()\n"          # (context + code object paid for)
+        "assert hip.hipMemGetInfo(ctypes.byref(f0), ctypes.byref(t)) == 0\n"
+        "with ModelChecker(cfg) as mc:\n"
+        "    assert hip.hipMemGetInfo(ctypes.byref(f1), ctypes.byref(t)) == 0\n"
+        "    r = mc.run()\n"
+        "print('HELD', f0.value - f1.value, r.distinct, r.generated)\n")
+    r = subprocess.run(["python", "-c", code], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, KMC_SEEN_SET_SPREAD="16", KMC_VERBOSE="1"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert re.search(r" [1-9]\d* spacers of 0\.\d+ GiB", r.stderr), r.stderr[-1500:]
+    held, distinct, generated = map(int, re.search(r"HELD (-?\d+) (\d+) (\d+)", r.stdout).groups())
+    o = kmo.Run(kmo.make_config("Kip320", N=3, L=2, R=2, E=1, invariants=INV))
+    assert (distinct, generated) == (o.distinct, o.generated)
+    assert held < (4 << 30), held   # 1 GiB of table + frontiers; sixteen times the table would be 16 GiB
