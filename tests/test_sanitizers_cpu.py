@@ -44,8 +44,7 @@ def test_the_c_oracle_is_clean_under_the_sanitizers_and_counts_the_same(sanitize
     assert got == want
 
 
-@pytest.fixture(scope="module")
-def sanitized_emu():
+def build_sanitized_emu():
     exe = os.path.join(ROOT, "tests", "_host_emu_bfs_san")
     src = [os.path.join(ROOT, "tests", f) for f in ("host_emu_bfs.cpp", "host_emu.cpp")]
     csrc = os.path.join(ROOT, "kafka_specification_amd", "csrc")
@@ -55,6 +54,11 @@ def sanitized_emu():
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-DKMC_EMU_SMALL_TABLE", "-fsanitize=address,undefined",
                                "-fno-sanitize-recover=undefined", "-o", exe, src[0]], cwd=os.path.join(ROOT, "tests"))
     return exe
+
+
+@pytest.fixture(scope="module")
+def sanitized_emu():
+    return build_sanitized_emu()   # (tests/conftest.py builds it before pytest-xdist workers start: two must not write it at once)
 
 
 # (model id, name, N, L, R, E, K, invariants, KMC_LAYOUT_* of the compiled entry: 0 automatic = tight here, 2 replica-major with the
